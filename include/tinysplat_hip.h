@@ -1,0 +1,152 @@
+/*
+ * tinysplat_hip.h - C ABI of libtinysplat_hip.so (HIP, gfx950 / MI355X).
+ *
+ * This is the drop-in boundary below tinysplat's render adapter.  tinysplat reaches its rasterizer
+ * through three Python callables imported from the third-party gsplat package
+ * (/root/reference/tinysplat/splatting/rasterize.py:3-4):
+ *
+ *     project_gaussians(...)      rasterize.py:32   (13 positional args built at rasterize.py:64-73)
+ *     spherical_harmonics(...)    rasterize.py:38   (3 args built at rasterize.py:75-81)
+ *     rasterize_gaussians(...)    rasterize.py:44,50 (10 args built at rasterize.py:83-86)
+ *
+ * gsplat binds those callables to a C++/CUDA extension; the entry points below are what a binding
+ * for the same three callables (forward and backward) binds on MI355X.  Each group is labelled with
+ * the callable it implements.  tinysplat_amd/_lib.py is the ctypes binding, tinysplat_amd/ops.py the
+ * torch.autograd.Function layer that restores the exact Python signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all arrays are dense, row-major, float32 / int32 / uint64 as typed;
+ *   - `stream` is a hipStream_t passed as void*; every entry only enqueues work on it, never
+ *     synchronises, never allocates, never frees; workspaces are caller-provided;
+ *   - return value: 0 on success, a negative TS_E_* code for an argument error, otherwise the
+ *     positive hipError_t of the failed launch;
+ *   - tile = 16x16 pixels (rasterize.py:19-20).  `tile_row0/tile_rows` select a stripe of tile rows
+ *     [tile_row0, tile_row0 + tile_rows) for multi-GPU tile-stripe sharding; a single GPU passes
+ *     (0, tile_bounds_y).  Pixel coordinates stay global; image buffers hold only the stripe's rows.
+ */
+#ifndef TINYSPLAT_HIP_H
+#define TINYSPLAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_ABI_VERSION 1
+
+#define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
+#define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
+
+#define TS_TILE 16
+#define TS_SPLAT_RECORD_FLOATS 12   /* packed per-Gaussian record, see ts_pack_splats */
+#define TS_PARTIAL_ROW_FLOATS 12    /* per-(tile,Gaussian) gradient row, see ts_raster_bwd */
+
+int ts_abi_version(void);
+
+/* ---- camera block ---------------------------------------------------------------------------
+ * Scalars of rasterize.py:64-73 (fx, fy, cx, cy, img_height, img_width, tile_bounds, glob_scale)
+ * plus the near-plane threshold of gsplat's project_gaussians (clip_thresh, default 0.01). */
+typedef struct ts_camera {
+    float fx, fy, cx, cy;
+    int32_t img_width, img_height;
+    int32_t tile_bounds_x, tile_bounds_y;
+    int32_t tile_row0, tile_rows;
+    float glob_scale;
+    float clip_thresh;
+} ts_camera;
+
+/* ============================ project_gaussians (rasterize.py:32) ============================ */
+
+/* Forward.  viewmat: 12 floats (rows of the 3x4 view matrix, rasterize.py:73 passes
+ * view_matrix[:3,:]); projmat: 16 floats (P @ V).  Outputs are fully written for every Gaussian;
+ * culled ones (z <= clip, singular cov2d, no tile hit) get zeros. */
+int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const float* quats,
+                   const float* viewmat, const float* projmat, const ts_camera* cam_host,
+                   float* xys, float* depths, int32_t* radii, float* conics,
+                   int32_t* num_tiles_hit, float* cov3d, void* stream);
+
+/* Backward.  v_conic uses the true-partial convention for the off-diagonal entry.  v_cov3d may be
+ * NULL (tinysplat discards cov3d, rasterize.py:32).  Gaussians with radii == 0 receive zeros. */
+int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const float* quats,
+                   const float* viewmat, const float* projmat, const ts_camera* cam_host,
+                   const int32_t* radii, const float* v_xy, const float* v_depth,
+                   const float* v_conic, const float* v_cov3d,
+                   float* v_means3d, float* v_scales, float* v_quats, void* stream);
+
+/* ========================= gsplat.sh.spherical_harmonics (rasterize.py:38) ==================== */
+
+/* colors[n,3] = sum over bands <= degrees_to_use of Y_k(normalize(viewdirs)) * coeffs[n,k,:].
+ * num_bases = K of the stored coefficients (1,4,9,16,25). */
+int ts_sh_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* viewdirs,
+              const float* coeffs, float* colors, void* stream);
+
+/* v_coeffs[n,K,3]: Y_k * v_colors for active bands, zero for inactive ones (fully written). */
+int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* viewdirs,
+              const float* v_colors, float* v_coeffs, void* stream);
+
+/* ========================= rasterize_gaussians (rasterize.py:44,50) =========================== */
+/* Stage order: ts_scan_tiles -> (read total) -> ts_bin_count -> ts_tile_offsets -> ts_bin_scatter
+ * -> ts_sort_tiles -> ts_pack_splats -> ts_raster_fwd ; backward: ts_raster_bwd -> ts_reduce_partials */
+
+/* Inclusive int32 prefix sum of num_tiles_hit -> cum_tiles_hit[n]; the grand total (number of
+ * tile/Gaussian intersections I) is cum_tiles_hit[n-1].  scan_ws: >= ts_scan_ws_ints(n) int32. */
+int64_t ts_scan_ws_ints(int32_t n);
+int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hit,
+                  int32_t* scan_ws, void* stream);
+
+/* tile_count[t] = number of Gaussians whose tile rectangle covers stripe-local tile t
+ * (t = (ty - tile_row0) * tile_bounds_x + tx).  tile_count is zeroed by this call. */
+int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
+                 int32_t* tile_count, void* stream);
+
+/* Exclusive scan of tile_count -> tile_bins[t] = {start, end} (both 0 for an empty tile) and
+ * tile_cursor[t] = start.  num_tiles = tile_rows * tile_bounds_x. */
+int ts_tile_offsets(int32_t num_tiles, const int32_t* tile_count, int32_t* tile_bins,
+                    int32_t* tile_cursor, void* stream);
+
+/* Appends key = (float_bits(depth) << 32 | gaussian_id) to each covered tile's bucket of isect_keys
+ * (order inside a bucket is arbitrary until ts_sort_tiles).  tile_cursor is consumed. */
+int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
+                   const ts_camera* cam_host, int32_t* tile_cursor, uint64_t* isect_keys,
+                   void* stream);
+
+/* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort
+ * of (tile<<32 | depth-bits) keys emitted Gaussian-major - and writes gaussian_ids_sorted[I]. */
+int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_keys,
+                  int32_t* gaussian_ids_sorted, void* stream);
+
+/* Packs the per-Gaussian operands of the compositing kernels into one 48-byte record:
+ *   {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 | c2, c3, slot_base(int), bbox_w(int)}
+ * channels = 3 (colors[n,3]; c3 = 0) or 4 (colors[n,4]).  slot_base/bbox_w locate the
+ * (tile,Gaussian) row of the backward partial buffer: slot = slot_base + ty*bbox_w + tx. */
+int ts_pack_splats(int32_t n, int32_t channels, const float* xys, const int32_t* radii,
+                   const float* conics, const float* colors, const float* opacity,
+                   const int32_t* cum_tiles_hit, const ts_camera* cam_host, float* splats,
+                   void* stream);
+
+/* Front-to-back compositing.  out_img[rows,W,channels], final_Ts[rows,W], final_index[rows,W]
+ * where rows = min(16*tile_rows, H - 16*tile_row0).  background: `channels` floats. */
+int ts_raster_fwd(int32_t channels, const ts_camera* cam_host, const int32_t* tile_bins,
+                  const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
+                  float* out_img, float* final_Ts, int32_t* final_index, void* stream);
+
+/* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row per contributing (tile,Gaussian):
+ *   {v_x, v_y, v_opacity, v_conic.xx, v_conic.xy, v_conic.yy, v_c0, v_c1, v_c2, v_c3, 0, 0}
+ * partials[I,12] is zeroed by this call first.  v_out_alpha may be NULL. */
+int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam_host,
+                  const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
+                  const float* background, const float* final_Ts, const int32_t* final_index,
+                  const float* v_out_img, const float* v_out_alpha, float* partials, void* stream);
+
+/* Sums each Gaussian's rows (a contiguous range of `partials`, fixed order => run-to-run
+ * bit-reproducible gradients) into v_xy[n,2], v_conic[n,3], v_colors[n,channels], v_opacity[n]. */
+int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
+                       const int32_t* cum_tiles_hit, const float* partials, float* v_xy,
+                       float* v_conic, float* v_colors, float* v_opacity, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYSPLAT_HIP_H */

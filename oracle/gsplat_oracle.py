@@ -1,0 +1,464 @@
+"""CPU oracle for the tinysplat render hot path.  TEST INFRASTRUCTURE ONLY.
+
+    *** PARITY UNPINNED ***
+
+The arithmetic of this path is not in /root/reference: tinysplat imports it from the third-party
+``gsplat`` package (tinysplat/splatting/rasterize.py:3-4), which is neither vendored, nor pinned
+(no dependency manifest exists), nor installable here.  The call signatures tinysplat uses
+(rasterize.py:32,38,44,50,73,81,86) are those of the gsplat 0.1.x functional API, so this file
+restates the *published* 0.1.x algorithm (EWA projection of Zwicker et al. / Kerbl et al. 2023, 16x16
+tile binning with (tile<<32 | depth-bits) keys, front-to-back alpha compositing) and anchors itself on
+what the reference does hold: its call sites, argument conventions (scene.py:96-121,
+utils.py:7-13,41-73) and parameter layouts (model_gaussian.py:84-89).  There is no golden vector of
+gsplat output anywhere in the reference, so numbers are pinned only by the analytic known-answer
+tests in tests/test_oracle_kat.py and float64 gradcheck.
+
+Who may import this module: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg - as the
+checker / baseline, never as the product path (tinysplat_amd never imports it).
+
+Implementation notes
+  * Pure PyTorch, differentiable by plain autograd, dtype-generic (float32 or float64).
+  * The projection is written as explicit scalar-expanded elementwise expressions with a fixed
+    left-to-right association, no matmul and no fused multiply-add, so that a float32 run is
+    reproducible bit-for-bit by a HIP kernel compiled with fp-contraction off.  That is what makes
+    ``radii`` / ``num_tiles_hit`` / ``tile_bins`` / ``gaussian_ids_sorted`` checks bit-exact.
+  * Compile-time style switches of the open parity questions are module constants
+    (PIXEL_CENTER_OFFSET, ALPHA_CLAMP_BWD is not needed because autograd differentiates the forward).
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+BLOCK = 16                  # tile edge, tinysplat/splatting/rasterize.py:19-20
+CLIP_THRESH = 0.01          # near plane of gsplat 0.1.x project_gaussians (default clip_thresh)
+COV2D_BLUR = 0.3            # low-pass added to the 2D covariance diagonal
+ALPHA_MAX = 0.999           # forward alpha clamp
+ALPHA_MIN = 1.0 / 255.0     # contribution threshold
+T_EPS = 1e-4                # transmittance early-termination threshold
+PIXEL_CENTER_OFFSET = 0.0   # pixel (j, i) is sampled at (j + off, i + off); 0.1.3-era: 0
+
+SH_C0 = 0.28209479177387814          # == tinysplat/utils.py:8
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+         -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
+SH_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892,
+         0.10578554691520431, -0.6690465435572892, 0.47308734787878004, -1.7701307697799304,
+         0.6258357354491761)
+
+
+# --------------------------------------------------------------------------------------------------
+# SH helpers   (call sites: rasterize.py:76, model_gaussian.py:71,106)
+# --------------------------------------------------------------------------------------------------
+def num_sh_bases(degree: int) -> int:
+    if degree == 0:
+        return 1
+    if degree == 1:
+        return 4
+    if degree == 2:
+        return 9
+    if degree == 3:
+        return 16
+    return 25
+
+
+def deg_from_sh(num_bases: int) -> int:
+    table = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}
+    if num_bases not in table:
+        raise ValueError(f"Invalid number of SH bases: {num_bases}")
+    return table[num_bases]
+
+
+def sh_basis(degree: int, dirs: Tensor) -> Tensor:
+    """Real SH basis values [N, num_sh_bases(degree)] in the 3DGS sign/ordering convention."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    one = torch.ones_like(x)
+    cols = [SH_C0 * one]
+    if degree >= 1:
+        cols += [-SH_C1 * y, SH_C1 * z, -SH_C1 * x]
+    if degree >= 2:
+        xx, yy, zz = x * x, y * y, z * z
+        xy, yz, xz = x * y, y * z, x * z
+        cols += [SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2.0 * zz - xx - yy),
+                 SH_C2[3] * xz, SH_C2[4] * (xx - yy)]
+    if degree >= 3:
+        cols += [SH_C3[0] * y * (3.0 * xx - yy), SH_C3[1] * xy * z,
+                 SH_C3[2] * y * (4.0 * zz - xx - yy),
+                 SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy),
+                 SH_C3[4] * x * (4.0 * zz - xx - yy), SH_C3[5] * z * (xx - yy),
+                 SH_C3[6] * x * (xx - 3.0 * yy)]
+    if degree >= 4:
+        cols += [SH_C4[0] * xy * (xx - yy), SH_C4[1] * yz * (3.0 * xx - yy),
+                 SH_C4[2] * xy * (7.0 * zz - 1.0), SH_C4[3] * yz * (7.0 * zz - 3.0),
+                 SH_C4[4] * (zz * (35.0 * zz - 30.0) + 3.0), SH_C4[5] * xz * (7.0 * zz - 3.0),
+                 SH_C4[6] * (xx - yy) * (7.0 * zz - 1.0), SH_C4[7] * xz * (xx - 3.0 * yy),
+                 SH_C4[8] * (xx * (xx - 3.0 * yy) - yy * (3.0 * xx - yy))]
+    return torch.stack(cols, dim=-1)
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -> Tensor:
+    """gsplat.sh.spherical_harmonics as called at rasterize.py:38 with the args of rasterize.py:81.
+
+    colors[N,3] = sum_k Y_k(normalize(dir)) * coeffs[:,k,:] over the bands <= degrees_to_use.
+    No gradient flows to ``viewdirs`` (upstream's backward returns none), hence the detach.
+    """
+    if coeffs.dim() != 3 or coeffs.shape[-1] != 3:
+        raise ValueError("coeffs must be [N, K, 3]")
+    stored = deg_from_sh(coeffs.shape[-2])
+    if degrees_to_use > stored:
+        raise ValueError("degrees_to_use exceeds the degree of the stored coefficients")
+    d = viewdirs.detach()
+    d = d / torch.sqrt(d[:, 0:1] * d[:, 0:1] + d[:, 1:2] * d[:, 1:2] + d[:, 2:3] * d[:, 2:3])
+    basis = sh_basis(degrees_to_use, d)                       # [N, Ka]
+    ka = basis.shape[-1]
+    out = basis[:, 0:1] * coeffs[:, 0, :]
+    for k in range(1, ka):                                    # fixed accumulation order
+        out = out + basis[:, k:k + 1] * coeffs[:, k, :]
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# project_gaussians   (call site rasterize.py:32, args rasterize.py:64-73)
+# --------------------------------------------------------------------------------------------------
+def quat_to_rotmat_entries(quats: Tensor):
+    """(w,x,y,z) -> the nine entries of R; same formula as tinysplat/utils.py:41-73."""
+    w, x, y, z = quats[:, 0], quats[:, 1], quats[:, 2], quats[:, 3]
+    n = torch.sqrt(((w * w + x * x) + y * y) + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    r00 = 1.0 - 2.0 * (y * y + z * z)
+    r01 = 2.0 * (x * y - w * z)
+    r02 = 2.0 * (x * z + w * y)
+    r10 = 2.0 * (x * y + w * z)
+    r11 = 1.0 - 2.0 * (x * x + z * z)
+    r12 = 2.0 * (y * z - w * x)
+    r20 = 2.0 * (x * z - w * y)
+    r21 = 2.0 * (y * z + w * x)
+    r22 = 1.0 - 2.0 * (x * x + y * y)
+    return r00, r01, r02, r10, r11, r12, r20, r21, r22
+
+
+def tile_bbox(xys: Tensor, radii_f: Tensor, tile_bounds):
+    """Tile rectangle [min, max) of a (centre, radius) in tile units; C-style truncation then clamp."""
+    tbx, tby = float(tile_bounds[0]), float(tile_bounds[1])
+    tcx, tcy = xys[:, 0] / BLOCK, xys[:, 1] / BLOCK
+    tr = radii_f / BLOCK
+    minx = torch.clamp(torch.trunc(tcx - tr), 0.0, tbx)
+    maxx = torch.clamp(torch.trunc(tcx + tr + 1.0), 0.0, tbx)
+    miny = torch.clamp(torch.trunc(tcy - tr), 0.0, tby)
+    maxy = torch.clamp(torch.trunc(tcy + tr + 1.0), 0.0, tby)
+    return (minx.to(torch.int32), miny.to(torch.int32), maxx.to(torch.int32), maxy.to(torch.int32))
+
+
+def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+                      viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
+                      img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
+                      clip_thresh: float = CLIP_THRESH):
+    """-> (xys[N,2], depths[N], radii[N] i32, conics[N,3], num_tiles_hit[N] i32, cov3d[N,6]).
+
+    Culled Gaussians (behind the near plane, singular 2D covariance, no tile hit) have every output 0.
+    """
+    dt = means3d.dtype
+    V = viewmat.to(dt)
+    P = projmat.to(dt)
+    mx, my, mz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
+    # 1. view space
+    px = ((V[0, 0] * mx + V[0, 1] * my) + V[0, 2] * mz) + V[0, 3]
+    py = ((V[1, 0] * mx + V[1, 1] * my) + V[1, 2] * mz) + V[1, 3]
+    pz = ((V[2, 0] * mx + V[2, 1] * my) + V[2, 2] * mz) + V[2, 3]
+    in_front = pz > clip_thresh
+    pz_s = torch.where(in_front, pz, torch.ones_like(pz))     # safe denominator for culled lanes
+
+    # 2. cov3d = (R S)(R S)^T, upper triangle
+    r00, r01, r02, r10, r11, r12, r20, r21, r22 = quat_to_rotmat_entries(quats)
+    gs = torch.tensor(glob_scale, dtype=dt)
+    s0, s1, s2 = gs * scales[:, 0], gs * scales[:, 1], gs * scales[:, 2]
+    m00, m01, m02 = r00 * s0, r01 * s1, r02 * s2
+    m10, m11, m12 = r10 * s0, r11 * s1, r12 * s2
+    m20, m21, m22 = r20 * s0, r21 * s1, r22 * s2
+    c00 = (m00 * m00 + m01 * m01) + m02 * m02
+    c01 = (m00 * m10 + m01 * m11) + m02 * m12
+    c02 = (m00 * m20 + m01 * m21) + m02 * m22
+    c11 = (m10 * m10 + m11 * m11) + m12 * m12
+    c12 = (m10 * m20 + m11 * m21) + m12 * m22
+    c22 = (m20 * m20 + m21 * m21) + m22 * m22
+
+    # 3. EWA
+    fx_t = torch.tensor(fx, dtype=dt)
+    fy_t = torch.tensor(fy, dtype=dt)
+    W_t = torch.tensor(float(img_width), dtype=dt)
+    H_t = torch.tensor(float(img_height), dtype=dt)
+    limx = 1.3 * ((0.5 * W_t) / fx_t)
+    limy = 1.3 * ((0.5 * H_t) / fy_t)
+    tx = pz_s * torch.minimum(limx, torch.maximum(-limx, px / pz_s))
+    ty = pz_s * torch.minimum(limy, torch.maximum(-limy, py / pz_s))
+    rz = 1.0 / pz_s
+    rz2 = rz * rz
+    j00 = fx_t * rz
+    j02 = -(fx_t * tx) * rz2
+    j11 = fy_t * rz
+    j12 = -(fy_t * ty) * rz2
+    t00 = j00 * V[0, 0] + j02 * V[2, 0]
+    t01 = j00 * V[0, 1] + j02 * V[2, 1]
+    t02 = j00 * V[0, 2] + j02 * V[2, 2]
+    t10 = j11 * V[1, 0] + j12 * V[2, 0]
+    t11 = j11 * V[1, 1] + j12 * V[2, 1]
+    t12 = j11 * V[1, 2] + j12 * V[2, 2]
+    u0 = (t00 * c00 + t01 * c01) + t02 * c02
+    u1 = (t00 * c01 + t01 * c11) + t02 * c12
+    u2 = (t00 * c02 + t01 * c12) + t02 * c22
+    w0 = (t10 * c00 + t11 * c01) + t12 * c02
+    w1 = (t10 * c01 + t11 * c11) + t12 * c12
+    w2 = (t10 * c02 + t11 * c12) + t12 * c22
+    a = ((u0 * t00 + u1 * t01) + u2 * t02) + COV2D_BLUR
+    b = (u0 * t10 + u1 * t11) + u2 * t12
+    c = ((w0 * t10 + w1 * t11) + w2 * t12) + COV2D_BLUR
+
+    # 4. conic + radius
+    det = a * c - b * b
+    det_ok = det != 0
+    det_s = torch.where(det_ok, det, torch.ones_like(det))
+    inv_det = 1.0 / det_s
+    conic_x, conic_y, conic_z = c * inv_det, -b * inv_det, a * inv_det
+    mid = 0.5 * (a + c)
+    disc = torch.clamp(mid * mid - det, min=0.1)
+    sq = torch.sqrt(disc)
+    lam = torch.maximum(mid + sq, mid - sq)
+    radius = torch.ceil(3.0 * torch.sqrt(lam)).detach()
+
+    # 5. pixel centre
+    hx = ((P[0, 0] * mx + P[0, 1] * my) + P[0, 2] * mz) + P[0, 3]
+    hy = ((P[1, 0] * mx + P[1, 1] * my) + P[1, 2] * mz) + P[1, 3]
+    hw = ((P[3, 0] * mx + P[3, 1] * my) + P[3, 2] * mz) + P[3, 3]
+    rw = 1.0 / (hw + 1e-6)
+    cx_t = torch.tensor(cx, dtype=dt)
+    cy_t = torch.tensor(cy, dtype=dt)
+    x_pix = ((0.5 * W_t) * (hx * rw) + cx_t) - 0.5
+    y_pix = ((0.5 * H_t) * (hy * rw) + cy_t) - 0.5
+    xys = torch.stack([x_pix, y_pix], dim=-1)
+
+    # 6. tile bbox
+    pre_ok = in_front & det_ok
+    rad_s = torch.where(pre_ok, radius, torch.zeros_like(radius))
+    xys_s = torch.where(pre_ok[:, None], xys.detach(), torch.zeros_like(xys))
+    minx, miny, maxx, maxy = tile_bbox(xys_s, rad_s, tile_bounds)
+    nth = (maxx - minx) * (maxy - miny)
+    ok = pre_ok & (nth > 0)
+
+    zero = torch.zeros_like(pz)
+    okf = ok[:, None]
+    xys_o = torch.where(okf, xys, torch.zeros_like(xys))
+    depths_o = torch.where(ok, pz, zero)
+    conics_o = torch.where(okf, torch.stack([conic_x, conic_y, conic_z], dim=-1),
+                           torch.zeros(1, dtype=dt))
+    cov3d = torch.stack([c00, c01, c02, c11, c12, c22], dim=-1)
+    cov3d_o = torch.where(in_front[:, None], cov3d, torch.zeros(1, dtype=dt))
+    radii_o = torch.where(ok, radius, zero).to(torch.int32)
+    nth_o = torch.where(ok, nth, torch.zeros_like(nth)).to(torch.int32)
+    return xys_o, depths_o, radii_o, conics_o, nth_o, cov3d_o
+
+
+# --------------------------------------------------------------------------------------------------
+# binning + sort   (inside gsplat.rasterize_gaussians; call sites rasterize.py:44,50)
+# --------------------------------------------------------------------------------------------------
+def float_bits(depths: Tensor) -> Tensor:
+    """int64 holding the IEEE-754 float32 bit pattern (depth > 0, so bit order == float order)."""
+    return depths.detach().to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+
+
+def bin_and_sort(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tensor, tile_bounds):
+    """-> cum_tiles_hit[N] i32, isect_keys_sorted[I] i64, gaussian_ids_sorted[I] i32, tile_bins[T,2] i32.
+
+    key = (tile_id << 32) | float32 bits of depth; intersections are emitted Gaussian-major, tiles of
+    one Gaussian row-major, and sorted with a STABLE sort, i.e. ties in (tile, depth) break by
+    ascending Gaussian id.
+    """
+    n = xys.shape[0]
+    tbx, tby = int(tile_bounds[0]), int(tile_bounds[1])
+    num_tiles = tbx * tby
+    cum = torch.cumsum(num_tiles_hit.to(torch.int64), dim=0)
+    total = int(cum[-1]) if n > 0 else 0
+    tile_bins = torch.zeros(num_tiles, 2, dtype=torch.int32)
+    if total == 0:
+        return (cum.to(torch.int32), torch.zeros(0, dtype=torch.int64),
+                torch.zeros(0, dtype=torch.int32), tile_bins)
+    minx, miny, maxx, maxy = tile_bbox(xys.detach(), radii.to(xys.dtype), tile_bounds)
+    hit = radii > 0
+    w = torch.where(hit, maxx - minx, torch.zeros_like(minx)).to(torch.int64)
+    h = torch.where(hit, maxy - miny, torch.zeros_like(miny)).to(torch.int64)
+    cnt = w * h
+    if not torch.equal(cnt, num_tiles_hit.to(torch.int64)):
+        raise ValueError("num_tiles_hit is inconsistent with (xys, radii, tile_bounds)")
+    gid = torch.repeat_interleave(torch.arange(n, dtype=torch.int64), cnt)          # [I]
+    start = (cum - cnt)[gid]
+    local = torch.arange(total, dtype=torch.int64) - start
+    wg = w[gid]
+    ty = miny.to(torch.int64)[gid] + local // wg
+    tx = minx.to(torch.int64)[gid] + local % wg
+    tile_id = ty * tbx + tx
+    keys = (tile_id << 32) | float_bits(depths)[gid]
+    keys_sorted, perm = torch.sort(keys, stable=True)
+    gids_sorted = gid[perm].to(torch.int32)
+    tiles_sorted = keys_sorted >> 32
+    counts = torch.bincount(tiles_sorted, minlength=num_tiles)
+    ends = torch.cumsum(counts, dim=0)
+    starts = ends - counts
+    nz = counts > 0
+    tile_bins[:, 0] = torch.where(nz, starts, torch.zeros_like(starts)).to(torch.int32)
+    tile_bins[:, 1] = torch.where(nz, ends, torch.zeros_like(ends)).to(torch.int32)
+    return cum.to(torch.int32), keys_sorted, gids_sorted, tile_bins
+
+
+# --------------------------------------------------------------------------------------------------
+# rasterize_gaussians   (call sites rasterize.py:44,50, args rasterize.py:83-86)
+# --------------------------------------------------------------------------------------------------
+def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
+                        num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
+                        img_width: int, background: Tensor, return_aux: bool = False):
+    """-> (out_img[H,W,C], out_alpha[H,W]); with return_aux also a dict of final_Ts, final_index,
+    tile_bins, gaussian_ids_sorted and ``margin`` (per-pixel distance of the closest discrete decision
+    - alpha >= 1/255, next_T <= 1e-4 - to its threshold, relative; pixels with a tiny margin are the
+    ones where two correct float32 implementations may legitimately differ by a whole contribution).
+    """
+    if colors.dim() != 2 or xys.shape[0] != colors.shape[0]:
+        raise ValueError("colors must be [N, C]")
+    if opacity.dim() == 2:
+        opacity = opacity[:, 0]
+    dt = xys.dtype
+    H, W = int(img_height), int(img_width)
+    C = colors.shape[1]
+    tbx, tby = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+    _, _, gids, tile_bins = bin_and_sort(xys, depths, radii, num_tiles_hit, (tbx, tby, 1))
+    gids = gids.to(torch.int64)
+    bg = background.to(dt)
+
+    out_img = torch.zeros(H, W, C, dtype=dt) + bg            # empty tiles: T=1 -> background
+    out_alpha = torch.zeros(H, W, dtype=dt)
+    final_T = torch.ones(H, W, dtype=dt)
+    final_idx = torch.zeros(H, W, dtype=torch.int32)
+    margin = torch.full((H, W), float("inf"), dtype=torch.float64)
+    img_parts = {}
+
+    for t in range(tbx * tby):
+        s, e = int(tile_bins[t, 0]), int(tile_bins[t, 1])
+        if e <= s:
+            continue
+        ty, tx = divmod(t, tbx)
+        y0, x0 = ty * BLOCK, tx * BLOCK
+        y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
+        g = gids[s:e]
+        pxs = torch.arange(x0, x1, dtype=dt) + PIXEL_CENTER_OFFSET
+        pys = torch.arange(y0, y1, dtype=dt) + PIXEL_CENTER_OFFSET
+        PY, PX = torch.meshgrid(pys, pxs, indexing="ij")
+        PX, PY = PX.reshape(-1, 1), PY.reshape(-1, 1)           # [p,1]
+        gx, gy = xys[g, 0][None, :], xys[g, 1][None, :]          # [1,n]
+        con = conics[g]
+        dx, dy = gx - PX, gy - PY
+        sigma = 0.5 * (con[:, 0][None] * dx * dx + con[:, 2][None] * dy * dy) + con[:, 1][None] * dx * dy
+        raw = opacity[g][None, :] * torch.exp(-sigma)
+        alpha = torch.clamp(raw, max=ALPHA_MAX)
+        valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
+        a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+        next_T = torch.cumprod(1.0 - a_eff, dim=1)               # T after each Gaussian
+        stop = valid & (next_T <= T_EPS)
+        # first stopping index per pixel (n if none)
+        n = g.shape[0]
+        idxs = torch.arange(n)[None, :]
+        first_stop = torch.where(stop, idxs, torch.full_like(idxs, n)).min(dim=1, keepdim=True).values
+        live = valid & (idxs < first_stop)
+        T_before = torch.cat([torch.ones_like(next_T[:, :1]), next_T[:, :-1]], dim=1)
+        wgt = torch.where(live, a_eff * T_before, torch.zeros_like(a_eff))          # alpha * T
+        pix = wgt @ colors[g]                                                      # [p,C]
+        # final T = T in front of the stopping Gaussian (or after the last one)
+        T_ext = torch.cat([torch.ones_like(next_T[:, :1]), next_T], dim=1)          # [p,n+1]
+        T_fin = T_ext.gather(1, first_stop)[:, 0]
+        last = torch.where(live, idxs, torch.full_like(idxs, -1)).max(dim=1).values
+        f_idx = torch.where(last >= 0, last + s, torch.zeros_like(last))
+        hh, ww = y1 - y0, x1 - x0
+        img_parts[t] = (pix + T_fin[:, None] * bg).reshape(hh, ww, C)
+        out_alpha[y0:y1, x0:x1] = (1.0 - T_fin).reshape(hh, ww)
+        final_T[y0:y1, x0:x1] = T_fin.detach().reshape(hh, ww)
+        final_idx[y0:y1, x0:x1] = f_idx.to(torch.int32).reshape(hh, ww)
+        if return_aux:
+            with torch.no_grad():
+                seen = idxs <= first_stop                         # evaluated before/at termination
+                m_a = torch.where(seen & (sigma >= 0),
+                                  (raw.double() * 255.0 - 1.0).abs(), torch.full_like(raw, 1e30).double())
+                m_t = torch.where(seen & valid, (next_T.double() / T_EPS - 1.0).abs(),
+                                  torch.full_like(raw, 1e30).double())
+                mag = (0.5 * ((con[:, 0][None] * dx * dx).abs() + (con[:, 2][None] * dy * dy).abs())
+                       + (con[:, 1][None] * dx * dy).abs()).double()
+                m_s = torch.where(seen & (mag > 0), sigma.double().abs() / (mag + 1e-300),
+                                  torch.full_like(raw, 1e30).double())
+                m = torch.minimum(torch.minimum(m_a, m_t), m_s).min(dim=1).values
+                margin[y0:y1, x0:x1] = m.reshape(hh, ww)
+
+    if img_parts:
+        # assemble with differentiable ops (index_put on a cloned base keeps autograd intact)
+        rows = []
+        for ty in range(tby):
+            cols = []
+            for tx in range(tbx):
+                t = ty * tbx + tx
+                y0, x0 = ty * BLOCK, tx * BLOCK
+                y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
+                if t in img_parts:
+                    cols.append(img_parts[t])
+                else:
+                    cols.append(bg.expand(y1 - y0, x1 - x0, C))
+            rows.append(torch.cat(cols, dim=1))
+        out_img = torch.cat(rows, dim=0)
+    if return_aux:
+        aux = {"final_Ts": final_T, "final_index": final_idx, "tile_bins": tile_bins,
+               "gaussian_ids_sorted": gids.to(torch.int32), "margin": margin}
+        return out_img, out_alpha, aux
+    return out_img, out_alpha
+
+
+def rasterize_pixel_loop(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                         img_width, background):
+    """Scalar, per-pixel sequential restatement of the compositing loop (tiny cases only).  Used by
+    the tests to pin the vectorised ``rasterize_gaussians`` above to the algorithm as stated."""
+    H, W = int(img_height), int(img_width)
+    C = colors.shape[1]
+    tbx, tby = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+    _, _, gids, tile_bins = bin_and_sort(xys, depths, radii, num_tiles_hit, (tbx, tby, 1))
+    if opacity.dim() == 2:
+        opacity = opacity[:, 0]
+    out = torch.zeros(H, W, C, dtype=xys.dtype)
+    fT = torch.ones(H, W, dtype=xys.dtype)
+    fI = torch.zeros(H, W, dtype=torch.int32)
+    for i in range(H):
+        for j in range(W):
+            t = (i // BLOCK) * tbx + (j // BLOCK)
+            s, e = int(tile_bins[t, 0]), int(tile_bins[t, 1])
+            px, py = j + PIXEL_CENTER_OFFSET, i + PIXEL_CENTER_OFFSET
+            T = 1.0
+            cur = 0
+            acc = [0.0] * C
+            for idx in range(s, e):
+                g = int(gids[idx])
+                dx = float(xys[g, 0]) - px
+                dy = float(xys[g, 1]) - py
+                cxx, cxy, cyy = (float(conics[g, 0]), float(conics[g, 1]), float(conics[g, 2]))
+                sigma = 0.5 * (cxx * dx * dx + cyy * dy * dy) + cxy * dx * dy
+                alpha = min(ALPHA_MAX, float(opacity[g]) * math.exp(-sigma))
+                if sigma < 0 or alpha < ALPHA_MIN:
+                    continue
+                nT = T * (1.0 - alpha)
+                if nT <= T_EPS:
+                    break
+                vis = alpha * T
+                for ch in range(C):
+                    acc[ch] += float(colors[g, ch]) * vis
+                T = nT
+                cur = idx
+            for ch in range(C):
+                out[i, j, ch] = acc[ch] + T * float(background[ch])
+            fT[i, j] = T
+            fI[i, j] = cur
+    return out, 1.0 - fT, fT, fI

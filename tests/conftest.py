@@ -1,0 +1,50 @@
+import ctypes
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class HmCamera(ctypes.Structure):
+    _fields_ = [("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float),
+                ("cy", ctypes.c_float), ("W", ctypes.c_int), ("H", ctypes.c_int),
+                ("tbx", ctypes.c_int), ("tby", ctypes.c_int), ("row0", ctypes.c_int),
+                ("rows", ctypes.c_int), ("gs", ctypes.c_float), ("clip", ctypes.c_float)]
+
+
+@pytest.fixture(scope="session")
+def hostmath():
+    """g++ build of tests/hostmath/hostmath.cpp: the kernels' math header compiled for the host."""
+    d = ROOT / "tests" / "hostmath"
+    so = d / "_hostmath.so"
+    src = d / "hostmath.cpp"
+    hdr = ROOT / "tinysplat_amd" / "csrc" / "splat_math.h"
+    if (not so.exists()) or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", str(src),
+                        "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def fptr(t):
+    assert t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())

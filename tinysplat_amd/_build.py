@@ -1,0 +1,58 @@
+"""Builds libtinysplat_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libtinysplat_hip.so"
+
+# (source, extra flags).  project.hip must not contract a*b+c into fma: its float32 results are
+# checked bit-for-bit against the oracle (radii / num_tiles_hit drive bit-exact binning checks).
+SOURCES = [
+    ("project.hip", ["-ffp-contract=off"]),
+    ("binning.hip", ["-ffp-contract=off"]),
+    ("raster.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return exe
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    headers = [CSRC / "splat_math.h", CSRC.parent.parent / "include" / "tinysplat_hip.h"]
+    objs = []
+    for src, extra in SOURCES:
+        s = CSRC / src
+        o = CSRC / (Path(src).stem + ".o")
+        if force or _stale(o, [s, *headers]):
+            cmd = [hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(str(o))
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(verbose=True))

@@ -1,0 +1,87 @@
+"""ctypes binding of libtinysplat_hip.so (the C ABI declared in include/tinysplat_hip.h).
+
+There is no fallback: if the shared library is missing or does not export the full ABI, importing
+the ops raises.  Build it with ``python -m tinysplat_amd._build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
+ABI_VERSION = 1
+
+
+class TsCamera(ctypes.Structure):
+    """struct ts_camera of include/tinysplat_hip.h."""
+    _fields_ = [
+        ("fx", c_float), ("fy", c_float), ("cx", c_float), ("cy", c_float),
+        ("img_width", c_int32), ("img_height", c_int32),
+        ("tile_bounds_x", c_int32), ("tile_bounds_y", c_int32),
+        ("tile_row0", c_int32), ("tile_rows", c_int32),
+        ("glob_scale", c_float), ("clip_thresh", c_float),
+    ]
+
+
+_P = c_void_p  # every device pointer travels as an integer address
+_CAM = POINTER(TsCamera)
+
+# name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
+SIGNATURES = {
+    "ts_abi_version": (c_int32, []),
+    "ts_project_fwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_project_bwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_sh_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "ts_sh_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "ts_scan_ws_ints": (c_int64, [c_int32]),
+    "ts_scan_tiles": (c_int32, [c_int32, _P, _P, _P, _P]),
+    "ts_bin_count": (c_int32, [c_int32, _P, _P, _CAM, _P, _P]),
+    "ts_tile_offsets": (c_int32, [c_int32, _P, _P, _P, _P]),
+    "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
+    "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P]),
+    "ts_pack_splats": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P]),
+    "ts_raster_fwd": (c_int32, [c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_raster_bwd": (c_int32, [c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_reduce_partials": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Loads the library once; raises HipLibraryError (never falls back) when it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: tinysplat_amd has no CPU or PyTorch fallback. "
+            "Build it with `python -m tinysplat_amd._build` (needs hipcc, targets gfx950).")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.ts_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code == -1:
+        raise ValueError(f"{what}: bad argument (TS_E_BADARG)")
+    if code == -2:
+        raise ValueError(f"{what}: SH degree / number of bases not supported (TS_E_DEGREE)")
+    raise RuntimeError(f"{what}: HIP error {code}")

@@ -1,0 +1,345 @@
+// binning.hip - tile binning and per-tile depth sort for gfx950.
+//
+// What gsplat's rasterize_gaussians does before compositing (the part reached from
+// /root/reference/tinysplat/splatting/rasterize.py:44,50): cumsum(num_tiles_hit), emit one
+// (tile<<32 | depth bits, gaussian id) pair per covered tile, global 64-bit sort, bin edges.
+// Here the same final order (tile-major, then depth bits, ties by ascending Gaussian id) is produced
+// without a global sort:
+//   scan_tiles      wave-scan (DPP-free __shfl_up ladder inside a wave, LDS across the 4 waves)
+//   bin_count       one lane per Gaussian, hardware atomics on T tile counters
+//   tile_offsets    single-workgroup exclusive scan over tiles -> tile_bins, cursors
+//   bin_scatter     one lane per Gaussian, returning atomics on the cursors, 8-byte key stores
+//                   key = depth_bits << 32 | gaussian_id   (unique inside a tile)
+//   sort_tiles      one workgroup per tile: LDS bitonic network (flip/disperse form, all compares
+//                   ascending, so the tail of a non-power-of-two list needs no padding storage);
+//                   buckets larger than the LDS budget run the same network in global memory
+//   pack_splats     gathers the compositing operands of a Gaussian into one 48-byte record
+// Traffic: 8 I written + 8 I read + 4 I written (+ 2 I atomics) against the 36 I a 3-pass 64-bit
+// LSD radix sort of key+payload would move at minimum.
+#include <hip/hip_runtime.h>
+
+#include "../../include/tinysplat_hip.h"
+#include "splat_math.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kScanItems = 4;                       // per thread
+constexpr int kScanBlock = kThreads * kScanItems;   // 1024 elements per block
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+// block-wide inclusive scan of one int per thread (256 threads = 4 waves); returns inclusive value,
+// *total = block sum.
+__device__ __forceinline__ int block_inclusive_scan(int v, int* total) {
+    __shared__ int wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int s = wave_sums[w];
+        if (w < wave) add += s;
+    }
+    *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    __syncthreads();
+    return inc + add;
+}
+
+__global__ __launch_bounds__(kThreads) void scan_local_kernel(int n, const int* __restrict__ in,
+                                                              int* __restrict__ out,
+                                                              int* __restrict__ block_sums) {
+    const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        sum += v[k];
+        v[k] = sum;
+    }
+    int total;
+    const int inc = block_inclusive_scan(sum, &total);
+    const int excl = inc - sum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) out[base + k] = v[k] + excl;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of m ints
+__global__ __launch_bounds__(kThreads) void scan_sums_kernel(int m, int* __restrict__ sums) {
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += kThreads) {
+        const int i = base + threadIdx.x;
+        const int v = (i < m) ? sums[i] : 0;
+        int total;
+        const int inc = block_inclusive_scan(v, &total);
+        const int c = carry;
+        if (i < m) sums[i] = c + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restrict__ out,
+                                                            const int* __restrict__ block_excl) {
+    const int add = block_excl[blockIdx.x];
+    const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) out[base + k] += add;
+}
+
+__global__ __launch_bounds__(kThreads) void bin_count_kernel(int n, const float* __restrict__ xys,
+                                                             const int* __restrict__ radii,
+                                                             const ts_camera cam,
+                                                             int* __restrict__ tile_count) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+    const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
+                                        cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+    for (int ty = b.miny; ty < b.maxy; ++ty)
+        for (int tx = b.minx; tx < b.maxx; ++tx)
+            atomicAdd(&tile_count[(ty - cam.tile_row0) * cam.tile_bounds_x + tx], 1);
+}
+
+__global__ __launch_bounds__(kThreads) void tile_offsets_kernel(int num_tiles,
+                                                                const int* __restrict__ tile_count,
+                                                                int* __restrict__ tile_bins,
+                                                                int* __restrict__ tile_cursor) {
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < num_tiles; base += kThreads) {
+        const int t = base + threadIdx.x;
+        const int v = (t < num_tiles) ? tile_count[t] : 0;
+        int total;
+        const int inc = block_inclusive_scan(v, &total);
+        const int c = carry;
+        if (t < num_tiles) {
+            const int start = c + inc - v;
+            tile_cursor[t] = start;
+            reinterpret_cast<int2*>(tile_bins)[t] = v > 0 ? make_int2(start, start + v)
+                                                          : make_int2(0, 0);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bin_scatter_kernel(
+    int n, const float* __restrict__ xys, const float* __restrict__ depths,
+    const int* __restrict__ radii, const ts_camera cam, int* __restrict__ tile_cursor,
+    unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+    const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
+                                        cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint(depths[i]) << 32) | (unsigned int)i;
+    for (int ty = b.miny; ty < b.maxy; ++ty)
+        for (int tx = b.minx; tx < b.maxx; ++tx) {
+            const int pos = atomicAdd(&tile_cursor[(ty - cam.tile_row0) * cam.tile_bounds_x + tx], 1);
+            keys[pos] = key;
+        }
+}
+
+// ---- per-tile bitonic sort ---------------------------------------------------------------------
+constexpr int kSortCap = 4096;   // keys held in LDS (32 KiB); larger buckets sort in global memory
+
+template <typename Ptr>
+__device__ __forceinline__ void cmpswap(Ptr a, int i, int j) {
+    const unsigned long long x = a[i], y = a[j];
+    if (x > y) { a[i] = y; a[j] = x; }
+}
+
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_network(Ptr a, int n) {
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    const int half = npad >> 1;
+    for (int k = 2; k <= npad; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = threadIdx.x; p < half; p += kThreads) {          // flip
+            const int blk = p / hk, off = p - blk * hk;
+            const int i = blk * k + off, j = blk * k + k - 1 - off;
+            if (j < n) cmpswap(a, i, j);
+        }
+        __syncthreads();
+        for (int d = k >> 2; d >= 1; d >>= 1) {                       // disperse
+            for (int p = threadIdx.x; p < half; p += kThreads) {
+                const int i = 2 * d * (p / d) + (p % d), j = i + d;
+                if (j < n) cmpswap(a, i, j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
+    const int* __restrict__ tile_bins, unsigned long long* __restrict__ keys,
+    int* __restrict__ ids_sorted) {
+    __shared__ unsigned long long lk[kSortCap];
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
+    const int n = range.y - range.x;
+    if (n <= 0) return;
+    unsigned long long* g = keys + range.x;
+    int* out = ids_sorted + range.x;
+    if (n <= kSortCap) {
+        for (int i = threadIdx.x; i < n; i += kThreads) lk[i] = g[i];
+        __syncthreads();
+        bitonic_network(lk, n);
+        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = (int)(unsigned int)lk[i];
+    } else {
+        // one workgroup, one CU: the vector L1 is write-through and shared by the workgroup, a
+        // workgroup-scope fence + barrier orders the stages
+        volatile unsigned long long* vg = g;
+        __syncthreads();
+        bitonic_network(vg, n);
+        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = (int)(unsigned int)vg[i];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void pack_splats_kernel(
+    int n, int channels, const float* __restrict__ xys, const int* __restrict__ radii,
+    const float* __restrict__ conics, const float* __restrict__ colors,
+    const float* __restrict__ opacity, const int* __restrict__ cum_tiles_hit, const ts_camera cam,
+    float4* __restrict__ splats) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (r > 0) {
+        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
+                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+        const int w = b.maxx - b.minx, h = b.maxy - b.miny;
+        const int cnt = h > 0 ? w * h : 0;
+        const int excl = cum_tiles_hit[i] - cnt;
+        const int slot_base = excl - b.miny * w - b.minx;
+        q0 = make_float4(xy.x, xy.y, opacity[i], conics[3 * i]);
+        float c0, c1, c2, c3 = 0.0f;
+        if (channels == 4) {
+            const float4 c = reinterpret_cast<const float4*>(colors)[i];
+            c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+        } else {
+            c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2];
+        }
+        q1 = make_float4(conics[3 * i + 1], conics[3 * i + 2], c0, c1);
+        q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w));
+    }
+    splats[3 * (size_t)i] = q0;
+    splats[3 * (size_t)i + 1] = q1;
+    splats[3 * (size_t)i + 2] = q2;
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t ts_scan_ws_ints(int32_t n) {
+    return n <= 0 ? 1 : (int64_t)((n + kScanBlock - 1) / kScanBlock);
+}
+
+int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hit,
+                  int32_t* scan_ws, void* stream) {
+    if (n < 0) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!num_tiles_hit || !cum_tiles_hit || !scan_ws) return TS_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(kThreads), 0, s, n, num_tiles_hit,
+                       cum_tiles_hit, scan_ws);
+    if (nb > 1) {
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kThreads), 0, s, nb, scan_ws);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, n, cum_tiles_hit,
+                           scan_ws);
+    }
+    return launch_status();
+}
+
+int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
+                 int32_t* tile_count, void* stream) {
+    if (n < 0 || !cam || !tile_count) return TS_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = (size_t)cam->tile_rows * cam->tile_bounds_x;
+    hipError_t e = hipMemsetAsync(tile_count, 0, nt * sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    if (!xys || !radii) return TS_E_BADARG;
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       n, xys, radii, *cam, tile_count);
+    return launch_status();
+}
+
+int ts_tile_offsets(int32_t num_tiles, const int32_t* tile_count, int32_t* tile_bins,
+                    int32_t* tile_cursor, void* stream) {
+    if (num_tiles < 0) return TS_E_BADARG;
+    if (num_tiles == 0) return 0;
+    if (!tile_count || !tile_bins || !tile_cursor) return TS_E_BADARG;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
+                       num_tiles, tile_count, tile_bins, tile_cursor);
+    return launch_status();
+}
+
+int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
+                   const ts_camera* cam, int32_t* tile_cursor, uint64_t* isect_keys,
+                   void* stream) {
+    if (n < 0 || !cam) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!xys || !depths || !radii || !tile_cursor || !isect_keys) return TS_E_BADARG;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, n, xys, depths, radii, *cam, tile_cursor,
+                       reinterpret_cast<unsigned long long*>(isect_keys));
+    return launch_status();
+}
+
+int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_keys,
+                  int32_t* gaussian_ids_sorted, void* stream) {
+    if (num_tiles < 0) return TS_E_BADARG;
+    if (num_tiles == 0) return 0;
+    if (!tile_bins || !isect_keys || !gaussian_ids_sorted) return TS_E_BADARG;
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(num_tiles), dim3(kThreads), 0, (hipStream_t)stream,
+                       tile_bins, reinterpret_cast<unsigned long long*>(isect_keys),
+                       gaussian_ids_sorted);
+    return launch_status();
+}
+
+int ts_pack_splats(int32_t n, int32_t channels, const float* xys, const int32_t* radii,
+                   const float* conics, const float* colors, const float* opacity,
+                   const int32_t* cum_tiles_hit, const ts_camera* cam, float* splats,
+                   void* stream) {
+    if (n < 0 || !cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!xys || !radii || !conics || !colors || !opacity || !cum_tiles_hit || !splats)
+        return TS_E_BADARG;
+    hipLaunchKernelGGL(pack_splats_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, n, channels, xys, radii, conics, colors, opacity,
+                       cum_tiles_hit, *cam, reinterpret_cast<float4*>(splats));
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// project.hip - per-Gaussian streaming kernels for gfx950: EWA projection (fwd/bwd) and spherical
+// harmonics (fwd/bwd).  One lane per Gaussian; all four are HBM-bound (SURVEY.md 8(d) D5:
+// 96 N / 144 N / (24+12K) N bytes), so the work is in the access pattern, not the arithmetic:
+//   * [N,3]/[N,4]/[N,6] AoS rows are read/written with per-lane 12/16/24-byte accesses whose
+//     wave footprint is one contiguous 768 B..1.5 KiB span (every fetched line fully used);
+//   * SH coefficient rows (12*K bytes per Gaussian, 192 B at degree 3) are moved with 16-byte
+//     coalesced block transfers and transposed through LDS with an odd row stride, so the
+//     per-lane row walk is bank-conflict free.
+// This translation unit is compiled with -ffp-contract=off: project_fwd must reproduce the float32
+// oracle bit-for-bit (radii / num_tiles_hit feed bit-exact binning checks).
+#include <hip/hip_runtime.h>
+
+#include "../../include/tinysplat_hip.h"
+#include "splat_math.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ ts::Cam load_cam(const float* __restrict__ viewmat,
+                                            const float* __restrict__ projmat, const ts_camera c) {
+    ts::Cam C;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) C.v[i] = viewmat[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) C.p[i] = projmat[i];
+    C.fx = c.fx; C.fy = c.fy; C.cx = c.cx; C.cy = c.cy;
+    C.W = c.img_width; C.H = c.img_height; C.tbx = c.tile_bounds_x; C.tby = c.tile_bounds_y;
+    C.row0 = c.tile_row0; C.rows = c.tile_rows; C.gs = c.glob_scale; C.clip = c.clip_thresh;
+    return C;
+}
+
+__global__ __launch_bounds__(kThreads) void project_fwd_kernel(
+    int n, const float* __restrict__ means3d, const float* __restrict__ scales,
+    const float* __restrict__ quats, const float* __restrict__ viewmat,
+    const float* __restrict__ projmat, const ts_camera cam, float* __restrict__ xys,
+    float* __restrict__ depths, int* __restrict__ radii, float* __restrict__ conics,
+    int* __restrict__ num_tiles_hit, float* __restrict__ cov3d) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const ts::Cam C = load_cam(viewmat, projmat, cam);
+    const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
+    const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    ts::ProjOut o;
+    ts::project_one(C, m, s, q, o);
+    reinterpret_cast<float2*>(xys)[i] = make_float2(o.x, o.y);
+    depths[i] = o.depth;
+    radii[i] = o.radius;
+    conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
+    num_tiles_hit[i] = o.tiles;
+    float2* c3 = reinterpret_cast<float2*>(cov3d) + 3 * (size_t)i;
+    c3[0] = make_float2(o.cov3d[0], o.cov3d[1]);
+    c3[1] = make_float2(o.cov3d[2], o.cov3d[3]);
+    c3[2] = make_float2(o.cov3d[4], o.cov3d[5]);
+}
+
+__global__ __launch_bounds__(kThreads) void project_bwd_kernel(
+    int n, const float* __restrict__ means3d, const float* __restrict__ scales,
+    const float* __restrict__ quats, const float* __restrict__ viewmat,
+    const float* __restrict__ projmat, const ts_camera cam, const int* __restrict__ radii,
+    const float* __restrict__ v_xy, const float* __restrict__ v_depth,
+    const float* __restrict__ v_conic, const float* __restrict__ v_cov3d,
+    float* __restrict__ v_means3d, float* __restrict__ v_scales, float* __restrict__ v_quats) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    ts::ProjGrad g;
+    for (int k = 0; k < 3; ++k) { g.v_mean[k] = 0.0f; g.v_scale[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) g.v_quat[k] = 0.0f;
+    if (radii[i] > 0) {
+        const ts::Cam C = load_cam(viewmat, projmat, cam);
+        const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
+        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        const float2 vxy = reinterpret_cast<const float2*>(v_xy)[i];
+        const float vx[2] = {vxy.x, vxy.y};
+        const float vc[3] = {v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2]};
+        float vcov[6];
+        if (v_cov3d) {
+            for (int k = 0; k < 6; ++k) vcov[k] = v_cov3d[6 * (size_t)i + k];
+        }
+        ts::project_one_vjp(C, m, s, q, vx, v_depth[i], vc, v_cov3d ? vcov : nullptr, g);
+    }
+    v_means3d[3 * i] = g.v_mean[0]; v_means3d[3 * i + 1] = g.v_mean[1];
+    v_means3d[3 * i + 2] = g.v_mean[2];
+    v_scales[3 * i] = g.v_scale[0]; v_scales[3 * i + 1] = g.v_scale[1];
+    v_scales[3 * i + 2] = g.v_scale[2];
+    reinterpret_cast<float4*>(v_quats)[i] =
+        make_float4(g.v_quat[0], g.v_quat[1], g.v_quat[2], g.v_quat[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SH.  A block owns 256 consecutive Gaussians = one contiguous span of 256*3K floats of `coeffs`.
+// LDS row stride RSP = 3*Ka rounded up to an odd number of floats: lane t walks row t with
+// ds_read_b32 at (t*RSP + j) -> 32 distinct banks per half-wave.
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void sh_fwd_kernel(
+    int n, int num_bases, const float* __restrict__ viewdirs, const float* __restrict__ coeffs,
+    float* __restrict__ colors) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);       // active bases
+    constexpr int RS = 3 * KA;                      // active floats per row
+    constexpr int RSP = RS | 1;                     // odd LDS stride
+    extern __shared__ __align__(16) float lds[];
+    const int g0 = blockIdx.x * kThreads;
+    const int cnt = min(kThreads, n - g0);
+    const int tid = threadIdx.x;
+    const size_t row = 3 * (size_t)num_bases;       // stored floats per row
+    const float* src = coeffs + (size_t)g0 * row;
+    if (num_bases == KA && cnt == kThreads) {
+        // full rows, full block: 16-byte coalesced transfers of the whole span
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        constexpr int total4 = kThreads * RS / 4;
+        for (int f4 = tid; f4 < total4; f4 += kThreads) {
+            const float4 v = src4[f4];
+            const int f = 4 * f4;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ff = f + u;
+                lds[(ff / RS) * RSP + (ff % RS)] = e[u];
+            }
+        }
+    } else {
+        const int total = cnt * RS;
+        for (int f = tid; f < total; f += kThreads) {
+            const int g = f / RS, j = f % RS;
+            lds[g * RSP + j] = src[(size_t)g * row + j];
+        }
+    }
+    __syncthreads();
+    if (tid >= cnt) return;
+    const int i = g0 + tid;
+    float Y[KA];
+    ts::sh_basis(DEG, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+    const float* r = lds + tid * RSP;
+    float c0 = Y[0] * r[0], c1 = Y[0] * r[1], c2 = Y[0] * r[2];
+#pragma unroll
+    for (int k = 1; k < KA; ++k) {
+        c0 = c0 + Y[k] * r[3 * k];
+        c1 = c1 + Y[k] * r[3 * k + 1];
+        c2 = c2 + Y[k] * r[3 * k + 2];
+    }
+    colors[3 * i] = c0; colors[3 * i + 1] = c1; colors[3 * i + 2] = c2;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
+    int n, int num_bases, const float* __restrict__ viewdirs, const float* __restrict__ v_colors,
+    float* __restrict__ v_coeffs) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    extern __shared__ __align__(16) float lds[];
+    const int RS = 3 * num_bases;                   // full stored row (inactive bands get zeros)
+    const int RSP = RS | 1;
+    const int g0 = blockIdx.x * kThreads;
+    const int cnt = min(kThreads, n - g0);
+    const int tid = threadIdx.x;
+    if (tid < cnt) {
+        const int i = g0 + tid;
+        float Y[KA];
+        ts::sh_basis(DEG, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        const float v0 = v_colors[3 * i], v1 = v_colors[3 * i + 1], v2 = v_colors[3 * i + 2];
+        float* r = lds + tid * RSP;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            r[3 * k] = Y[k] * v0; r[3 * k + 1] = Y[k] * v1; r[3 * k + 2] = Y[k] * v2;
+        }
+        for (int j = 3 * KA; j < RS; ++j) r[j] = 0.0f;
+    }
+    __syncthreads();
+    float* dst = v_coeffs + (size_t)g0 * RS;
+    const int total = cnt * RS;
+    if ((total & 3) == 0) {
+        float4* dst4 = reinterpret_cast<float4*>(dst);    // g0*RS*4 bytes is a multiple of 16
+        for (int f4 = tid; f4 < total / 4; f4 += kThreads) {
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ff = 4 * f4 + u;
+                e[u] = lds[(ff / RS) * RSP + (ff % RS)];
+            }
+            dst4[f4] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    } else {
+        for (int f = tid; f < total; f += kThreads) dst[f] = lds[(f / RS) * RSP + (f % RS)];
+    }
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int ts_abi_version(void) { return TS_ABI_VERSION; }
+
+int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const float* quats,
+                   const float* viewmat, const float* projmat, const ts_camera* cam,
+                   float* xys, float* depths, int32_t* radii, float* conics,
+                   int32_t* num_tiles_hit, float* cov3d, void* stream) {
+    if (n < 0 || !cam) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!means3d || !scales || !quats || !viewmat || !projmat || !xys || !depths || !radii ||
+        !conics || !num_tiles_hit || !cov3d)
+        return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, viewmat, projmat, *cam, xys, depths, radii, conics,
+                       num_tiles_hit, cov3d);
+    return launch_status();
+}
+
+int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const float* quats,
+                   const float* viewmat, const float* projmat, const ts_camera* cam,
+                   const int32_t* radii, const float* v_xy, const float* v_depth,
+                   const float* v_conic, const float* v_cov3d, float* v_means3d, float* v_scales,
+                   float* v_quats, void* stream) {
+    if (n < 0 || !cam) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!means3d || !scales || !quats || !viewmat || !projmat || !radii || !v_xy || !v_depth ||
+        !v_conic || !v_means3d || !v_scales || !v_quats)
+        return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, viewmat, projmat, *cam, radii, v_xy, v_depth,
+                       v_conic, v_cov3d, v_means3d, v_scales, v_quats);
+    return launch_status();
+}
+
+static int sh_check(int32_t n, int32_t degree, int32_t num_bases) {
+    if (n < 0) return TS_E_BADARG;
+    if (num_bases != 1 && num_bases != 4 && num_bases != 9 && num_bases != 16 && num_bases != 25)
+        return TS_E_DEGREE;
+    if (degree < 0 || degree > 4 || (degree + 1) * (degree + 1) > num_bases) return TS_E_DEGREE;
+    return 0;
+}
+
+int ts_sh_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* viewdirs,
+              const float* coeffs, float* colors, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!viewdirs || !coeffs || !colors) return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
+    const size_t lds = (size_t)kThreads * ((3 * ka) | 1) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_SH_FWD(D)                                                                          \
+    hipLaunchKernelGGL(sh_fwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n, num_bases,     \
+                       viewdirs, coeffs, colors)
+    switch (degrees_to_use) {
+        case 0: TS_SH_FWD(0); break;
+        case 1: TS_SH_FWD(1); break;
+        case 2: TS_SH_FWD(2); break;
+        case 3: TS_SH_FWD(3); break;
+        default: {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_fwd_kernel<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            TS_SH_FWD(4);
+        } break;
+    }
+#undef TS_SH_FWD
+    return launch_status();
+}
+
+int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* viewdirs,
+              const float* v_colors, float* v_coeffs, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!viewdirs || !v_colors || !v_coeffs) return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    const size_t lds = (size_t)kThreads * ((3 * num_bases) | 1) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_SH_BWD(D)                                                                          \
+    do {                                                                                      \
+        if (lds > 48 * 1024)                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_bwd_kernel<D>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(sh_bwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n, num_bases, \
+                           viewdirs, v_colors, v_coeffs);                                     \
+    } while (0)
+    switch (degrees_to_use) {
+        case 0: TS_SH_BWD(0); break;
+        case 1: TS_SH_BWD(1); break;
+        case 2: TS_SH_BWD(2); break;
+        case 3: TS_SH_BWD(3); break;
+        default: TS_SH_BWD(4); break;
+    }
+#undef TS_SH_BWD
+    return launch_status();
+}
+
+}  // extern "C"

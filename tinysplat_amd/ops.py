@@ -1,0 +1,392 @@
+"""The three differentiable callables tinysplat imports from gsplat, served by the HIP library.
+
+Signatures are exactly those tinysplat uses (gsplat 0.1.x functional API):
+
+    project_gaussians   /root/reference/tinysplat/splatting/rasterize.py:32  (13 positional args, 6 returns)
+    spherical_harmonics rasterize.py:38                                      (3 args, 1 return)
+    rasterize_gaussians rasterize.py:44,50                                   (10 args, 2-tuple return)
+    num_sh_bases / deg_from_sh   rasterize.py:76, model_gaussian.py:71,106
+
+Every op runs on the HIP device of its inputs, on torch's current stream, through the C ABI of
+include/tinysplat_hip.h.  There is NO CPU path and NO PyTorch fallback: CPU tensors raise, and a
+missing libtinysplat_hip.so raises at the first call.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import TsCamera
+
+BLOCK = 16            # rasterize.py:19-20
+CLIP_THRESH = 0.01    # gsplat's default near-plane threshold for project_gaussians
+
+
+# --------------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------------
+def num_sh_bases(degree: int) -> int:
+    """Number of SH bases of a degree (call sites rasterize.py:76, model_gaussian.py:71)."""
+    if degree == 0:
+        return 1
+    if degree == 1:
+        return 4
+    if degree == 2:
+        return 9
+    if degree == 3:
+        return 16
+    return 25
+
+
+def deg_from_sh(num_bases: int) -> int:
+    """Inverse of num_sh_bases (call site model_gaussian.py:106); raises on an invalid count."""
+    for deg, nb in ((0, 1), (1, 4), (2, 9), (3, 16), (4, 25)):
+        if nb == num_bases:
+            return deg
+    raise ValueError(f"Invalid number of SH bases: {num_bases}")
+
+
+def _need_hip(*tensors: Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if not isinstance(t, Tensor):
+            raise TypeError("expected torch tensors")
+        if not t.is_cuda:
+            raise RuntimeError(
+                "tinysplat_amd ops run only on a HIP (cuda) device; got a CPU tensor. "
+                "There is deliberately no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("all tensors must live on the same device")
+    return dev
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        raise ValueError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _i32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.int32:
+        raise ValueError(f"expected int32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _camera(fx, fy, cx, cy, img_height, img_width, tile_bounds, glob_scale=1.0,
+            clip_thresh=CLIP_THRESH, tile_rows: Optional[Tuple[int, int]] = None) -> TsCamera:
+    tbx, tby = int(tile_bounds[0]), int(tile_bounds[1])
+    if tile_rows is None:
+        row0, rows = 0, tby
+    else:
+        row0, rows = int(tile_rows[0]), int(tile_rows[1]) - int(tile_rows[0])
+        if row0 < 0 or rows < 0 or row0 + rows > tby:
+            raise ValueError(f"tile_rows {tile_rows} outside [0, {tby}]")
+    return TsCamera(float(fx), float(fy), float(cx), float(cy), int(img_width), int(img_height),
+                    tbx, tby, row0, rows, float(glob_scale), float(clip_thresh))
+
+
+def _tile_bounds(img_height: int, img_width: int) -> Tuple[int, int, int]:
+    return ((img_width + BLOCK - 1) // BLOCK, (img_height + BLOCK - 1) // BLOCK, 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# project_gaussians
+# --------------------------------------------------------------------------------------------------
+class _ProjectGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy,
+                img_height, img_width, tile_bounds, clip_thresh, tile_rows):
+        dev = _need_hip(means3d, scales, quats, viewmat, projmat)
+        n = means3d.shape[0]
+        if means3d.shape != (n, 3) or scales.shape != (n, 3) or quats.shape != (n, 4):
+            raise ValueError("means3d [N,3], scales [N,3], quats [N,4] expected")
+        if viewmat.numel() < 12 or projmat.shape != (4, 4):
+            raise ValueError("viewmat must hold the 3x4 view rows, projmat must be [4,4]")
+        means3d, scales, quats = _f32c(means3d), _f32c(scales), _f32c(quats)
+        viewmat, projmat = _f32c(viewmat), _f32c(projmat)
+        cam = _camera(fx, fy, cx, cy, img_height, img_width, tile_bounds, glob_scale, clip_thresh,
+                      tile_rows)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        xys = torch.empty((n, 2), **f32)
+        depths = torch.empty((n,), **f32)
+        radii = torch.empty((n,), **i32)
+        conics = torch.empty((n, 3), **f32)
+        nth = torch.empty((n,), **i32)
+        cov3d = torch.empty((n, 6), **f32)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_project_fwd(n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
+                                          _ptr(projmat), cam, _ptr(xys), _ptr(depths), _ptr(radii),
+                                          _ptr(conics), _ptr(nth), _ptr(cov3d), _stream(dev)),
+                       "ts_project_fwd")
+        ctx.cam = cam
+        ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii)
+        ctx.mark_non_differentiable(radii, nth)
+        ctx.set_materialize_grads(False)
+        return xys, depths, radii, conics, nth, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, _v_radii, v_conics, _v_nth, v_cov3d):
+        means3d, scales, quats, viewmat, projmat, radii = ctx.saved_tensors
+        dev = means3d.device
+        n = means3d.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        v_xys = torch.zeros((n, 2), **f32) if v_xys is None else _f32c(v_xys)
+        v_depths = torch.zeros((n,), **f32) if v_depths is None else _f32c(v_depths)
+        v_conics = torch.zeros((n, 3), **f32) if v_conics is None else _f32c(v_conics)
+        v_cov3d = None if v_cov3d is None else _f32c(v_cov3d)
+        v_means = torch.empty((n, 3), **f32)
+        v_scales = torch.empty((n, 3), **f32)
+        v_quats = torch.empty((n, 4), **f32)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_project_bwd(n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
+                                          _ptr(projmat), ctx.cam, _ptr(radii), _ptr(v_xys),
+                                          _ptr(v_depths), _ptr(v_conics), _ptr(v_cov3d),
+                                          _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
+                                          _stream(dev)), "ts_project_bwd")
+        return (v_means, v_scales, None, v_quats) + (None,) * 11
+
+
+def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+                      viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
+                      img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
+                      clip_thresh: float = CLIP_THRESH,
+                      tile_rows: Optional[Tuple[int, int]] = None):
+    """EWA projection of N Gaussians.  Same positional signature tinysplat calls at rasterize.py:32.
+
+    Returns ``(xys[N,2], depths[N], radii[N] int32, conics[N,3], num_tiles_hit[N] int32,
+    cov3d[N,6])``; differentiable w.r.t. ``means3d``, ``scales``, ``quats``.  ``tile_rows=(r0,r1)``
+    (extension, multi-GPU stripes) restricts ``num_tiles_hit`` to tile rows [r0, r1).
+    """
+    return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx,
+                                   cy, img_height, img_width, tile_bounds, clip_thresh, tile_rows)
+
+
+# --------------------------------------------------------------------------------------------------
+# spherical_harmonics
+# --------------------------------------------------------------------------------------------------
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use, viewdirs, coeffs):
+        dev = _need_hip(viewdirs, coeffs)
+        if coeffs.dim() != 3 or coeffs.shape[-1] != 3:
+            raise ValueError("coeffs must be [N, K, 3]")
+        n, nb = coeffs.shape[0], coeffs.shape[1]
+        if viewdirs.shape != (n, 3):
+            raise ValueError("viewdirs must be [N, 3]")
+        stored = deg_from_sh(nb)
+        if degrees_to_use < 0 or degrees_to_use > stored:
+            raise ValueError(f"degrees_to_use={degrees_to_use} not in [0, {stored}]")
+        viewdirs, coeffs = _f32c(viewdirs), _f32c(coeffs)
+        colors = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_sh_fwd(n, int(degrees_to_use), nb, _ptr(viewdirs), _ptr(coeffs),
+                                     _ptr(colors), _stream(dev)), "ts_sh_fwd")
+        ctx.degree, ctx.nb = int(degrees_to_use), nb
+        ctx.save_for_backward(viewdirs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        (viewdirs,) = ctx.saved_tensors
+        dev = viewdirs.device
+        n = viewdirs.shape[0]
+        v_colors = _f32c(v_colors)
+        v_coeffs = torch.empty((n, ctx.nb, 3), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_sh_bwd(n, ctx.degree, ctx.nb, _ptr(viewdirs), _ptr(v_colors),
+                                     _ptr(v_coeffs), _stream(dev)), "ts_sh_bwd")
+        return None, None, v_coeffs
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -> Tensor:
+    """colors[N,3] from SH coefficients [N,K,3]; signature of the call at rasterize.py:38.
+    Differentiable w.r.t. ``coeffs`` only (no gradient to ``viewdirs``, as upstream)."""
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
+
+
+# --------------------------------------------------------------------------------------------------
+# rasterize_gaussians
+# --------------------------------------------------------------------------------------------------
+class TileBinning:
+    """Result of the binning stages: everything compositing needs besides colours."""
+    __slots__ = ("cam", "n", "num_tiles", "num_intersects", "cum_tiles_hit", "tile_bins",
+                 "gaussian_ids_sorted", "num_tiles_hit", "_keep", "_versions")
+
+
+_bin_cache = {}
+
+
+def _same(t: Tensor, kept: Tensor, version: int) -> bool:
+    return (t.data_ptr() == kept.data_ptr() and t._version == version and t.shape == kept.shape)
+
+
+def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tensor,
+                  img_height: int, img_width: int,
+                  tile_rows: Optional[Tuple[int, int]] = None, use_cache: bool = True) -> TileBinning:
+    """cumsum -> per-tile count -> offsets -> scatter -> per-tile depth sort.
+
+    tinysplat rasterizes twice per frame on identical (xys, depths, radii, num_tiles_hit)
+    (rasterize.py:44 and :50); the result is memoised on the identity (storage address + version
+    counter) of those tensors, whose storages are kept alive by the cache entry, so the second call
+    and the backward reuse it.
+    """
+    dev = _need_hip(xys, depths, radii, num_tiles_hit)
+    n = xys.shape[0]
+    xys_c, depths_c = _f32c(xys.detach()), _f32c(depths.detach())
+    radii_c, nth_c = _i32c(radii), _i32c(num_tiles_hit)
+    tb = _tile_bounds(img_height, img_width)
+    cam = _camera(0.0, 0.0, 0.0, 0.0, img_height, img_width, tb, tile_rows=tile_rows)
+    key = (dev.index, int(img_height), int(img_width), cam.tile_row0, cam.tile_rows)
+    if use_cache:
+        hit = _bin_cache.get(dev.index)
+        if hit is not None and hit[0] == key:
+            b = hit[1]
+            if all(_same(t, k, v) for t, k, v in zip((xys_c, depths_c, radii_c, nth_c), b._keep,
+                                                     b._versions)):
+                return b
+    lib = _lib.load()
+    s = _stream(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    num_tiles = cam.tile_rows * cam.tile_bounds_x
+    b = TileBinning()
+    b.cam, b.n, b.num_tiles, b.num_tiles_hit = cam, n, num_tiles, nth_c
+    with torch.cuda.device(dev):
+        cum = torch.empty((n,), **i32)
+        ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
+        _lib.check(lib.ts_scan_tiles(n, _ptr(nth_c), _ptr(cum), _ptr(ws), s), "ts_scan_tiles")
+        total = int(cum[-1].item()) if n > 0 else 0          # the one host sync of the path
+        tile_count = torch.empty((max(num_tiles, 1),), **i32)
+        tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
+        cursor = torch.empty((max(num_tiles, 1),), **i32)
+        keys = torch.empty((max(total, 1),), dtype=torch.int64, device=dev)
+        ids = torch.empty((max(total, 1),), **i32)
+        _lib.check(lib.ts_bin_count(n, _ptr(xys_c), _ptr(radii_c), cam, _ptr(tile_count), s),
+                   "ts_bin_count")
+        _lib.check(lib.ts_tile_offsets(num_tiles, _ptr(tile_count), _ptr(tile_bins), _ptr(cursor), s),
+                   "ts_tile_offsets")
+        if total > 0:
+            _lib.check(lib.ts_bin_scatter(n, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c), cam,
+                                          _ptr(cursor), _ptr(keys), s), "ts_bin_scatter")
+            _lib.check(lib.ts_sort_tiles(num_tiles, _ptr(tile_bins), _ptr(keys), _ptr(ids), s),
+                       "ts_sort_tiles")
+    b.num_intersects = total
+    b.cum_tiles_hit = cum
+    b.tile_bins = tile_bins[:num_tiles]
+    b.gaussian_ids_sorted = ids[:total]
+    b._keep = (xys_c, depths_c, radii_c, nth_c)
+    b._versions = tuple(t._version for t in b._keep)
+    if use_cache:
+        _bin_cache[dev.index] = (key, b)
+    return b
+
+
+def clear_binning_cache() -> None:
+    _bin_cache.clear()
+
+
+def _stripe_rows(cam: TsCamera) -> int:
+    return max(0, min(BLOCK * cam.tile_rows, cam.img_height - BLOCK * cam.tile_row0))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                img_width, background, tile_rows):
+        dev = _need_hip(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
+        n = xys.shape[0]
+        if colors.dim() != 2 or colors.shape[0] != n or colors.shape[1] not in (3, 4):
+            raise ValueError("colors must be [N,3] (or [N,4])")
+        ch = colors.shape[1]
+        if xys.shape != (n, 2) or conics.shape != (n, 3) or opacity.numel() != n:
+            raise ValueError("xys [N,2], conics [N,3], opacity [N,1] expected")
+        if background.numel() != ch:
+            raise ValueError(f"background must have {ch} entries")
+        b = bin_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width, tile_rows)
+        cam = b.cam
+        xys_c, conics_c = _f32c(xys), _f32c(conics)
+        colors_c, opac_c, bg_c = _f32c(colors), _f32c(opacity), _f32c(background)
+        rows = _stripe_rows(cam)
+        W = int(img_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        splats = torch.empty((max(n, 1), 12), **f32)
+        out_img = torch.empty((rows, W, ch), **f32)
+        final_Ts = torch.empty((rows, W), **f32)
+        final_idx = torch.empty((rows, W), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        s = _stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_pack_splats(n, ch, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
+                                          _ptr(colors_c), _ptr(opac_c), _ptr(b.cum_tiles_hit), cam,
+                                          _ptr(splats), s), "ts_pack_splats")
+            _lib.check(lib.ts_raster_fwd(ch, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
+                                         _ptr(splats), _ptr(bg_c), _ptr(out_img), _ptr(final_Ts),
+                                         _ptr(final_idx), s), "ts_raster_fwd")
+        out_alpha = 1.0 - final_Ts
+        ctx.binning, ctx.ch, ctx.n = b, ch, n
+        ctx.opacity_shape = opacity.shape
+        ctx.save_for_backward(splats, bg_c, final_Ts, final_idx)
+        ctx.set_materialize_grads(False)
+        return out_img, out_alpha
+
+    @staticmethod
+    def backward(ctx, v_out_img, v_out_alpha):
+        splats, bg_c, final_Ts, final_idx = ctx.saved_tensors
+        b, ch, n = ctx.binning, ctx.ch, ctx.n
+        dev = splats.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if v_out_img is None:
+            v_out_img = torch.zeros(final_Ts.shape + (ch,), **f32)
+        v_out_img = _f32c(v_out_img)
+        v_out_alpha = None if v_out_alpha is None else _f32c(v_out_alpha)
+        total = b.num_intersects
+        v_xy = torch.empty((n, 2), **f32)
+        v_conic = torch.empty((n, 3), **f32)
+        v_colors = torch.empty((n, ch), **f32)
+        v_opacity = torch.empty((n,), **f32)
+        partials = torch.empty((max(total, 1), 12), **f32)
+        lib = _lib.load()
+        s = _stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ts_raster_bwd(ch, total, b.cam, _ptr(b.tile_bins),
+                                         _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
+                                         _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
+                                         _ptr(v_out_alpha), _ptr(partials), s), "ts_raster_bwd")
+            _lib.check(lib.ts_reduce_partials(n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
+                                              _ptr(partials), _ptr(v_xy), _ptr(v_conic),
+                                              _ptr(v_colors), _ptr(v_opacity), s),
+                       "ts_reduce_partials")
+        return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
+                None, None, None, None)
+
+
+def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
+                        num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
+                        img_width: int, background: Tensor,
+                        tile_rows: Optional[Tuple[int, int]] = None):
+    """Tile-based alpha compositing; positional signature of the calls at rasterize.py:44,50.
+
+    Returns the 2-tuple ``(out_img[H,W,C], out_alpha[H,W])`` that tinysplat unpacks
+    (``rgbs, _ = rasterize_gaussians(*inputs)``).  Differentiable w.r.t. ``xys``, ``conics``,
+    ``colors``, ``opacity``.  With ``tile_rows=(r0,r1)`` only that stripe of tile rows is rendered
+    and the outputs hold its pixel rows.
+    """
+    return _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                     img_height, img_width, background, tile_rows)

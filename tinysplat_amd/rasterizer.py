@@ -1,0 +1,110 @@
+"""Render adapter: the build's counterpart of tinysplat's ``GaussianRasterizer``.
+
+Mirrors /root/reference/tinysplat/splatting/rasterize.py:13-94 - same constructor, same
+``__call__(camera, dims, sh_degree) -> (rgb[H,W,3], extras)`` contract, same argument lists handed
+to the three ops (so a model/camera pair produces bit-identical boundary traffic), same frame
+recipe: project -> retain xys grad -> SH -> clamp(rgb+0.5, min 0) -> rasterize RGB -> clamp(max 1)
+-> rasterize depth replicated to 3 channels -> depth = channel 0.
+
+Two reference quirks are reproduced on purpose (results parity with tinysplat):
+  * SH view directions are ``means - view_matrix[:3,3]`` (the translation column, rasterize.py:77),
+    not ``means - camera_position``;
+  * the depth image is composited with ``model.background`` (rasterize.py:86), so it contains
+    ``T_final * background[0]``.
+The ``sh_degree`` argument is accepted and ignored, as in the reference (model.active_sh_degree is
+used, rasterize.py:81).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import ops as _hip_ops
+
+TILE = 16  # rasterize.py:19-20
+
+
+def tile_bounds(dims: Tuple[int, int]) -> Tuple[int, int, int]:
+    """(ceil(W/16), ceil(H/16), 1) for dims = (W, H); rasterize.py:88-94."""
+    w, h = int(dims[0]), int(dims[1])
+    return (-(-w // TILE), -(-h // TILE), 1)
+
+
+def project_args(model, camera, dims, device):
+    """The 13 positional arguments of project_gaussians (rasterize.py:64-73)."""
+    w, h = dims
+    view = camera.view_matrix.to(device)
+    proj = camera.proj_matrix.to(device)
+    unit_quats = model.quats / model.quats.norm(dim=-1, keepdim=True)
+    return [model.means, torch.exp(model.scales), 1., unit_quats, view[:3, :], proj @ view,
+            camera.f_x, camera.f_y, w / 2, h / 2, h, w, tile_bounds(dims)]
+
+
+def sh_args(model, camera, device):
+    """[active degree, view directions, coefficients[N,K,3]] (rasterize.py:75-81)."""
+    origin = camera.view_matrix[:3, 3].to(device)     # reference quirk: translation column
+    dirs = model.means - origin
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    coeffs = torch.cat([model.colors_dc[:, None, :], model.colors_rest], dim=1)
+    return [model.active_sh_degree, dirs, coeffs]
+
+
+def raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims):
+    """The 10 positional arguments of rasterize_gaussians (rasterize.py:83-86)."""
+    w, h = dims
+    return [xys, depths, radii, conics, num_tiles, colors, torch.sigmoid(model.opacities), h, w,
+            model.background]
+
+
+class GaussianRasterizer:
+    BLOCK_X = TILE
+    BLOCK_Y = TILE
+
+    def __init__(self, model, cameras: Optional[Sequence] = None, device=torch.device("cuda:0")):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.model = model
+        self.global_scale = torch.tensor([1.0])
+        # the three callables of the boundary; the product default is the HIP library
+        self.ops = SimpleNamespace(project_gaussians=_hip_ops.project_gaussians,
+                                   spherical_harmonics=_hip_ops.spherical_harmonics,
+                                   rasterize_gaussians=_hip_ops.rasterize_gaussians)
+
+    def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
+        if dims is None:
+            dims = (camera.width, camera.height)
+        ops = self.ops
+
+        xys, depths, radii, conics, num_tiles, _cov3d = ops.project_gaussians(
+            *self.project_forward_inputs(camera, dims))
+        if xys.requires_grad:
+            xys.retain_grad()          # model_gaussian.py:130-132 reads extras['xys'].grad
+
+        colors = ops.spherical_harmonics(*self.spherical_harmonics_inputs(camera))
+        colors = torch.clamp(colors + 0.5, min=0.0)
+
+        rgb, _ = ops.rasterize_gaussians(*self.rasterize_forward_inputs(
+            xys, depths, radii, conics, num_tiles, colors, dims))
+        rgb = torch.clamp(rgb, max=1.0)
+
+        depth_as_color = depths[:, None].repeat(1, 3)
+        depth_img, _ = ops.rasterize_gaussians(*self.rasterize_forward_inputs(
+            xys, depths, radii, conics, num_tiles, depth_as_color, dims))
+
+        extras = {"depth": depth_img[:, :, 0], "radii": radii, "xys": xys,
+                  "camera": {"height": camera.height, "width": camera.width}}
+        return rgb, extras
+
+    # the reference's method names, kept so callers/tests written against it keep working
+    def project_forward_inputs(self, camera, dims):
+        return project_args(self.model, camera, dims, self.device)
+
+    def spherical_harmonics_inputs(self, camera):
+        return sh_args(self.model, camera, self.device)
+
+    def rasterize_forward_inputs(self, xys, depths, radii, conics, num_tiles, rgbs, dims):
+        return raster_args(self.model, xys, depths, radii, conics, num_tiles, rgbs, dims)
+
+    def tile_bounds(self, dims):
+        return tile_bounds(dims)

@@ -1,0 +1,139 @@
+"""Synthetic scenes and cameras for tests and bench.
+
+The camera conventions restate tinysplat/scene.py:96-121 (``Camera.update_view_matrix`` /
+``update_proj_matrix``): world->camera ``V = [R | -R p]``, camera looks down +z, and the projection
+matrix with ``P[0,0]=1/tan(fov_x/2)``, ``P[1,1]=1/tan(fov_y/2)``, ``P[2,2]=(f+n)/(f-n)``,
+``P[2,3]=-f n/(f-n)``, ``P[3,2]=1``; both are built in float64 numpy and cast to float32 exactly as
+the reference does (scene.py:109,121).
+
+The parameter layout of :class:`SplatModel` is the six leaf tensors of
+tinysplat/splatting/model_gaussian.py:84-89 (means, colors_dc, colors_rest, log-scales, wxyz quats,
+opacity logits) plus ``background`` (model_gaussian.py:60) and ``active_sh_degree``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+def num_sh_bases(degree: int) -> int:
+    return {0: 1, 1: 4, 2: 9, 3: 16}.get(degree, 25)
+
+
+def quat_to_rot_matrix(quat) -> np.ndarray:
+    """(w,x,y,z) -> 3x3, the numpy formula of tinysplat/utils.py:29-39."""
+    q0, q1, q2, q3 = (float(quat[0]), float(quat[1]), float(quat[2]), float(quat[3]))
+    return np.asarray([
+        [1 - 2 * q2 ** 2 - 2 * q3 ** 2, 2 * q1 * q2 - 2 * q3 * q0, 2 * q1 * q3 + 2 * q2 * q0],
+        [2 * q1 * q2 + 2 * q3 * q0, 1 - 2 * q1 ** 2 - 2 * q3 ** 2, 2 * q2 * q3 - 2 * q1 * q0],
+        [2 * q1 * q3 - 2 * q2 * q0, 2 * q2 * q3 + 2 * q1 * q0, 1 - 2 * q1 ** 2 - 2 * q2 ** 2],
+    ])
+
+
+@dataclass
+class PinholeCamera:
+    """The subset of tinysplat.scene.Camera that GaussianRasterizer reads (rasterize.py:26-94):
+    ``view_matrix`` [4,4], ``proj_matrix`` [4,4], ``f_x``, ``f_y``, ``width``, ``height``."""
+    view_matrix: torch.Tensor
+    proj_matrix: torch.Tensor
+    f_x: float
+    f_y: float
+    width: int
+    height: int
+
+    @classmethod
+    def look_at_origin_plus_z(cls, width: int, height: int, fov_x_deg: float = 60.0,
+                              position=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0),
+                              znear: float = 0.001, zfar: float = 1000.0) -> "PinholeCamera":
+        fov_x = math.radians(fov_x_deg)
+        f_x = width / (2.0 * math.tan(fov_x / 2.0))
+        f_y = f_x
+        fov_y = 2.0 * math.atan(height / (2.0 * f_y))
+        rot = quat_to_rot_matrix(quat)
+        view = np.zeros((4, 4))
+        view[:3, :3] = rot
+        view[:3, 3] = -rot.dot(np.asarray(position, dtype=np.float64))
+        view[3, 3] = 1
+        proj = np.zeros((4, 4))
+        proj[0, 0] = 1.0 / np.tan(fov_x / 2)
+        proj[1, 1] = 1.0 / np.tan(fov_y / 2)
+        proj[2, 2] = (zfar + znear) / (zfar - znear)
+        proj[2, 3] = -1.0 * zfar * znear / (zfar - znear)
+        proj[3, 2] = 1
+        return cls(torch.as_tensor(view, dtype=torch.float32),
+                   torch.as_tensor(proj, dtype=torch.float32), f_x, f_y, width, height)
+
+
+class SplatModel:
+    """Holder of the six learnable tensors in the reference's layout (model_gaussian.py:84-89)."""
+
+    def __init__(self, means, colors_dc, colors_rest, scales, quats, opacities,
+                 active_sh_degree: int, background=None):
+        self.means = means
+        self.colors_dc = colors_dc
+        self.colors_rest = colors_rest
+        self.scales = scales
+        self.quats = quats
+        self.opacities = opacities
+        self.active_sh_degree = active_sh_degree
+        self.background = (torch.zeros(3, device=means.device) if background is None else background)
+
+    def parameters(self):
+        return [self.means, self.colors_dc, self.colors_rest, self.scales, self.quats, self.opacities]
+
+    def to(self, device):
+        kw = dict(active_sh_degree=self.active_sh_degree, background=self.background.to(device))
+        ps = [p.detach().to(device) for p in self.parameters()]
+        return SplatModel(*ps, **kw)
+
+    def requires_grad_(self, flag: bool = True):
+        for p in self.parameters():
+            p.requires_grad_(flag)
+        return self
+
+    @property
+    def num_points(self) -> int:
+        return self.means.shape[0]
+
+
+def make_scene(n: int, sh_degree: int, width: int, height: int, seed: int = 0,
+               scale_mult: float = 1.0, fov_x_deg: float = 60.0):
+    """Seeded random-Gaussian scene of SURVEY.md 8(d) D2.  Generated on CPU in float32.
+
+    z ~ U(2,10); x,y = z*tan_fov*U(-1.1,1.1) (~17 % off-screen); per-axis log-scale =
+    log z + U(log 8e-4, log 4e-3) (+ log scale_mult: the high-overlap stress variant uses 4);
+    quats ~ N(0,1)^4; opacity logits ~ N(0,1.5); colors_dc ~ N(0,1); colors_rest ~ N(0,0.1);
+    background 0.  Camera at the origin looking down +z with fov_x = 60 deg.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    cam = PinholeCamera.look_at_origin_plus_z(width, height, fov_x_deg)
+    tan_x = 0.5 * width / cam.f_x
+    tan_y = 0.5 * height / cam.f_y
+
+    def U(shape, lo, hi):
+        return lo + (hi - lo) * torch.rand(shape, generator=g, dtype=torch.float32)
+
+    z = U((n,), 2.0, 10.0)
+    x = z * tan_x * U((n,), -1.1, 1.1)
+    y = z * tan_y * U((n,), -1.1, 1.1)
+    means = torch.stack([x, y, z], dim=-1)
+    scales = torch.log(z)[:, None] + U((n, 3), math.log(8e-4), math.log(4e-3)) + math.log(scale_mult)
+    quats = torch.randn((n, 4), generator=g, dtype=torch.float32)
+    opacities = 1.5 * torch.randn((n, 1), generator=g, dtype=torch.float32)
+    k = num_sh_bases(sh_degree)
+    colors_dc = torch.randn((n, 3), generator=g, dtype=torch.float32)
+    colors_rest = 0.1 * torch.randn((n, k - 1, 3), generator=g, dtype=torch.float32)
+    model = SplatModel(means, colors_dc, colors_rest, scales, quats, opacities, sh_degree,
+                       background=torch.zeros(3))
+    return model, cam
+
+
+def loss_weights(width: int, height: int, seed: int = 1):
+    """Fixed dense upstream-gradient weights for ``L = (rgb*w_rgb).sum() + (depth*w_d).sum()``."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w_rgb = torch.rand((height, width, 3), generator=g, dtype=torch.float32)
+    w_d = torch.rand((height, width), generator=g, dtype=torch.float32)
+    return w_rgb, w_d

@@ -1,0 +1,252 @@
+"""HIP path vs the oracle, through the C ABI (tinysplat_amd.ops -> ctypes -> libtinysplat_hip.so).
+
+Bars (BASELINE.json north_star): integers (radii, num_tiles_hit, tile_bins, gaussian_ids_sorted,
+final_index) bit-exact; rendered values and gradients within 1e-5 abs (scaled by the magnitude of
+the reference tensor where that exceeds 1).  Compositing has two discrete per-pixel decisions
+(alpha >= 1/255, next_T <= 1e-4); pixels where the float64 oracle sits within 1e-4 (relative) of a
+threshold are excluded from value checks - there a 1-ulp difference in exp() legitimately flips a
+whole contribution - and their fraction is asserted to be tiny.
+"""
+import pytest
+import torch
+
+from oracle import gsplat_oracle as O
+from tinysplat_amd import ops
+from tinysplat_amd.rasterizer import GaussianRasterizer, project_args, raster_args, sh_args, tile_bounds
+
+from helpers import assert_close_masked, oracle_frame, scene_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MARGIN = 1e-4
+
+
+def _to_dev(args):
+    return [a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args]
+
+
+@pytest.mark.parametrize("n,w,h,seed,mult", [(20000, 256, 256, 0, 1.0), (50000, 1920, 1080, 1, 1.0),
+                                             (7000, 333, 201, 2, 5.0), (1, 16, 16, 3, 1.0)])
+def test_project_fwd_bit_exact(n, w, h, seed, mult):
+    model, cam = scene_args(n, 0, w, h, seed=seed, scale_mult=mult)
+    pa = project_args(model, cam, (w, h), "cpu")
+    ref = O.project_gaussians(*pa)
+    got = ops.project_gaussians(*_to_dev(pa))
+    torch.cuda.synchronize()
+    for r, g, nm in zip(ref, got, ["xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"]):
+        assert torch.equal(r, g.cpu()), f"{nm}: max diff {(r.double() - g.cpu().double()).abs().max()}"
+
+
+def test_project_bwd():
+    n, w, h = 20000, 640, 360
+    model, cam = scene_args(n, 0, w, h, seed=4, scale_mult=2.0)
+    pa = project_args(model, cam, (w, h), "cpu")
+    pa[3] = torch.randn(n, 4)
+    g = torch.Generator().manual_seed(7)
+    v_xy, v_depth = torch.randn(n, 2, generator=g), torch.randn(n, generator=g)
+    v_conic, v_cov3d = torch.randn(n, 3, generator=g), torch.randn(n, 6, generator=g)
+    m64, s64, q64 = (t.double().requires_grad_(True) for t in (pa[0], pa[1], pa[3]))
+    xys, depths, radii, conics, nth, cov3d = O.project_gaussians(*([m64, s64, pa[2], q64] + pa[4:]))
+    ((xys * v_xy).sum() + (depths * v_depth).sum() + (conics * v_conic).sum()
+     + (cov3d * v_cov3d).sum()).backward()
+    da = _to_dev(pa)
+    md, sd, qd = (da[i].requires_grad_(True) for i in (0, 1, 3))
+    out = ops.project_gaussians(*da)
+    ((out[0] * v_xy.to(DEV)).sum() + (out[1] * v_depth.to(DEV)).sum() + (out[3] * v_conic.to(DEV)).sum()
+     + (out[5] * v_cov3d.to(DEV)).sum()).backward()
+    live = radii > 0
+    for got, ref, nm in ((md.grad, m64.grad, "means"), (sd.grad, s64.grad, "scales"),
+                         (qd.grad, q64.grad, "quats")):
+        ref = ref[live]
+        err = (got.cpu().double()[live] - ref).abs().max() / ref.abs().max()
+        assert err < 2e-4, f"v_{nm}: {err:.2e}"
+        assert torch.all(got.cpu()[~live] == 0)
+
+
+@pytest.mark.parametrize("deg,stored", [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (0, 3), (2, 3), (1, 4)])
+def test_sh_fwd_bwd(deg, stored):
+    n = 5000 if stored < 4 else 1300
+    g = torch.Generator().manual_seed(deg * 7 + stored)
+    dirs = torch.randn(n, 3, generator=g)
+    K = O.num_sh_bases(stored)
+    coeffs = torch.randn(n, K, 3, generator=g)
+    v = torch.randn(n, 3, generator=g)
+    c64 = coeffs.double().requires_grad_(True)
+    ref = O.spherical_harmonics(deg, dirs.double(), c64)
+    (ref * v.double()).sum().backward()
+    cd = coeffs.to(DEV).requires_grad_(True)
+    got = ops.spherical_harmonics(deg, dirs.to(DEV), cd)
+    (got * v.to(DEV)).sum().backward()
+    assert (got.cpu().double() - ref).abs().max() < 1e-5
+    assert (cd.grad.cpu().double() - c64.grad).abs().max() < 1e-5
+    ka = O.num_sh_bases(deg)
+    assert torch.all(cd.grad[:, ka:, :] == 0)
+
+
+def _binning_case(n, w, h, seed, mult):
+    model, cam = scene_args(n, 0, w, h, seed=seed, scale_mult=mult)
+    f = oracle_frame(model, cam, (w, h), depth=False)
+    return model, cam, f
+
+
+@pytest.mark.parametrize("n,w,h,seed,mult", [(20000, 256, 256, 0, 2.0), (30000, 640, 360, 1, 1.5),
+                                             (60000, 64, 48, 2, 12.0), (3, 40, 40, 3, 1.0)])
+def test_binning_bit_exact(n, w, h, seed, mult):
+    """tile_bins and gaussian_ids_sorted equal the stable (tile, depth-bits) sort of the oracle.
+    The (60000, 64x48, x12) case puts > 4096 entries in single tiles -> global-memory sort path."""
+    _, _, f = _binning_case(n, w, h, seed, mult)
+    xys, depths, radii, nth = f["xys"].detach(), f["depths"].detach(), f["radii"], f["nth"]
+    tb = tile_bounds((w, h))
+    cum, keys, ids, bins = O.bin_and_sort(xys, depths, radii, nth, tb)
+    b = ops.bin_gaussians(xys.to(DEV), depths.to(DEV), radii.to(DEV), nth.to(DEV), h, w, use_cache=False)
+    torch.cuda.synchronize()
+    assert b.num_intersects == int(nth.sum())
+    assert torch.equal(b.cum_tiles_hit.cpu(), cum)
+    assert torch.equal(b.tile_bins.cpu(), bins)
+    assert torch.equal(b.gaussian_ids_sorted.cpu(), ids)
+    if mult >= 12.0:
+        assert (bins[:, 1] - bins[:, 0]).max() > 4096
+
+
+def test_binning_empty():
+    n, w, h = 100, 64, 64
+    z = torch.zeros
+    b = ops.bin_gaussians(z(n, 2, device=DEV), z(n, device=DEV), z(n, dtype=torch.int32, device=DEV),
+                          z(n, dtype=torch.int32, device=DEV), h, w, use_cache=False)
+    assert b.num_intersects == 0 and torch.all(b.tile_bins == 0)
+    img, alpha = ops.rasterize_gaussians(z(n, 2, device=DEV), z(n, device=DEV),
+                                         z(n, dtype=torch.int32, device=DEV), z(n, 3, device=DEV),
+                                         z(n, dtype=torch.int32, device=DEV), z(n, 3, device=DEV),
+                                         z(n, 1, device=DEV), h, w, torch.tensor([0.1, 0.2, 0.3], device=DEV))
+    assert torch.allclose(img.cpu(), torch.tensor([0.1, 0.2, 0.3]).expand(h, w, 3))
+    assert torch.all(alpha == 0)
+
+
+def _raster_inputs(n, w, h, seed, mult, sh=0):
+    model, cam = scene_args(n, sh, w, h, seed=seed, scale_mult=mult)
+    model.background = torch.tensor([0.3, 0.5, 0.7])
+    f = oracle_frame(model, cam, (w, h), depth=False)
+    args = raster_args(model, f["xys"].detach(), f["depths"].detach(), f["radii"], f["conics"].detach(),
+                       f["nth"], f["colors"].detach(), (w, h))
+    return model, args
+
+
+@pytest.mark.parametrize("n,w,h,seed,mult", [(20000, 256, 256, 0, 2.0), (40000, 640, 360, 1, 2.0),
+                                             (4000, 100, 70, 2, 8.0)])
+def test_raster_fwd(n, w, h, seed, mult):
+    _, args = _raster_inputs(n, w, h, seed, mult)
+    a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in args]
+    ref_img, ref_alpha, aux = O.rasterize_gaussians(*a64, return_aux=True)
+    img, alpha = ops.rasterize_gaussians(*_to_dev(args))
+    torch.cuda.synchronize()
+    stable = aux["margin"] > MARGIN
+    assert (~stable).double().mean() < 2e-3
+    assert_close_masked(img, ref_img, 1e-5, stable, what="out_img")
+    assert_close_masked(alpha, ref_alpha, 1e-5, stable, what="out_alpha")
+    assert (ref_alpha > 0.05).double().mean() > 0.3      # the scene actually covers the image
+
+
+def test_raster_fwd_internals_final_index():
+    """final_index / final_Ts (saved for backward) at stable pixels, read through the autograd ctx."""
+    _, args = _raster_inputs(15000, 320, 200, 5, 3.0)
+    a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in args]
+    _, _, aux = O.rasterize_gaussians(*a64, return_aux=True)
+    da = _to_dev(args)
+    da[5] = da[5].requires_grad_(True)
+    img, alpha = ops.rasterize_gaussians(*da)
+    splats, bg, fT, fI = img.grad_fn.saved_tensors
+    stable = aux["margin"] > MARGIN
+    assert torch.equal(fI.cpu()[stable], aux["final_index"][stable])
+    assert (fT.cpu().double() - aux["final_Ts"])[stable].abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("n,w,h,seed,mult,use_alpha", [(20000, 256, 256, 0, 2.0, False),
+                                                       (8000, 200, 120, 1, 5.0, True)])
+def test_raster_bwd(n, w, h, seed, mult, use_alpha):
+    _, args = _raster_inputs(n, w, h, seed, mult)
+    a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in args]
+    leaves64 = {i: a64[i].clone().requires_grad_(True) for i in (0, 3, 5, 6)}
+    for i, t in leaves64.items():
+        a64[i] = t
+    ref_img, ref_alpha, aux = O.rasterize_gaussians(*a64, return_aux=True)
+    stable = (aux["margin"] > MARGIN)
+    g = torch.Generator().manual_seed(11)
+    w_img = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    w_a = torch.rand(h, w, generator=g) * stable * (1.0 if use_alpha else 0.0)
+    ((ref_img * w_img).sum() + (ref_alpha * w_a).sum()).backward()
+
+    da = _to_dev(args)
+    leaves = {i: da[i].clone().requires_grad_(True) for i in (0, 3, 5, 6)}
+    for i, t in leaves.items():
+        da[i] = t
+    img, alpha = ops.rasterize_gaussians(*da)
+    loss = (img * w_img.to(DEV)).sum()
+    if use_alpha:
+        loss = loss + (alpha * w_a.to(DEV)).sum()
+    loss.backward()
+    for i, nm in ((0, "v_xy"), (3, "v_conic"), (5, "v_colors"), (6, "v_opacity")):
+        ref = leaves64[i].grad
+        got = leaves[i].grad.cpu().double()
+        tol = 1e-5 * max(1.0, ref.abs().max().item())
+        bad = ((got - ref).abs() > tol).double().mean().item()
+        assert bad < 1e-4, f"{nm}: {bad:.2e} entries off by more than {tol:.2e}; max {(got-ref).abs().max():.3e}"
+    # depth is not differentiable through the sort key
+    assert da[1].grad is None
+
+
+def test_raster_bwd_deterministic():
+    """No float atomics: two backward passes give bit-identical gradients."""
+    _, args = _raster_inputs(30000, 320, 200, 8, 3.0)
+    grads = []
+    for _ in range(2):
+        da = _to_dev(args)
+        for i in (0, 3, 5, 6):
+            da[i] = da[i].clone().requires_grad_(True)
+        img, _ = ops.rasterize_gaussians(*da)
+        img.square().sum().backward()
+        grads.append([da[i].grad.clone() for i in (0, 3, 5, 6)])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,sh,w,h,mult", [(10000, 0, 256, 256, 2.0), (30000, 3, 480, 270, 2.0)])
+def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult):
+    """The whole adapter (project -> SH -> rasterize RGB -> rasterize depth) fwd + bwd to the six
+    parameter tensors, HIP vs the same recipe run with the oracle ops (float32, CPU autograd)."""
+    model, cam = scene_args(n, sh, w, h, seed=21, scale_mult=mult)
+    model.background = torch.tensor([0.2, 0.3, 0.1])
+    m64, _ = scene_args(n, sh, w, h, seed=21, scale_mult=mult)     # float32: integer outputs must match
+    m64.background = model.background.clone()
+    m64.requires_grad_(True)
+    f = oracle_frame(m64, cam, (w, h), depth=True)
+    stable = f["aux"]["margin"] > MARGIN
+    g = torch.Generator().manual_seed(1)
+    w_rgb = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    w_d = torch.rand(h, w, generator=g) * stable
+    ((f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()).backward()
+
+    md = model.to(DEV).requires_grad_(True)
+    r = GaussianRasterizer(md, None, device=torch.device(DEV))
+    rgb, extras = r(cam, (w, h), sh)
+    ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(extras["radii"].cpu(), f["radii"])
+    assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb")
+    assert_close_masked(extras["depth"], f["depth"], 1e-5 * 10.0, stable, what="depth")   # depth values reach 10
+    assert extras["xys"].grad is not None
+    pairs = [(md.means, m64.means), (md.scales, m64.scales), (md.quats, m64.quats),
+             (md.opacities, m64.opacities), (md.colors_dc, m64.colors_dc),
+             (md.colors_rest, m64.colors_rest), (extras["xys"], f["xys"])]
+    names = ["means", "scales", "quats", "opacities", "colors_dc", "colors_rest", "xys"]
+    for (a, b), nm in zip(pairs, names):
+        if b.grad is None or b.numel() == 0:
+            continue
+        ref, got = b.grad, a.grad.cpu().double()
+        tol = 2e-5 * max(1.0, ref.abs().max().item())
+        bad = ((got - ref).abs() > tol).double().mean().item()
+        assert bad < 2e-4, f"grad {nm}: {bad:.2e} off by > {tol:.2e}; max {(got-ref).abs().max():.3e} of {ref.abs().max():.3e}"
+
+
+def test_cpu_tensors_raise():
+    with pytest.raises(RuntimeError):
+        ops.spherical_harmonics(0, torch.zeros(2, 3), torch.zeros(2, 1, 3))

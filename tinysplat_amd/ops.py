@@ -49,6 +49,46 @@ def deg_from_sh(num_bases: int) -> int:
     raise ValueError(f"Invalid number of SH bases: {num_bases}")
 
 
+class _KernelTimer:
+    """Optional per-entry timing with events recorded on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py for the live roofline numbers; off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def start(self):
+        self.enabled = True
+        self.records = {}
+
+    def stop(self):
+        """-> {entry: (launches, mean_ms)}; synchronises."""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        self.records = {}
+        return out
+
+
+kernel_timer = _KernelTimer()
+
+
+def _call(name: str, fn, *args) -> None:
+    """Invokes one C-ABI entry and raises on a non-zero status."""
+    if kernel_timer.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        code = fn(*args)
+        b.record()
+        kernel_timer.records.setdefault(name, []).append((a, b))
+    else:
+        code = fn(*args)
+    _lib.check(code, name)
+
+
 def _need_hip(*tensors: Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -129,10 +169,9 @@ class _ProjectGaussians(torch.autograd.Function):
         cov3d = torch.empty((n, 6), **f32)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_project_fwd(n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
+            _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
                                           _ptr(projmat), cam, _ptr(xys), _ptr(depths), _ptr(radii),
-                                          _ptr(conics), _ptr(nth), _ptr(cov3d), _stream(dev)),
-                       "ts_project_fwd")
+                                          _ptr(conics), _ptr(nth), _ptr(cov3d), _stream(dev))
         ctx.cam = cam
         ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii)
         ctx.mark_non_differentiable(radii, nth)
@@ -154,11 +193,11 @@ class _ProjectGaussians(torch.autograd.Function):
         v_quats = torch.empty((n, 4), **f32)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_project_bwd(n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
+            _call("ts_project_bwd", lib.ts_project_bwd, n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
                                           _ptr(projmat), ctx.cam, _ptr(radii), _ptr(v_xys),
                                           _ptr(v_depths), _ptr(v_conics), _ptr(v_cov3d),
                                           _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
-                                          _stream(dev)), "ts_project_bwd")
+                                          _stream(dev))
         return (v_means, v_scales, None, v_quats) + (None,) * 11
 
 
@@ -196,8 +235,8 @@ class _SphericalHarmonics(torch.autograd.Function):
         colors = torch.empty((n, 3), dtype=torch.float32, device=dev)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_sh_fwd(n, int(degrees_to_use), nb, _ptr(viewdirs), _ptr(coeffs),
-                                     _ptr(colors), _stream(dev)), "ts_sh_fwd")
+            _call("ts_sh_fwd", lib.ts_sh_fwd, n, int(degrees_to_use), nb, _ptr(viewdirs), _ptr(coeffs),
+                                     _ptr(colors), _stream(dev))
         ctx.degree, ctx.nb = int(degrees_to_use), nb
         ctx.save_for_backward(viewdirs)
         return colors
@@ -211,8 +250,8 @@ class _SphericalHarmonics(torch.autograd.Function):
         v_coeffs = torch.empty((n, ctx.nb, 3), dtype=torch.float32, device=dev)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_sh_bwd(n, ctx.degree, ctx.nb, _ptr(viewdirs), _ptr(v_colors),
-                                     _ptr(v_coeffs), _stream(dev)), "ts_sh_bwd")
+            _call("ts_sh_bwd", lib.ts_sh_bwd, n, ctx.degree, ctx.nb, _ptr(viewdirs), _ptr(v_colors),
+                                     _ptr(v_coeffs), _stream(dev))
         return None, None, v_coeffs
 
 
@@ -271,22 +310,19 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
     with torch.cuda.device(dev):
         cum = torch.empty((n,), **i32)
         ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
-        _lib.check(lib.ts_scan_tiles(n, _ptr(nth_c), _ptr(cum), _ptr(ws), s), "ts_scan_tiles")
+        _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth_c), _ptr(cum), _ptr(ws), s)
         total = int(cum[-1].item()) if n > 0 else 0          # the one host sync of the path
         tile_count = torch.empty((max(num_tiles, 1),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
         cursor = torch.empty((max(num_tiles, 1),), **i32)
         keys = torch.empty((max(total, 1),), dtype=torch.int64, device=dev)
         ids = torch.empty((max(total, 1),), **i32)
-        _lib.check(lib.ts_bin_count(n, _ptr(xys_c), _ptr(radii_c), cam, _ptr(tile_count), s),
-                   "ts_bin_count")
-        _lib.check(lib.ts_tile_offsets(num_tiles, _ptr(tile_count), _ptr(tile_bins), _ptr(cursor), s),
-                   "ts_tile_offsets")
+        _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys_c), _ptr(radii_c), cam, _ptr(tile_count), s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, num_tiles, _ptr(tile_count), _ptr(tile_bins), _ptr(cursor), s)
         if total > 0:
-            _lib.check(lib.ts_bin_scatter(n, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c), cam,
-                                          _ptr(cursor), _ptr(keys), s), "ts_bin_scatter")
-            _lib.check(lib.ts_sort_tiles(num_tiles, _ptr(tile_bins), _ptr(keys), _ptr(ids), s),
-                       "ts_sort_tiles")
+            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c), cam,
+                                          _ptr(cursor), _ptr(keys), s)
+            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(keys), _ptr(ids), s)
     b.num_intersects = total
     b.cum_tiles_hit = cum
     b.tile_bins = tile_bins[:num_tiles]
@@ -333,12 +369,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_pack_splats(n, ch, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
+            _call("ts_pack_splats", lib.ts_pack_splats, n, ch, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
                                           _ptr(colors_c), _ptr(opac_c), _ptr(b.cum_tiles_hit), cam,
-                                          _ptr(splats), s), "ts_pack_splats")
-            _lib.check(lib.ts_raster_fwd(ch, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
+                                          _ptr(splats), s)
+            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
                                          _ptr(splats), _ptr(bg_c), _ptr(out_img), _ptr(final_Ts),
-                                         _ptr(final_idx), s), "ts_raster_fwd")
+                                         _ptr(final_idx), s)
         out_alpha = 1.0 - final_Ts
         ctx.binning, ctx.ch, ctx.n = b, ch, n
         ctx.opacity_shape = opacity.shape
@@ -365,14 +401,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.ts_raster_bwd(ch, total, b.cam, _ptr(b.tile_bins),
+            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, b.cam, _ptr(b.tile_bins),
                                          _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
-                                         _ptr(v_out_alpha), _ptr(partials), s), "ts_raster_bwd")
-            _lib.check(lib.ts_reduce_partials(n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
+                                         _ptr(v_out_alpha), _ptr(partials), s)
+            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
                                               _ptr(partials), _ptr(v_xy), _ptr(v_conic),
-                                              _ptr(v_colors), _ptr(v_opacity), s),
-                       "ts_reduce_partials")
+                                              _ptr(v_colors), _ptr(v_opacity), s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
                 None, None, None, None)
 

@@ -1,0 +1,86 @@
+"""Multi-GPU tile-stripe sharding of one frame (new design - the reference is
+single-device, tinysplat/splatting/rasterize.py:17 hard-codes "cuda:0").
+
+One process per GPU.  The Gaussian parameters are replicated; the tile grid is cut into
+``world_size`` contiguous stripes of tile rows.  Each rank projects all Gaussians (96 N bytes, cheap),
+bins / sorts / composites only its stripe, and in backward produces the per-Gaussian 2-D gradients
+(v_xy, v_conic, v_colors, v_opacity: 40 N bytes) of its stripe's pixels.  Those are summed over
+ranks with ONE all-reduce (RCCL over xGMI when the backend is "nccl") placed between the rasterizer
+backward and the projection / SH backward, which then run replicated and leave identical, complete
+parameter gradients on every rank.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .rasterizer import project_args, raster_args, sh_args
+
+
+def stripe_rows(tile_rows_total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of tile rows: the first (total % world) ranks get one more row."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank / world_size")
+    q, r = divmod(tile_rows_total, world_size)
+    r0 = rank * q + min(rank, r)
+    return r0, r0 + q + (1 if rank < r else 0)
+
+
+class _SumGradsAcrossRanks(torch.autograd.Function):
+    """Identity in forward; in backward packs the incoming gradients into one flat buffer, sums it
+    over the process group with a single all-reduce, and unpacks."""
+
+    @staticmethod
+    def forward(ctx, group, *tensors):
+        ctx.group = group
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g for g in grads if g is not None]
+        if not live:
+            return (None,) + grads
+        flat = torch.cat([g.reshape(-1) for g in live])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        out, off = [], 0
+        for g in grads:
+            if g is None:
+                out.append(None)
+            else:
+                out.append(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        return (None,) + tuple(out)
+
+
+def sum_grads_across_ranks(tensors, group=None):
+    return _SumGradsAcrossRanks.apply(group, *tensors)
+
+
+def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_size: int = 1,
+                      group=None, tile_rows: Optional[Tuple[int, int]] = None):
+    """Steps 1-3 of the reference frame (rasterize.py:30-45: project, SH, clamp, rasterize RGB,
+    clamp) for this rank's stripe.  Returns (rgb_stripe[rows,W,3], (row_begin_px, row_end_px), xys).
+
+    world_size == 1 renders the whole frame and involves no collective.
+    """
+    w, h = dims
+    pa = project_args(model, camera, dims, device)
+    tby = pa[12][1]
+    if tile_rows is None:
+        tile_rows = stripe_rows(tby, world_size, rank)
+    sharded = world_size > 1
+    kw = {"tile_rows": tile_rows} if (sharded or tile_rows != (0, tby)) else {}
+    xys, depths, radii, conics, num_tiles, _ = ops.project_gaussians(*pa, **kw)
+    if xys.requires_grad:
+        xys.retain_grad()
+    colors = ops.spherical_harmonics(*sh_args(model, camera, device))
+    colors = torch.clamp(colors + 0.5, min=0.0)
+    ra = raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims)
+    if sharded:
+        ra[0], ra[3], ra[5], ra[6] = sum_grads_across_ranks((ra[0], ra[3], ra[5], ra[6]), group)
+    rgb, _ = ops.rasterize_gaussians(*ra, **kw)
+    rgb = torch.clamp(rgb, max=1.0)
+    y0 = 16 * tile_rows[0]
+    return rgb, (y0, y0 + rgb.shape[0]), xys

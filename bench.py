@@ -66,7 +66,11 @@ def cpu_baseline(seconds_budget: float = 20.0):
     from tinysplat_amd.rasterizer import project_args, raster_args, sh_args
     from tinysplat_amd.synthetic import loss_weights, make_scene
     n, w, h, sh = 100_000, 480, 270, 3
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))      # many tiny per-tile ops: more threads only add sync cost
     torch.set_num_threads(cores)
     model, cam = make_scene(n, sh, w, h, seed=0)
     model.requires_grad_(True)

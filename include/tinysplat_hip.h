@@ -132,8 +132,9 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam_host, const int32_t* ti
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, void* stream);
 
-/* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row per contributing (tile,Gaussian):
- *   {v_x, v_y, v_opacity, v_conic.xx, v_conic.xy, v_conic.yy, v_c0, v_c1, v_c2, v_c3, 0, 0}
+/* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
+ * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
+ *   {S v_s, S v_s dx, S v_s dy, S v_s dx^2, S v_s dx dy, S v_s dy^2, v_c0, v_c1, v_c2, v_c3, -, -}
  * partials[I,12] is zeroed by this call first.  v_out_alpha may be NULL. */
 int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam_host,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
@@ -141,10 +142,12 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
                   const float* v_out_img, const float* v_out_alpha, float* partials, void* stream);
 
 /* Sums each Gaussian's rows (a contiguous range of `partials`, fixed order => run-to-run
- * bit-reproducible gradients) into v_xy[n,2], v_conic[n,3], v_colors[n,channels], v_opacity[n]. */
+ * bit-reproducible gradients), applies the conic / opacity factors read from `splats`, and writes
+ * v_xy[n,2], v_conic[n,3] (true partials), v_colors[n,channels], v_opacity[n]. */
 int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
-                       const int32_t* cum_tiles_hit, const float* partials, float* v_xy,
-                       float* v_conic, float* v_colors, float* v_opacity, void* stream);
+                       const int32_t* cum_tiles_hit, const float* partials, const float* splats,
+                       float* v_xy, float* v_conic, float* v_colors, float* v_opacity,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,21 +5,24 @@
 // depth-sorted per-tile lists, and the back-to-front replay that produces v_xy / v_conic /
 // v_colors / v_opacity), re-designed around the 64-wide wavefront:
 //
-//   * ONE WAVE OWNS ONE 16x16 TILE.  Lane l covers column (l & 15) and the four rows
-//     (l >> 4) + {0,4,8,12}; four pixels per lane.  There is no workgroup barrier anywhere: the
-//     four waves of a 256-thread workgroup run four different tiles independently, early-out is a
-//     wave ballot, and per-Gaussian terms that depend only on the column (dx, A dx^2, B dx) are
-//     computed once per lane instead of once per pixel.
+//   * ONE WAVE OWNS ONE 16x16 TILE, seen as four 8x8 pixel blocks.  Lane l sits at (l & 7, l >> 3)
+//     of every block: four pixels per lane, and one VALU instruction covers exactly one block, so
+//     a block is the unit of skipping.  There is no workgroup barrier anywhere: the four waves of a
+//     256-thread workgroup run four different tiles independently; early-out is a wave ballot.
 //   * Per 64-entry chunk of the tile's sorted list each lane gathers ONE Gaussian's 48-byte packed
-//     record (3 x 16 B loads), tests it exactly against the tile rectangle (minimum of the conic
-//     form over the rectangle vs. the alpha >= 1/255 level set - conservative, so results are
-//     unchanged), and survivors are compacted into LDS with a wave ballot + prefix count.  The
-//     inner loop then reads each survivor back with wave-uniform (broadcast) ds_read_b128s.
-//   * Backward: per-lane partial sums over its 4 pixels, then a DPP butterfly (quad_perm,
-//     row_half_mirror, row_mirror, row_bcast15/31) reduces 6+C values across the wave and one lane
-//     writes one 48-byte row per (tile, Gaussian) into a slot that is contiguous per Gaussian.
-//     reduce_partials then sums each Gaussian's rows in a fixed order: no float atomics, and the
-//     gradients are bit-reproducible run to run.
+//     record (3 x 16 B loads) and tests it exactly against each 8x8 block (minimum of the conic
+//     form over the block rectangle vs. the alpha >= 1/255 level set - conservative, so results
+//     are unchanged).  Gaussians that can reach a still-unfinished block are compacted into LDS
+//     with a wave ballot + prefix count, carrying a 4-bit block mask; the inner loop reads each
+//     survivor back with wave-uniform (broadcast) ds_read_b128s and runs the per-pixel math only
+//     for the blocks in its mask (scalar branches).  Finished blocks (all 64 pixels saturated)
+//     drop out of the mask, so dense scenes stop early block by block.
+//   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
+//     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
+//     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot
+//     that is contiguous per Gaussian.  reduce_partials sums each Gaussian's rows in a fixed order
+//     and applies the conic / opacity factors once: no float atomics, and the gradients are
+//     bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"
@@ -92,18 +95,19 @@ __device__ __forceinline__ float min_form_on_rect(float hA, float B, float hC, f
 
 // sigma * log2(e) for one pixel; explicit fmas so that forward and backward (which must replay the
 // forward's alpha >= 1/255 decisions) evaluate bit-identical values whatever the optimiser does.
-__device__ __forceinline__ float sigma_l2(float Adx2, float Bdx, float hC, float dy) {
-    return __builtin_fmaf(dy, __builtin_fmaf(hC, dy, Bdx), Adx2);
+__device__ __forceinline__ float sigma_l2(float diag, float Bdx, float dy) {
+    return __builtin_fmaf(dy, Bdx, diag);      // diag = hA dx^2 + hC dy^2
 }
 
 struct Staged {          // what a lane derives from the Gaussian it gathered
-    bool keep;
+    int mask;            // bit k set: the alpha >= 1/255 level set may reach 8x8 block k of the tile
     float gx, gy, hA, B, hC, lo;   // conic and opacity in the log2 domain
 };
 
-// gather + exact tile cull.  rect = pixel sample extents of the tile.
+// gather + exact cull against the four 8x8 pixel blocks of the tile (block k: bx = k&1, by = k>>1).
+// (X0,Y0) = sample position of the tile's first pixel.
 __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const float4 q1,
-                                              float X0, float X1, float Y0, float Y1) {
+                                              float X0, float Y0) {
     Staged s;
     s.gx = q0.x; s.gy = q0.y;
     const float A = q0.w, Bc = q1.x, Cc = q1.y, op = q0.z;
@@ -111,22 +115,32 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
     s.B = kLog2e * Bc;
     s.hC = 0.5f * kLog2e * Cc;
     s.lo = __log2f(op);
-    s.keep = have && (op > 0.0f);
-    if (s.keep) {
+    s.mask = 0;
+    if (have && op > 0.0f) {
         const float tau = s.lo + kLog2_255;            // sigma' <= tau  <=>  alpha >= 1/255
-        if (tau < -0.02f) {
-            s.keep = false;
-        } else if (s.hA > 0.0f && s.hC > 0.0f) {
-            const float xlo = s.gx - X1, xhi = s.gx - X0, ylo = s.gy - Y1, yhi = s.gy - Y0;
-            const float m = min_form_on_rect(s.hA, s.B, s.hC, xlo, xhi, ylo, yhi);
-            const float dxm = fmaxf(fabsf(xlo), fabsf(xhi)), dym = fmaxf(fabsf(ylo), fabsf(yhi));
-            const float mag = s.hA * dxm * dxm + s.hC * dym * dym + fabsf(s.B) * dxm * dym;
-            s.keep = (m <= tau + 0.02f + 4.0e-6f * mag);
+        if (tau >= -0.02f) {
+            if (s.hA > 0.0f && s.hC > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float bx0 = X0 + (float)(8 * (k & 1)), by0 = Y0 + (float)(8 * (k >> 1));
+                    const float xlo = s.gx - (bx0 + 7.0f), xhi = s.gx - bx0;
+                    const float ylo = s.gy - (by0 + 7.0f), yhi = s.gy - by0;
+                    const float m = min_form_on_rect(s.hA, s.B, s.hC, xlo, xhi, ylo, yhi);
+                    const float dxm = fmaxf(fabsf(xlo), fabsf(xhi));
+                    const float dym = fmaxf(fabsf(ylo), fabsf(yhi));
+                    const float mag = s.hA * dxm * dxm + s.hC * dym * dym + fabsf(s.B) * dxm * dym;
+                    if (m <= tau + 0.02f + 4.0e-6f * mag) s.mask |= (1 << k);
+                }
+            } else {
+                s.mask = 15;                            // not a PSD conic: no geometric cull
+            }
         }
     }
     return s;
 }
 
+// Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
+// that position in each of the four blocks k of the 16x16 tile.
 template <int CH>
 __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
@@ -140,30 +154,30 @@ __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
     float4* lds = lds_all[wave];
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
-    const int px = tx * 16 + (lane & 15);
-    const int py0 = ty * 16 + (lane >> 4);
-    const float fpx = (float)px + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
-    const float X0 = (float)(tx * 16) + ts::kPixOff, X1 = X0 + 15.0f;
-    const float Y0 = (float)(ty * 16) + ts::kPixOff, Y1 = Y0 + 15.0f;
+    const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
+    const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
 
-    float T[4], acc[4][CH];
+    // T = live transmittance (0 once the pixel is finished), Tout = transmittance to report
+    float T[4], Tout[4], acc[4][CH];
     int fidx[4];
-    bool done[4], inside[4];
+    bool inside[4];
+    int live = 0;                                   // blocks that still have unfinished pixels
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        inside[k] = (px < W) && (py0 + 4 * k < H);
-        done[k] = !inside[k];
-        T[k] = 1.0f;
+        inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H);
+        T[k] = inside[k] ? 1.0f : 0.0f;
+        Tout[k] = 1.0f;
         fidx[k] = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[k][c] = 0.0f;
+        if (__any(inside[k])) live |= (1 << k);
     }
 
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
-    bool all_done = __all(done[0] && done[1] && done[2] && done[3]);
 
-    for (int base = range.x; base < range.y && !all_done; base += 64) {
+    for (int base = range.x; base < range.y && live != 0; base += 64) {
         const int i = base + lane;
         const bool have = i < range.y;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
@@ -173,45 +187,56 @@ __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
             q1 = splats[3 * (size_t)g + 1];
             q2 = splats[3 * (size_t)g + 2];
         }
-        const Staged s = stage_splat(have, q0, q1, X0, X1, Y0, Y1);
-        const unsigned long long mask = __ballot(s.keep);
+        const Staged s = stage_splat(have, q0, q1, X0, Y0);
+        const bool keep = (s.mask & live) != 0;
+        const unsigned long long mask = __ballot(keep);
         const int cnt = __popcll(mask);
-        if (s.keep) {
+        if (keep) {
             const int pos = __popcll(mask & ((1ull << lane) - 1ull));
             lds[3 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
             lds[3 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
-            lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), 0.0f);
+            lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
         TS_WAVE_SYNC();
         for (int j = 0; j < cnt; ++j) {
             const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
-            const float dx = r0.x - fpx;
-            const float Adx2 = (r0.z * dx) * dx, Bdx = r0.w * dx;
-            const float dy0 = r0.y - fpy0;
+            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)) & live;
+            if (bm == 0) continue;
             const int idx = __float_as_int(r2.z);
+            float dxv[2], dyv[2], Ax[2], Bx[2], Cy[2];
+            dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+            dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Ax[h] = (r0.z * dxv[h]) * dxv[h];
+                Bx[h] = r0.w * dxv[h];
+                Cy[h] = (r1.x * dyv[h]) * dyv[h];
+            }
             float col[CH];
             col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
             if (CH == 4) col[CH - 1] = r2.y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float dy = dy0 - 4.0f * (float)k;
-                const float sg = sigma_l2(Adx2, Bdx, r1.x, dy);
+                if (!(bm & (1 << k))) continue;                       // wave-uniform
+                const float sg = sigma_l2(Ax[k & 1] + Cy[k >> 1], Bx[k & 1], dyv[k >> 1]);
                 const float a = fminf(ts::kAlphaMax, __builtin_amdgcn_exp2f(r1.y - sg));
-                const bool valid = !done[k] && (sg >= 0.0f) && (a >= ts::kAlphaMin);
-                const float nT = T[k] * (1.0f - a);
-                const bool stop = valid && (nT <= ts::kTEps);
-                const bool hit = valid && !stop;
-                const float vis = hit ? a * T[k] : 0.0f;
+                const bool ok = (sg >= 0.0f) && (a >= ts::kAlphaMin);
+                const float ae = ok ? a : 0.0f;
+                const float nT = __builtin_fmaf(-ae, T[k], T[k]);
+                const bool stop = nT <= ts::kTEps;                    // also true once T == 0
+                const float vis = stop ? 0.0f : ae * T[k];            // the stopping Gaussian is not composited
 #pragma unroll
-                for (int c = 0; c < CH; ++c) acc[k][c] += col[c] * vis;
-                T[k] = hit ? nT : T[k];
-                fidx[k] = hit ? idx : fidx[k];
-                done[k] = done[k] || stop;
+                for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
+                fidx[k] = (ok && !stop) ? idx : fidx[k];
+                Tout[k] = stop ? Tout[k] : nT;
+                T[k] = stop ? 0.0f : nT;
             }
-            all_done = __all(done[0] && done[1] && done[2] && done[3]);
-            if (all_done) break;
         }
         TS_WAVE_SYNC();
+        // per-block early out: a block whose 64 pixels are all finished is skipped from now on
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((live & (1 << k)) && !__any(T[k] != 0.0f)) live &= ~(1 << k);
     }
 
     float bg[CH];
@@ -221,13 +246,42 @@ __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!inside[k]) continue;
-        const size_t pix = (size_t)(py0 + 4 * k - row_off) * W + px;
-        final_Ts[pix] = T[k];
+        const size_t pix = (size_t)(py0 + 8 * (k >> 1) - row_off) * W + (px0 + 8 * (k & 1));
+        final_Ts[pix] = Tout[k];
         final_index[pix] = fidx[k];
         float* o = out_img + pix * CH;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + T[k] * bg[c];
+        for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + Tout[k] * bg[c];
     }
+}
+
+// Butterfly merge of two per-lane partial vectors: lanes whose `bit` is clear keep a, the others
+// keep b, and each adds the kept quantity of its partner lane (partner given by the DPP control).
+template <int CTRL>
+__device__ __forceinline__ float merge2(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_t(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// Reduces eight per-lane values over the wave: on return every lane l holds the wave sum of
+// v[l & 7].  8 DPP adds + 14 selects + 2 ds_bpermute adds instead of 8 x 6 DPP adds.
+__device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    const float u0 = merge2<0xB1>(v[0], v[1], b0), u1 = merge2<0xB1>(v[2], v[3], b0);
+    const float u2 = merge2<0xB1>(v[4], v[5], b0), u3 = merge2<0xB1>(v[6], v[7], b0);
+    const float w0 = merge2<0x4E>(u0, u1, b1), w1 = merge2<0x4E>(u2, u3, b1);
+    float x = merge2<0x124>(w0, w1, b2);     // row_ror:4  (source lane differs in bit 2, same bits 1:0)
+    x = dpp_add_t<0x128, 0xF>(x);            // row_ror:8  -> row-of-16 totals, value (lane & 7)
+    // rows hold different values per lane, so the single-lane row_bcast forms cannot be used here:
+    // combine the four rows lane-wise through the LDS crossbar (ds_bpermute, no memory access)
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
 }
 
 template <int CH>
@@ -237,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     const float4* __restrict__ splats, const float* __restrict__ background,
     const float* __restrict__ final_Ts, const int* __restrict__ final_index,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
-    float4* __restrict__ partials) {
+    float* __restrict__ partials) {
     __shared__ float4 lds_all[kWaves][64 * 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWaves + wave;
@@ -247,11 +301,9 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     float4* lds = lds_all[wave];
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
-    const int px = tx * 16 + (lane & 15);
-    const int py0 = ty * 16 + (lane >> 4);
-    const float fpx = (float)px + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
-    const float X0 = (float)(tx * 16) + ts::kPixOff, X1 = X0 + 15.0f;
-    const float Y0 = (float)(ty * 16) + ts::kPixOff, Y1 = Y0 + 15.0f;
+    const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
+    const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
     const int row_off = cam.tile_row0 * 16;
 
@@ -260,18 +312,19 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     for (int c = 0; c < CH; ++c) bg[c] = background[c];
 
     float T[4], tb[4], buf[4][CH], vo[4][CH];
-    int fidx[4];
+    int fidx[4], bmax[4];
     int fmax = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool inside = (px < W) && (py0 + 4 * k < H);
+        const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
+        const bool inside = (px < W) && (py < H);
         fidx[k] = -1;
         T[k] = 1.0f;
         tb[k] = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) { buf[k][c] = 0.0f; vo[k][c] = 0.0f; }
         if (inside) {
-            const size_t pix = (size_t)(py0 + 4 * k - row_off) * W + px;
+            const size_t pix = (size_t)(py - row_off) * W + px;
             fidx[k] = final_index[pix];
             T[k] = final_Ts[pix];
             float dotbg = 0.0f;
@@ -283,9 +336,9 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
             tb[k] = T[k] * (va - dotbg);
         }
-        fmax = max(fmax, fidx[k]);
+        bmax[k] = wave_max_int(fidx[k]);            // last list index any pixel of block k used
+        fmax = max(fmax, bmax[k]);
     }
-    fmax = wave_max_int(fmax);
     const int last = min(range.y - 1, fmax);
 
     for (int hi = last; hi >= range.x; hi -= 64) {
@@ -298,87 +351,88 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
             q1 = splats[3 * (size_t)g + 1];
             q2 = splats[3 * (size_t)g + 2];
         }
-        const Staged s = stage_splat(have, q0, q1, X0, X1, Y0, Y1);
-        const unsigned long long mask = __ballot(s.keep);
+        Staged s = stage_splat(have, q0, q1, X0, Y0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i > bmax[k]) s.mask &= ~(1 << k);   // nothing in block k got this far in forward
+        const bool keep = s.mask != 0;
+        const unsigned long long mask = __ballot(keep);
         const int cnt = __popcll(mask);
-        if (s.keep) {
+        if (keep) {
             const int pos = __popcll(mask & ((1ull << lane) - 1ull));
             const int slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
             lds[4 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
             lds[4 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
             lds[4 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(slot));
-            lds[4 * pos + 3] = make_float4(q0.w, q1.x, q1.y, q0.z);      // A, B, C, opacity
+            lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
         TS_WAVE_SYNC();
         for (int j = 0; j < cnt; ++j) {
             const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
-            const float dx = r0.x - fpx;
-            const float Adx2 = (r0.z * dx) * dx, Bdx = r0.w * dx;
-            const float dy0 = r0.y - fpy0;
+            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
             const int idx = __float_as_int(r2.z);
+            float dxv[2], dyv[2], Ax[2], Bx[2], Cy[2];
+            dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+            dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Ax[h] = (r0.z * dxv[h]) * dxv[h];
+                Bx[h] = r0.w * dxv[h];
+                Cy[h] = (r1.x * dyv[h]) * dyv[h];
+            }
             float col[CH];
             col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
             if (CH == 4) col[CH - 1] = r2.y;
 
-            float araw[4], dyv[4];
-            bool valid[4];
+            // per-lane sums over its (up to) four pixels
+            float s_ = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, vc[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) vc[c] = 0.0f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                dyv[k] = dy0 - 4.0f * (float)k;
-                const float sg = sigma_l2(Adx2, Bdx, r1.x, dyv[k]);
-                araw[k] = __builtin_amdgcn_exp2f(r1.y - sg);                 // opacity * exp(-sigma)
-                valid[k] = (idx <= fidx[k]) && (sg >= 0.0f) &&
-                           (fminf(ts::kAlphaMax, araw[k]) >= ts::kAlphaMin);
-                any = any || valid[k];
-            }
-            if (!__any(any)) continue;
-
-            float s_ = 0.0f, sy = 0.0f, syy = 0.0f, vc[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) vc[c] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (valid[k]) {
-                    const float a = fminf(ts::kAlphaMax, araw[k]);
+                if (!(bm & (1 << k))) continue;                       // wave-uniform
+                const float dx = dxv[k & 1], dy = dyv[k >> 1];
+                const float sg = sigma_l2(Ax[k & 1] + Cy[k >> 1], Bx[k & 1], dy);
+                const float araw = __builtin_amdgcn_exp2f(r1.y - sg);  // opacity * exp(-sigma)
+                const float a = fminf(ts::kAlphaMax, araw);
+                const bool valid = (idx <= fidx[k]) && (sg >= 0.0f) && (a >= ts::kAlphaMin);
+                if (valid) {
+                    any = true;
                     const float ra = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tk = T[k] * ra;                 // transmittance in front of g
                     const float fac = a * Tk;
                     float v_a = ra * tb[k];
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        vc[c] += fac * vo[k][c];
-                        v_a += (col[c] * Tk - buf[k][c] * ra) * vo[k][c];
-                        buf[k][c] += col[c] * fac;
+                        vc[c] = __builtin_fmaf(fac, vo[k][c], vc[c]);
+                        v_a = __builtin_fmaf(col[c] * Tk - buf[k][c] * ra, vo[k][c], v_a);
+                        buf[k][c] = __builtin_fmaf(col[c], fac, buf[k][c]);
                     }
                     T[k] = Tk;
                     // d alpha / d sigma = -araw unless the 0.999 clamp is active (then 0)
-                    const float v_sig = (araw[k] > ts::kAlphaMax) ? 0.0f : -araw[k] * v_a;
-                    s_ += v_sig;
-                    sy += v_sig * dyv[k];
-                    syy += v_sig * dyv[k] * dyv[k];
+                    const float v_sig = (araw > ts::kAlphaMax) ? 0.0f : -araw * v_a;
+                    const float vdx = v_sig * dx, vdy = v_sig * dy;
+                    s_ += v_sig; sx += vdx; sy += vdy;
+                    sxx = __builtin_fmaf(vdx, dx, sxx);
+                    sxy = __builtin_fmaf(vdx, dy, sxy);
+                    syy = __builtin_fmaf(vdy, dy, syy);
                 }
             }
-            float red[6 + CH];
-            red[0] = wave_sum_hi(s_);
-            red[1] = wave_sum_hi(dx * s_);
-            red[2] = wave_sum_hi(sy);
-            red[3] = wave_sum_hi(dx * dx * s_);
-            red[4] = wave_sum_hi(dx * sy);
-            red[5] = wave_sum_hi(syy);
+            if (!__any(any)) continue;
+            const float v8[8] = {s_, sx, sy, sxx, sxy, syy, vc[0], vc[1]};
+            const float r8 = wave_sum8(v8, lane);
+            float rc[2] = {0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < CH; ++c) red[6 + c] = wave_sum_hi(vc[c]);
-            if (lane == 63) {
-                const float4 r3 = lds[4 * j + 3];
+            for (int c = 2; c < CH; ++c) rc[c - 2] = wave_sum_hi(vc[c]);
+            const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
+            if (w >= 0 && w < 6 + CH) {
                 const long long slot = (long long)__float_as_int(r2.w);
                 if (slot >= 0 && slot < num_isects) {
-                    const float v_x = r3.x * red[1] + r3.y * red[2];
-                    const float v_y = r3.y * red[1] + r3.z * red[2];
-                    const float v_op = -red[0] / r3.w;
-                    float4* row = partials + 3 * slot;
-                    row[0] = make_float4(v_x, v_y, v_op, 0.5f * red[3]);
-                    row[1] = make_float4(red[4], 0.5f * red[5], red[6], red[7]);
-                    row[2] = make_float4(red[8], CH == 4 ? red[6 + CH - 1] : 0.0f, 0.0f, 0.0f);
+                    float val = r8;
+                    if (w == 8) val = rc[0];
+                    if (CH == 4 && w == 9) val = rc[1];
+                    partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
                 }
             }
         }
@@ -386,11 +440,15 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     }
 }
 
+// Row layout (raw sums over the pixels of one tile, see raster_bwd_kernel):
+//   [ S v_sigma, S v_sigma dx, S v_sigma dy, S v_sigma dx^2, S v_sigma dx dy, S v_sigma dy^2, c0..c3, -, - ]
+// with d = xy - pixel.  The conic / opacity factors are applied once per Gaussian here.
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
-    const float4* __restrict__ partials, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_opacity) {
+    const float4* __restrict__ partials, const float4* __restrict__ splats,
+    float* __restrict__ v_xy, float* __restrict__ v_conic, float* __restrict__ v_colors,
+    float* __restrict__ v_opacity) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
@@ -402,9 +460,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
         a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
         a2.x += p2.x; a2.y += p2.y;
     }
-    reinterpret_cast<float2*>(v_xy)[i] = make_float2(a0.x, a0.y);
-    v_opacity[i] = a0.z;
-    v_conic[3 * i] = a0.w; v_conic[3 * i + 1] = a1.x; v_conic[3 * i + 2] = a1.y;
+    float vx = 0.f, vy = 0.f, vop = 0.f;
+    if (cnt > 0) {
+        const float4 q0 = splats[3 * (size_t)i], q1 = splats[3 * (size_t)i + 1];
+        const float A = q0.w, B = q1.x, C = q1.y, op = q0.z;
+        vx = A * a0.y + B * a0.z;
+        vy = B * a0.y + C * a0.z;
+        vop = op > 0.0f ? -a0.x / op : 0.0f;
+    }
+    reinterpret_cast<float2*>(v_xy)[i] = make_float2(vx, vy);
+    v_opacity[i] = vop;
+    v_conic[3 * i] = 0.5f * a0.w; v_conic[3 * i + 1] = a1.x; v_conic[3 * i + 2] = 0.5f * a1.y;
     if (CH == 4) {
         reinterpret_cast<float4*>(v_colors)[i] = make_float4(a1.z, a1.w, a2.x, a2.y);
     } else {
@@ -455,34 +521,35 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
     if (e != hipSuccess) return (int)e;
     const int grid = (nt + kWaves - 1) / kWaves;
     const float4* sp = reinterpret_cast<const float4*>(splats);
-    float4* pr = reinterpret_cast<float4*>(partials);
     if (channels == 3)
         hipLaunchKernelGGL(raster_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, pr);
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials);
     else
         hipLaunchKernelGGL(raster_bwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, pr);
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials);
     return launch_status();
 }
 
 int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
-                       const int32_t* cum_tiles_hit, const float* partials, float* v_xy,
-                       float* v_conic, float* v_colors, float* v_opacity, void* stream) {
+                       const int32_t* cum_tiles_hit, const float* partials, const float* splats,
+                       float* v_xy, float* v_conic, float* v_colors, float* v_opacity,
+                       void* stream) {
     if (n < 0 || (channels != 3 && channels != 4)) return TS_E_BADARG;
     if (n == 0) return 0;
-    if (!num_tiles_hit || !cum_tiles_hit || !v_xy || !v_conic || !v_colors || !v_opacity)
+    if (!num_tiles_hit || !cum_tiles_hit || !splats || !v_xy || !v_conic || !v_colors || !v_opacity)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const float4* pr = reinterpret_cast<const float4*>(partials);
+    const float4* sp = reinterpret_cast<const float4*>(splats);
     const int grid = (n + 255) / 256;
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
-                           cum_tiles_hit, pr, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, sp, v_xy, v_conic, v_colors, v_opacity);
     else
         hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
-                           cum_tiles_hit, pr, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, sp, v_xy, v_conic, v_colors, v_opacity);
     return launch_status();
 }
 

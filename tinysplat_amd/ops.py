@@ -406,7 +406,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
                                          _ptr(v_out_alpha), _ptr(partials), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
-                                              _ptr(partials), _ptr(v_xy), _ptr(v_conic),
+                                              _ptr(partials), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                                               _ptr(v_colors), _ptr(v_opacity), s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
                 None, None, None, None)

@@ -96,20 +96,24 @@ int64_t ts_scan_ws_ints(int32_t n);
 int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hit,
                   int32_t* scan_ws, void* stream);
 
-/* tile_count[t] = number of Gaussians whose tile rectangle covers stripe-local tile t
- * (t = (ty - tile_row0) * tile_bounds_x + tx).  tile_count is zeroed by this call. */
+/* Tile bucketing without global atomics.  The Gaussians are cut into B = ts_bin_chunks(n) contiguous
+ * chunks; bin_ws (>= ts_bin_ws_ints(n, num_tiles) int32, num_tiles = tile_rows * tile_bounds_x) holds
+ * the B x num_tiles count matrix followed by num_tiles tile totals.  Stripe-local tile index
+ * t = (ty - tile_row0) * tile_bounds_x + tx. */
+int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles);
+
+/* bin_ws[b][t] = number of Gaussians of chunk b whose tile rectangle covers tile t (LDS histograms). */
 int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
-                 int32_t* tile_count, void* stream);
+                 int32_t* bin_ws, void* stream);
 
-/* Exclusive scan of tile_count -> tile_bins[t] = {start, end} (both 0 for an empty tile) and
- * tile_cursor[t] = start.  num_tiles = tile_rows * tile_bounds_x. */
-int ts_tile_offsets(int32_t num_tiles, const int32_t* tile_count, int32_t* tile_bins,
-                    int32_t* tile_cursor, void* stream);
+/* Turns the counts into bases in place (exclusive scan down the chunk axis, then over tiles) and
+ * writes tile_bins[t] = {start, end} (both 0 for an empty tile). */
+int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins, void* stream);
 
-/* Appends key = (float_bits(depth) << 32 | gaussian_id) to each covered tile's bucket of isect_keys
- * (order inside a bucket is arbitrary until ts_sort_tiles).  tile_cursor is consumed. */
+/* Writes key = (float_bits(depth) << 32 | gaussian_id) of every (Gaussian, covered tile) pair into
+ * the tile's bucket of isect_keys (order inside a bucket is arbitrary until ts_sort_tiles). */
 int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
-                   const ts_camera* cam_host, int32_t* tile_cursor, uint64_t* isect_keys,
+                   const ts_camera* cam_host, const int32_t* bin_ws, uint64_t* isect_keys,
                    void* stream);
 
 /* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort

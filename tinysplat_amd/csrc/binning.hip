@@ -6,15 +6,15 @@
 // Here the same final order (tile-major, then depth bits, ties by ascending Gaussian id) is produced
 // without a global sort:
 //   scan_tiles      wave-scan (DPP-free __shfl_up ladder inside a wave, LDS across the 4 waves)
-//   bin_count       one lane per Gaussian, hardware atomics on T tile counters
-//   tile_offsets    single-workgroup exclusive scan over tiles -> tile_bins, cursors
-//   bin_scatter     one lane per Gaussian, returning atomics on the cursors, 8-byte key stores
+//   bin_count       per-chunk tile histograms in LDS (ds_add), B x T count matrix, no global atomics
+//   tile_offsets    column scan of the matrix (per-chunk bases) + exclusive scan over tiles -> tile_bins
+//   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 8-byte key stores
 //                   key = depth_bits << 32 | gaussian_id   (unique inside a tile)
 //   sort_tiles      one workgroup per tile: LDS bitonic network (flip/disperse form, all compares
 //                   ascending, so the tail of a non-power-of-two list needs no padding storage);
 //                   buckets larger than the LDS budget run the same network in global memory
 //   pack_splats     gathers the compositing operands of a Gaussian into one 48-byte record
-// Traffic: 8 I written + 8 I read + 4 I written (+ 2 I atomics) against the 36 I a 3-pass 64-bit
+// Traffic: 8 I written + 8 I read + 4 I written (+ 8 B T for the count matrix) against the 36 I a 3-pass 64-bit
 // LSD radix sort of key+payload would move at minimum.
 #include <hip/hip_runtime.h>
 
@@ -104,38 +104,85 @@ __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restri
         if (base + k < n) out[base + k] += add;
 }
 
-__global__ __launch_bounds__(kThreads) void bin_count_kernel(int n, const float* __restrict__ xys,
-                                                             const int* __restrict__ radii,
-                                                             const ts_camera cam,
-                                                             int* __restrict__ tile_count) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const int r = radii[i];
-    if (r <= 0) return;
-    const float2 xy = reinterpret_cast<const float2*>(xys)[i];
-    const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
-                                        cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-    for (int ty = b.miny; ty < b.maxy; ++ty)
-        for (int tx = b.minx; tx < b.maxx; ++tx)
-            atomicAdd(&tile_count[(ty - cam.tile_row0) * cam.tile_bounds_x + tx], 1);
+// ---- tile bucketing without global atomics --------------------------------------------------
+// Device-scope atomics on MI355X are executed memory-side (the per-XCD L2s are not coherent), and
+// measured ~25 G atomics/s: 6 M intersections cost 0.25 ms per pass.  Instead the Gaussians are cut
+// into B contiguous chunks; workgroup b builds the tile histogram of its chunk in LDS (ds_add, no
+// memory traffic), the B x T count matrix is column-scanned into per-(chunk,tile) bases, and the
+// scatter pass replays the chunk with LDS cursors preloaded from those bases.  The order inside a
+// bucket is arbitrary (LDS atomic order); sort_tiles makes it canonical.
+constexpr int kBinThreads = 512;
+constexpr int kBinChunkMin = 4096;        // Gaussians per chunk (at least)
+constexpr int kBinMaxChunks = 512;
+constexpr int kBinWindow = 36864;         // tiles per LDS window (144 KiB of the 160 KiB LDS)
+
+__host__ __device__ inline int bin_num_chunks(int n) {
+    int b = (n + kBinChunkMin - 1) / kBinChunkMin;
+    if (b < 1) b = 1;
+    if (b > kBinMaxChunks) b = kBinMaxChunks;
+    return b;
 }
 
+// grid = (chunks, windows); counts[b * T + t]
+__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
+    int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
+    const ts_camera cam, int num_tiles, int* __restrict__ counts) {
+    extern __shared__ int hist[];
+    const int t0 = blockIdx.y * kBinWindow;
+    const int tw = min(num_tiles - t0, kBinWindow);
+    for (int j = threadIdx.x; j < tw; j += kBinThreads) hist[j] = 0;
+    __syncthreads();
+    const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+    for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
+        const int r = radii[i];
+        if (r <= 0) continue;
+        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
+                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+        for (int ty = b.miny; ty < b.maxy; ++ty)
+            for (int tx = b.minx; tx < b.maxx; ++tx) {
+                const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
+                if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
+            }
+    }
+    __syncthreads();
+    int* dst = counts + (size_t)blockIdx.x * num_tiles + t0;
+    for (int j = threadIdx.x; j < tw; j += kBinThreads) dst[j] = hist[j];
+}
+
+// one lane per tile: exclusive scan down the chunk axis; tile_total[t] = column sum
+__global__ __launch_bounds__(kThreads) void column_scan_kernel(int num_tiles, int chunks,
+                                                               int* __restrict__ counts,
+                                                               int* __restrict__ tile_total) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= num_tiles) return;
+    int run = 0;
+    int* col = counts + t;
+#pragma unroll 8
+    for (int b = 0; b < chunks; ++b) {
+        const int c = col[(size_t)b * num_tiles];
+        col[(size_t)b * num_tiles] = run;
+        run += c;
+    }
+    tile_total[t] = run;
+}
+
+// single workgroup: exclusive scan over tiles -> tile_bins, and tile_total[t] becomes start[t]
 __global__ __launch_bounds__(kThreads) void tile_offsets_kernel(int num_tiles,
-                                                                const int* __restrict__ tile_count,
-                                                                int* __restrict__ tile_bins,
-                                                                int* __restrict__ tile_cursor) {
+                                                                int* __restrict__ tile_total,
+                                                                int* __restrict__ tile_bins) {
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < num_tiles; base += kThreads) {
         const int t = base + threadIdx.x;
-        const int v = (t < num_tiles) ? tile_count[t] : 0;
+        const int v = (t < num_tiles) ? tile_total[t] : 0;
         int total;
         const int inc = block_inclusive_scan(v, &total);
         const int c = carry;
         if (t < num_tiles) {
             const int start = c + inc - v;
-            tile_cursor[t] = start;
+            tile_total[t] = start;
             reinterpret_cast<int2*>(tile_bins)[t] = v > 0 ? make_int2(start, start + v)
                                                           : make_int2(0, 0);
         }
@@ -145,24 +192,32 @@ __global__ __launch_bounds__(kThreads) void tile_offsets_kernel(int num_tiles,
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bin_scatter_kernel(
-    int n, const float* __restrict__ xys, const float* __restrict__ depths,
-    const int* __restrict__ radii, const ts_camera cam, int* __restrict__ tile_cursor,
+__global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
+    int n, int chunk, const float* __restrict__ xys, const float* __restrict__ depths,
+    const int* __restrict__ radii, const ts_camera cam, int num_tiles,
+    const int* __restrict__ bases, const int* __restrict__ tile_start,
     unsigned long long* __restrict__ keys) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const int r = radii[i];
-    if (r <= 0) return;
-    const float2 xy = reinterpret_cast<const float2*>(xys)[i];
-    const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
-                                        cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-    const unsigned long long key =
-        ((unsigned long long)__float_as_uint(depths[i]) << 32) | (unsigned int)i;
-    for (int ty = b.miny; ty < b.maxy; ++ty)
-        for (int tx = b.minx; tx < b.maxx; ++tx) {
-            const int pos = atomicAdd(&tile_cursor[(ty - cam.tile_row0) * cam.tile_bounds_x + tx], 1);
-            keys[pos] = key;
-        }
+    extern __shared__ int cursor[];
+    const int t0 = blockIdx.y * kBinWindow;
+    const int tw = min(num_tiles - t0, kBinWindow);
+    const int* src = bases + (size_t)blockIdx.x * num_tiles + t0;
+    for (int j = threadIdx.x; j < tw; j += kBinThreads) cursor[j] = tile_start[t0 + j] + src[j];
+    __syncthreads();
+    const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+    for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
+        const int r = radii[i];
+        if (r <= 0) continue;
+        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
+                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(depths[i]) << 32) | (unsigned int)i;
+        for (int ty = b.miny; ty < b.maxy; ++ty)
+            for (int tx = b.minx; tx < b.maxx; ++tx) {
+                const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
+                if ((unsigned)t < (unsigned)tw) keys[atomicAdd(&cursor[t], 1)] = key;
+            }
+    }
 }
 
 // ---- per-tile bitonic sort ---------------------------------------------------------------------
@@ -281,39 +336,66 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
     return launch_status();
 }
 
+int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
+    if (num_tiles < 0) num_tiles = 0;
+    return (int64_t)bin_num_chunks(n) * num_tiles + num_tiles + 1;
+}
+
+static size_t bin_lds_bytes(int num_tiles) {
+    return (size_t)(num_tiles < kBinWindow ? num_tiles : kBinWindow) * sizeof(int);
+}
+
 int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
-                 int32_t* tile_count, void* stream) {
-    if (n < 0 || !cam || !tile_count) return TS_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t nt = (size_t)cam->tile_rows * cam->tile_bounds_x;
-    hipError_t e = hipMemsetAsync(tile_count, 0, nt * sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
-    if (n == 0) return 0;
-    if (!xys || !radii) return TS_E_BADARG;
-    hipLaunchKernelGGL(bin_count_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
-                       n, xys, radii, *cam, tile_count);
+                 int32_t* bin_ws, void* stream) {
+    if (n < 0 || !cam || !bin_ws) return TS_E_BADARG;
+    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    if (nt <= 0) return 0;
+    if (n > 0 && (!xys || !radii)) return TS_E_BADARG;
+    const int chunks = bin_num_chunks(n);
+    const int chunk = n > 0 ? (n + chunks - 1) / chunks : 1;
+    const int windows = (nt + kBinWindow - 1) / kBinWindow;
+    const size_t lds = bin_lds_bytes(nt);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_count_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
+                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, bin_ws);
     return launch_status();
 }
 
-int ts_tile_offsets(int32_t num_tiles, const int32_t* tile_count, int32_t* tile_bins,
-                    int32_t* tile_cursor, void* stream) {
-    if (num_tiles < 0) return TS_E_BADARG;
+int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
+                    void* stream) {
+    if (n < 0 || num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
-    if (!tile_count || !tile_bins || !tile_cursor) return TS_E_BADARG;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
-                       num_tiles, tile_count, tile_bins, tile_cursor);
+    if (!bin_ws || !tile_bins) return TS_E_BADARG;
+    const int chunks = bin_num_chunks(n);
+    int* tile_total = bin_ws + (size_t)chunks * num_tiles;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(column_scan_kernel, dim3((num_tiles + kThreads - 1) / kThreads),
+                       dim3(kThreads), 0, s, num_tiles, chunks, bin_ws, tile_total);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kThreads), 0, s, num_tiles, tile_total,
+                       tile_bins);
     return launch_status();
 }
 
 int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
-                   const ts_camera* cam, int32_t* tile_cursor, uint64_t* isect_keys,
+                   const ts_camera* cam, const int32_t* bin_ws, uint64_t* isect_keys,
                    void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
-    if (!xys || !depths || !radii || !tile_cursor || !isect_keys) return TS_E_BADARG;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       (hipStream_t)stream, n, xys, depths, radii, *cam, tile_cursor,
-                       reinterpret_cast<unsigned long long*>(isect_keys));
+    if (!xys || !depths || !radii || !bin_ws || !isect_keys) return TS_E_BADARG;
+    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    if (nt <= 0) return 0;
+    const int chunks = bin_num_chunks(n);
+    const int chunk = (n + chunks - 1) / chunks;
+    const int windows = (nt + kBinWindow - 1) / kBinWindow;
+    const size_t lds = bin_lds_bytes(nt);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_scatter_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
+                       (hipStream_t)stream, n, chunk, xys, depths, radii, *cam, nt, bin_ws,
+                       bin_ws + (size_t)chunks * nt, reinterpret_cast<unsigned long long*>(isect_keys));
     return launch_status();
 }
 

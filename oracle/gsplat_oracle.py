@@ -167,7 +167,7 @@ def tile_bbox(xys: Tensor, radii_f: Tensor, tile_bounds):
 def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
                       viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
                       img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
-                      clip_thresh: float = CLIP_THRESH):
+                      clip_thresh: float = CLIP_THRESH, tile_rows=None):
     """-> (xys[N,2], depths[N], radii[N] i32, conics[N,3], num_tiles_hit[N] i32, cov3d[N,6]).
 
     Culled Gaussians (behind the near plane, singular 2D covariance, no tile hit) have every output 0.
@@ -269,6 +269,8 @@ def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats:
     cov3d_o = torch.where(in_front[:, None], cov3d, torch.zeros(1, dtype=dt))
     radii_o = torch.where(ok, radius, zero).to(torch.int32)
     nth_o = torch.where(ok, nth, torch.zeros_like(nth)).to(torch.int32)
+    if tile_rows is not None:      # stripes: everything as for the full frame, only the count differs
+        nth_o = stripe_tiles_hit(xys_o, radii_o, tile_bounds, tile_rows)
     return xys_o, depths_o, radii_o, conics_o, nth_o, cov3d_o
 
 
@@ -328,9 +330,28 @@ def bin_and_sort(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tens
 # --------------------------------------------------------------------------------------------------
 # rasterize_gaussians   (call sites rasterize.py:44,50, args rasterize.py:83-86)
 # --------------------------------------------------------------------------------------------------
+def full_frame_tiles_hit(xys: Tensor, radii: Tensor, tile_bounds) -> Tensor:
+    """num_tiles_hit over the whole tile grid, recomputed from (xys, radii)."""
+    minx, miny, maxx, maxy = tile_bbox(xys.detach().to(torch.float32), radii.to(torch.float32),
+                                       tile_bounds)
+    cnt = (maxx - minx) * (maxy - miny)
+    return torch.where(radii > 0, cnt, torch.zeros_like(cnt)).to(torch.int32)
+
+
+def stripe_tiles_hit(xys: Tensor, radii: Tensor, tile_bounds, tile_rows) -> Tensor:
+    """num_tiles_hit restricted to tile rows [r0, r1) (multi-GPU stripes; the build's extension)."""
+    minx, miny, maxx, maxy = tile_bbox(xys.detach().to(torch.float32), radii.to(torch.float32),
+                                       tile_bounds)
+    r0, r1 = int(tile_rows[0]), int(tile_rows[1])
+    h = (torch.clamp(maxy, max=r1) - torch.clamp(miny, min=r0)).clamp(min=0)
+    cnt = (maxx - minx) * h
+    return torch.where(radii > 0, cnt, torch.zeros_like(cnt)).to(torch.int32)
+
+
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
                         num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
-                        img_width: int, background: Tensor, return_aux: bool = False):
+                        img_width: int, background: Tensor, return_aux: bool = False,
+                        tile_rows=None):
     """-> (out_img[H,W,C], out_alpha[H,W]); with return_aux also a dict of final_Ts, final_index,
     tile_bins, gaussian_ids_sorted and ``margin`` (per-pixel distance of the closest discrete decision
     - alpha >= 1/255, next_T <= 1e-4 - to its threshold, relative; pixels with a tiny margin are the
@@ -344,9 +365,14 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     H, W = int(img_height), int(img_width)
     C = colors.shape[1]
     tbx, tby = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+    if tile_rows is not None:
+        # stripe mode (not part of the reference API): composite only tile rows [r0, r1) of the
+        # full-frame binning and return that stripe's pixel rows
+        num_tiles_hit = full_frame_tiles_hit(xys, radii, (tbx, tby, 1))
     _, _, gids, tile_bins = bin_and_sort(xys, depths, radii, num_tiles_hit, (tbx, tby, 1))
     gids = gids.to(torch.int64)
     bg = background.to(dt)
+    row_lo, row_hi = (0, tby) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
 
     out_img = torch.zeros(H, W, C, dtype=dt) + bg            # empty tiles: T=1 -> background
     out_alpha = torch.zeros(H, W, dtype=dt)
@@ -355,7 +381,7 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     margin = torch.full((H, W), float("inf"), dtype=torch.float64)
     img_parts = {}
 
-    for t in range(tbx * tby):
+    for t in range(row_lo * tbx, row_hi * tbx):
         s, e = int(tile_bins[t, 0]), int(tile_bins[t, 1])
         if e <= s:
             continue
@@ -424,6 +450,10 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
                     cols.append(bg.expand(y1 - y0, x1 - x0, C))
             rows.append(torch.cat(cols, dim=1))
         out_img = torch.cat(rows, dim=0)
+    if tile_rows is not None:
+        y0, y1 = row_lo * BLOCK, min(row_hi * BLOCK, H)
+        out_img, out_alpha = out_img[y0:y1], out_alpha[y0:y1]
+        final_T, final_idx, margin = final_T[y0:y1], final_idx[y0:y1], margin[y0:y1]
     if return_aux:
         aux = {"final_Ts": final_T, "final_index": final_idx, "tile_bins": tile_bins,
                "gaussian_ids_sorted": gids.to(torch.int32), "margin": margin}

@@ -1,0 +1,91 @@
+"""The C-ABI shared library loads and exports exactly the symbols include/tinysplat_hip.h declares,
+the ctypes binding covers all of them, and the product never routes through the oracle or a CPU
+path.  No GPU needed (no compute entry is called)."""
+import ctypes
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "tinysplat_hip.h"
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tinysplat_amd import _lib
+    assert _lib.LIB_PATH.exists(), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True,
+                        text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\bT (ts_[a-z0-9_]+)", nm)))
+    assert exported == names, (set(exported) ^ set(names))
+
+
+def test_binding_covers_the_header_and_version_matches():
+    from tinysplat_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
+    assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
+    assert ctypes.sizeof(_lib.TsCamera) == 48
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from tinysplat_amd import _lib
+    lib = _lib.load()
+    # negative sizes / bad channel counts / bad SH degrees are rejected before any launch
+    assert lib.ts_sh_fwd(-1, 0, 1, None, None, None, None) == -1
+    assert lib.ts_sh_fwd(4, 2, 4, None, None, None, None) == -2      # degree 2 needs 9 bases
+    assert lib.ts_sh_fwd(4, 0, 5, None, None, None, None) == -2      # 5 is not a base count
+    assert lib.ts_project_fwd(-3, *([None] * 5), None, *([None] * 7)) == -1
+    cam = _lib.TsCamera(1, 1, 0, 0, 16, 16, 1, 1, 0, 1, 1.0, 0.01)
+    assert lib.ts_pack_splats(4, 5, *([None] * 6), cam, None, None) == -1
+    assert lib.ts_raster_fwd(2, cam, *([None] * 8)) == -1
+
+
+def test_ops_refuse_cpu_tensors_and_product_never_imports_the_oracle():
+    import tinysplat_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tinysplat_amd.project_gaussians(torch.zeros(1, 3), torch.ones(1, 3), 1.0,
+                                        torch.tensor([[1.0, 0, 0, 0]]), torch.eye(4)[:3], torch.eye(4),
+                                        1.0, 1.0, 8, 8, 16, 16, (1, 1, 1))
+    with pytest.raises(RuntimeError):
+        tinysplat_amd.rasterize_gaussians(torch.zeros(1, 2), torch.zeros(1), torch.zeros(1, dtype=torch.int32),
+                                          torch.zeros(1, 3), torch.zeros(1, dtype=torch.int32),
+                                          torch.zeros(1, 3), torch.zeros(1, 1), 16, 16, torch.zeros(3))
+    for py in (ROOT / "tinysplat_amd").rglob("*.py"):
+        src = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{py} imports the oracle"
+    for py in (ROOT / "tinysplat_amd" / "csrc").glob("*"):
+        if py.suffix in (".hip", ".h"):
+            assert "oracle/" not in py.read_text().replace("oracle/gsplat_oracle.py::", ""), py
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from tinysplat_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libtinysplat_hip.so")
+    with pytest.raises(_lib.HipLibraryError, match="no CPU or PyTorch fallback"):
+        _lib.load()
+
+
+def test_sh_helpers_match_reference_call_sites():
+    from tinysplat_amd import deg_from_sh, num_sh_bases
+    from tinysplat_amd import sh as shmod
+    assert [num_sh_bases(d) for d in range(5)] == [1, 4, 9, 16, 25]
+    assert [deg_from_sh(k) for k in (1, 4, 9, 16, 25)] == [0, 1, 2, 3, 4]
+    with pytest.raises(ValueError):
+        deg_from_sh(7)
+    assert shmod.spherical_harmonics is not None and shmod.num_sh_bases(3) == 16

@@ -1,0 +1,65 @@
+"""HIP path against the golden fixtures captured from the reference adapter (see test_golden.py):
+the recorded boundary arguments go through the C ABI and must give the recorded results."""
+import pytest
+import torch
+
+from oracle import gsplat_oracle as O
+from tinysplat_amd import ops
+from tinysplat_amd.rasterizer import GaussianRasterizer
+
+from helpers import assert_close_masked
+from test_golden import FRAMES, load_case, recorded_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev(args):
+    return [a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args]
+
+
+@pytest.mark.parametrize("name", FRAMES)
+def test_recorded_calls_through_the_c_abi(name):
+    z, model, cam, dims = load_case(name)
+    w, h = dims
+    # project_gaussians: recorded inputs -> recorded outputs (they are the inputs of call 2), bit-exact
+    out = ops.project_gaussians(*_dev(recorded_args(z, 0, "project_gaussians")))
+    r2 = recorded_args(z, 2, "rasterize_gaussians")
+    for got, ref, nm in zip(out[:5], r2[:5], ["xys", "depths", "radii", "conics", "num_tiles_hit"]):
+        assert torch.equal(got.cpu(), ref), nm
+    # spherical_harmonics
+    col = ops.spherical_harmonics(*_dev(recorded_args(z, 1, "spherical_harmonics")))
+    assert torch.allclose(torch.clamp(col + 0.5, min=0.0).cpu(), r2[5], atol=2e-6)
+    # rasterize_gaussians, RGB pass and depth pass; threshold-unstable pixels masked via the oracle
+    for ci, key, tol in ((2, "rgb", 1e-5), (3, "depth", 1e-4)):
+        ra = recorded_args(z, ci, "rasterize_gaussians")
+        a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in ra]
+        ref_img, ref_alpha, aux = O.rasterize_gaussians(*a64, return_aux=True)
+        stable = aux["margin"] > 1e-4
+        img, alpha = ops.rasterize_gaussians(*_dev(ra))
+        assert img.shape == (h, w, 3) and alpha.shape == (h, w)
+        assert_close_masked(img, ref_img, tol, stable, what=key)
+        assert_close_masked(alpha, ref_alpha, 1e-5, stable, what="alpha")
+        gold = torch.from_numpy(z[key])
+        mine = torch.clamp(img, max=1.0).cpu() if key == "rgb" else img[:, :, 0].cpu()
+        assert_close_masked(mine, gold, 2 * tol, stable, what=key + " vs fixture")
+
+
+@pytest.mark.parametrize("name", FRAMES)
+def test_adapter_frame_on_gpu_matches_reference_adapter_frame(name):
+    z, model, cam, dims = load_case(name)
+    md = model.to(DEV)
+    with torch.no_grad():
+        rgb, extras = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, None, int(z["sh_degree"]))
+    # stability mask from the recorded rasterize arguments
+    ra = recorded_args(z, 2, "rasterize_gaussians")
+    a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in ra]
+    _, _, aux = O.rasterize_gaussians(*a64, return_aux=True)
+    stable = aux["margin"] > 1e-4
+    same = (extras["radii"].cpu() == torch.from_numpy(z["radii"])).double().mean()
+    assert same > 0.995          # exp(scales) runs in torch on a different device here
+    if same == 1.0:
+        assert_close_masked(rgb, torch.from_numpy(z["rgb"]), 2e-5, stable, what="rgb")
+        assert_close_masked(extras["depth"], torch.from_numpy(z["depth"]), 2e-4, stable, what="depth")
+    assert extras["camera"] == {"height": dims[1], "width": dims[0]}
+    assert extras["xys"].shape == (int(z["n"]), 2)

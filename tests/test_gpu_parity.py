@@ -250,3 +250,45 @@ def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult):
 def test_cpu_tensors_raise():
     with pytest.raises(RuntimeError):
         ops.spherical_harmonics(0, torch.zeros(2, 3), torch.zeros(2, 1, 3))
+
+
+def test_tile_row_stripes_tile_the_frame():
+    """Multi-GPU partition on one GPU: rendering tile-row stripes separately reproduces the full
+    frame bit-for-bit (pixels are independent) and the per-stripe 2-D gradients sum to the full
+    frame's (what the all-reduce in sharding.py computes)."""
+    from tinysplat_amd.sharding import stripe_rows
+    n, w, h = 20000, 400, 300                      # 19 tile rows, last one partial
+    model, cam = scene_args(n, 1, w, h, seed=13, scale_mult=2.5)
+    model.background = torch.tensor([0.1, 0.6, 0.3])
+    md = model.to(DEV)
+    pa = _to_dev(project_args(md, cam, (w, h), DEV))
+    tby = pa[12][1]
+    g = torch.Generator().manual_seed(2)
+    w_img = torch.rand(h, w, 3, generator=g).to(DEV)
+
+    def run(tile_rows):
+        kw = {} if tile_rows is None else {"tile_rows": tile_rows}
+        xys, depths, radii, conics, nth, _ = ops.project_gaussians(*pa, **kw)
+        col = torch.clamp(ops.spherical_harmonics(*sh_args(md, cam, DEV)) + 0.5, min=0.0)
+        ra = raster_args(md, xys, depths, radii, conics, nth, col, (w, h))
+        leaves = {i: ra[i].detach().clone().requires_grad_(True) for i in (0, 3, 5, 6)}
+        for i, t in leaves.items():
+            ra[i] = t
+        img, alpha = ops.rasterize_gaussians(*ra, **kw)
+        y0 = 0 if tile_rows is None else 16 * tile_rows[0]
+        (img * w_img[y0:y0 + img.shape[0]]).sum().backward()
+        return img.detach(), radii, nth, [leaves[i].grad for i in (0, 3, 5, 6)]
+
+    full_img, full_radii, full_nth, full_g = run(None)
+    parts, sums, nth_sum = [], None, torch.zeros_like(full_nth)
+    for r in range(3):
+        img, radii, nth, gr = run(stripe_rows(tby, 3, r))
+        assert torch.equal(radii, full_radii)               # radii do not depend on the stripe
+        parts.append(img)
+        nth_sum += nth
+        sums = gr if sums is None else [a + b for a, b in zip(sums, gr)]
+    assert torch.equal(nth_sum, full_nth)
+    assert torch.equal(torch.cat(parts, dim=0), full_img)
+    for a, b, nm in zip(sums, full_g, ["v_xy", "v_conic", "v_colors", "v_opacity"]):
+        tol = 2e-5 * max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= tol, nm

@@ -86,6 +86,18 @@ int ts_sh_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
 int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* viewdirs,
               const float* v_colors, float* v_coeffs, void* stream);
 
+/* Fused colour stage of the render adapter = rasterize.py:75-81 (view directions
+ * normalize(means - origin), origin = view_matrix[:3,3]; coefficients given as the two parameter
+ * tensors colors_dc[n,3] and colors_rest[n,K-1,3] instead of their torch.cat) + rasterize.py:38-39
+ * (SH evaluation, clamp(rgb + 0.5, min=0)).  clamp_mask[n]: bit c set where channel c passes
+ * gradient.  origin: 3 device floats.  colors_rest may be NULL when num_bases == 1. */
+int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const float* colors_dc, const float* colors_rest,
+                     float* colors, uint8_t* clamp_mask, void* stream);
+int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                     float* v_colors_dc, float* v_colors_rest, void* stream);
+
 /* ========================= rasterize_gaussians (rasterize.py:44,50) =========================== */
 /* Stage order: ts_scan_tiles -> (read total) -> ts_bin_count -> ts_tile_offsets -> ts_bin_scatter
  * -> ts_sort_tiles -> ts_pack_splats -> ts_raster_fwd ; backward: ts_raster_bwd -> ts_reduce_partials */

@@ -209,8 +209,10 @@ def test_raster_bwd_deterministic():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,sh,w,h,mult", [(10000, 0, 256, 256, 2.0), (30000, 3, 480, 270, 2.0)])
-def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult):
+@pytest.mark.parametrize("n,sh,w,h,mult,fused", [(10000, 0, 256, 256, 2.0, False),
+                                                  (30000, 3, 480, 270, 2.0, False),
+                                                  (30000, 3, 480, 270, 2.0, True)])
+def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
     """The whole adapter (project -> SH -> rasterize RGB -> rasterize depth) fwd + bwd to the six
     parameter tensors, HIP vs the same recipe run with the oracle ops (float32, CPU autograd)."""
     model, cam = scene_args(n, sh, w, h, seed=21, scale_mult=mult)
@@ -226,7 +228,7 @@ def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult):
     ((f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()).backward()
 
     md = model.to(DEV).requires_grad_(True)
-    r = GaussianRasterizer(md, None, device=torch.device(DEV))
+    r = GaussianRasterizer(md, None, device=torch.device(DEV), fused_colors=fused)
     rgb, extras = r(cam, (w, h), sh)
     ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
@@ -292,3 +294,34 @@ def test_tile_row_stripes_tile_the_frame():
     for a, b, nm in zip(sums, full_g, ["v_xy", "v_conic", "v_colors", "v_opacity"]):
         tol = 2e-5 * max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() <= tol, nm
+
+
+@pytest.mark.parametrize("deg,stored", [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (1, 3), (0, 2)])
+def test_fused_color_stage_equals_op_by_op_recipe(deg, stored):
+    """ts_sh_colors_* (view dirs + split coefficients + SH + 0.5 + clamp in one kernel) against the
+    reference recipe rasterize.py:75-81,38-39 evaluated with the oracle."""
+    n = 5000 if stored < 4 else 700
+    g = torch.Generator().manual_seed(100 + deg * 5 + stored)
+    means = torch.randn(n, 3, generator=g) * 3
+    origin = torch.tensor([0.3, -0.2, 1.5])
+    K = O.num_sh_bases(stored)
+    dc = torch.randn(n, 3, generator=g)
+    rest = torch.randn(n, K - 1, 3, generator=g) * 0.5
+    v = torch.randn(n, 3, generator=g)
+    dc64, rest64 = dc.double().requires_grad_(True), rest.double().requires_grad_(True)
+    dirs = means.double() - origin.double()
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    pre = O.spherical_harmonics(deg, dirs, torch.cat([dc64[:, None, :], rest64], dim=1)) + 0.5
+    ref = torch.clamp(pre, min=0.0)
+    (ref * v.double()).sum().backward()
+    dcd, restd = dc.to(DEV).requires_grad_(True), rest.to(DEV).requires_grad_(True)
+    got = ops.sh_colors(deg, means.to(DEV), origin.to(DEV), dcd, restd)
+    (got * v.to(DEV)).sum().backward()
+    safe = (pre.detach().abs() > 1e-5).all(dim=1)          # away from the clamp kink
+    assert (got.cpu().double() - ref.detach()).abs().max() < 1e-5
+    assert (got >= 0).all()
+    assert (dcd.grad.cpu().double() - dc64.grad)[safe].abs().max() < 1e-5
+    if K > 1:
+        assert (restd.grad.cpu().double() - rest64.grad)[safe].abs().max() < 1e-5
+        ka = O.num_sh_bases(deg)
+        assert torch.all(restd.grad[:, ka - 1:, :] == 0)

@@ -35,13 +35,16 @@ def _stale(target: Path, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
+    # developer knob for ablation runs (tools/time_raster.py): extra -D flags, implies a rebuild
+    extra_env = os.environ.get("TS_EXTRA_HIPCC_FLAGS", "").split()
+    force = force or bool(extra_env)
     headers = [CSRC / "splat_math.h", CSRC.parent.parent / "include" / "tinysplat_hip.h"]
     objs = []
     for src, extra in SOURCES:
         s = CSRC / src
         o = CSRC / (Path(src).stem + ".o")
         if force or _stale(o, [s, *headers]):
-            cmd = [hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
+            cmd = [hipcc, *COMMON, *extra, *extra_env, "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

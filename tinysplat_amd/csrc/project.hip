@@ -188,6 +188,115 @@ __global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused colour stage of the adapter (rasterize.py:75-81 + :38-39): view directions from the means
+// and the view-matrix translation column, SH evaluation on the SPLIT coefficient tensors
+// colors_dc[N,3] / colors_rest[N,K-1,3] (no 192 N-byte torch.cat), then clamp(rgb + 0.5, min=0).
+// mask[n] bit c is set where the clamp passes gradient (pre-clamp value >= 0, torch's rule).
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
+    int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
+    const float* __restrict__ dc, const float* __restrict__ rest, float* __restrict__ colors,
+    unsigned char* __restrict__ mask) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    constexpr int RS = 3 * (KA - 1);                // active floats of a `rest` row
+    constexpr int RSP = RS | 1;
+    extern __shared__ __align__(16) float lds[];
+    const int g0 = blockIdx.x * kThreads;
+    const int cnt = min(kThreads, n - g0);
+    const int tid = threadIdx.x;
+    if (RS > 0) {
+        const size_t row = 3 * (size_t)(num_bases - 1);
+        const float* src = rest + (size_t)g0 * row;
+        if (num_bases == KA && cnt == kThreads && ((kThreads * RS) & 3) == 0) {
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            constexpr int total4 = kThreads * RS / 4;
+            for (int f4 = tid; f4 < total4; f4 += kThreads) {
+                const float4 v = src4[f4];
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ff = 4 * f4 + u;
+                    lds[(ff / RS) * RSP + (ff % RS)] = e[u];
+                }
+            }
+        } else {
+            const int total = cnt * RS;
+            for (int f = tid; f < total; f += kThreads) {
+                const int g = f / RS, j = f % RS;
+                lds[g * RSP + j] = src[(size_t)g * row + j];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid >= cnt) return;
+    const int i = g0 + tid;
+    float Y[KA];
+    ts::sh_basis(DEG, means[3 * i] - origin[0], means[3 * i + 1] - origin[1],
+                 means[3 * i + 2] - origin[2], Y);
+    float c0 = Y[0] * dc[3 * i], c1 = Y[0] * dc[3 * i + 1], c2 = Y[0] * dc[3 * i + 2];
+    const float* r = lds + tid * RSP;
+#pragma unroll
+    for (int k = 1; k < KA; ++k) {
+        c0 = c0 + Y[k] * r[3 * (k - 1)];
+        c1 = c1 + Y[k] * r[3 * (k - 1) + 1];
+        c2 = c2 + Y[k] * r[3 * (k - 1) + 2];
+    }
+    c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
+    mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
+    colors[3 * i] = fmaxf(c0, 0.0f); colors[3 * i + 1] = fmaxf(c1, 0.0f);
+    colors[3 * i + 2] = fmaxf(c2, 0.0f);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
+    int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
+    const unsigned char* __restrict__ mask, const float* __restrict__ v_colors,
+    float* __restrict__ v_dc, float* __restrict__ v_rest) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    extern __shared__ __align__(16) float lds[];
+    const int RS = 3 * (num_bases - 1);
+    const int RSP = RS | 1;
+    const int g0 = blockIdx.x * kThreads;
+    const int cnt = min(kThreads, n - g0);
+    const int tid = threadIdx.x;
+    if (tid < cnt) {
+        const int i = g0 + tid;
+        float Y[KA];
+        ts::sh_basis(DEG, means[3 * i] - origin[0], means[3 * i + 1] - origin[1],
+                     means[3 * i + 2] - origin[2], Y);
+        const int m = mask[i];
+        const float v0 = (m & 1) ? v_colors[3 * i] : 0.0f, v1 = (m & 2) ? v_colors[3 * i + 1] : 0.0f,
+                    v2 = (m & 4) ? v_colors[3 * i + 2] : 0.0f;
+        v_dc[3 * i] = Y[0] * v0; v_dc[3 * i + 1] = Y[0] * v1; v_dc[3 * i + 2] = Y[0] * v2;
+        float* r = lds + tid * RSP;
+#pragma unroll
+        for (int k = 1; k < KA; ++k) {
+            r[3 * (k - 1)] = Y[k] * v0; r[3 * (k - 1) + 1] = Y[k] * v1; r[3 * (k - 1) + 2] = Y[k] * v2;
+        }
+        for (int j = 3 * (KA - 1); j < RS; ++j) r[j] = 0.0f;
+    }
+    if (RS == 0) return;
+    __syncthreads();
+    float* dst = v_rest + (size_t)g0 * RS;
+    const int total = cnt * RS;
+    if ((total & 3) == 0 && (((size_t)g0 * RS) & 3) == 0) {
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        for (int f4 = tid; f4 < total / 4; f4 += kThreads) {
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ff = 4 * f4 + u;
+                e[u] = lds[(ff / RS) * RSP + (ff % RS)];
+            }
+            dst4[f4] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    } else {
+        for (int f = tid; f < total; f += kThreads) dst[f] = lds[(f / RS) * RSP + (f % RS)];
+    }
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -290,6 +399,69 @@ int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
         default: TS_SH_BWD(4); break;
     }
 #undef TS_SH_BWD
+    return launch_status();
+}
+
+int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const float* colors_dc, const float* colors_rest,
+                     float* colors, uint8_t* clamp_mask, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!means3d || !origin || !colors_dc || !colors || !clamp_mask || (num_bases > 1 && !colors_rest))
+        return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
+    const size_t lds = (size_t)kThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_SHC_FWD(D)                                                                             \
+    do {                                                                                          \
+        if (lds > 48 * 1024)                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_fwd_kernel<D>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n,         \
+                           num_bases, means3d, origin, colors_dc, colors_rest, colors, clamp_mask); \
+    } while (0)
+    switch (degrees_to_use) {
+        case 0: TS_SHC_FWD(0); break;
+        case 1: TS_SHC_FWD(1); break;
+        case 2: TS_SHC_FWD(2); break;
+        case 3: TS_SHC_FWD(3); break;
+        default: TS_SHC_FWD(4); break;
+    }
+#undef TS_SHC_FWD
+    return launch_status();
+}
+
+int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                     float* v_colors_dc, float* v_colors_rest, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!means3d || !origin || !clamp_mask || !v_colors || !v_colors_dc ||
+        (num_bases > 1 && !v_colors_rest))
+        return TS_E_BADARG;
+    const int grid = (n + kThreads - 1) / kThreads;
+    const size_t lds = (size_t)kThreads * ((3 * (num_bases - 1)) | 1) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_SHC_BWD(D)                                                                             \
+    do {                                                                                          \
+        if (lds > 48 * 1024)                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_bwd_kernel<D>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n,         \
+                           num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,         \
+                           v_colors_rest);                                                        \
+    } while (0)
+    switch (degrees_to_use) {
+        case 0: TS_SHC_BWD(0); break;
+        case 1: TS_SHC_BWD(1); break;
+        case 2: TS_SHC_BWD(2); break;
+        case 3: TS_SHC_BWD(3); break;
+        default: TS_SHC_BWD(4); break;
+    }
+#undef TS_SHC_BWD
     return launch_status();
 }
 

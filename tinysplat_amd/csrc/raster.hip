@@ -30,7 +30,22 @@
 
 namespace {
 
-constexpr int kWaves = 4;              // tiles per workgroup
+// tuning knobs (overridable with -D for the ablation runs of tools/time_raster.py)
+#ifndef TS_FWD_MIN_WAVES
+#define TS_FWD_MIN_WAVES 1             // __launch_bounds__ 2nd argument = min waves per SIMD
+#endif
+#ifndef TS_BWD_MIN_WAVES
+#define TS_BWD_MIN_WAVES 1
+#endif
+
+#ifndef TS_ABLATE
+#define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0)
+#endif
+
+#ifndef TS_RASTER_WAVES
+#define TS_RASTER_WAVES 4
+#endif
+constexpr int kWaves = TS_RASTER_WAVES;   // tiles (= waves) per workgroup; waves never synchronise
 constexpr int kThreads = 64 * kWaves;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLog2_255 = 7.994353436858858f;
@@ -99,6 +114,15 @@ __device__ __forceinline__ float sigma_l2(float diag, float Bdx, float dy) {
     return __builtin_fmaf(dy, Bdx, diag);      // diag = hA dx^2 + hC dy^2
 }
 
+// XCD-aware workgroup -> tile-group mapping.  Workgroup b is observed to run on XCD (b % 8), and
+// every XCD has a private 4 MiB L2.  Handing XCD x the x-th contiguous eighth of the tile groups
+// (a band of tile rows) keeps the packed-record gathers of neighbouring tiles, which share most of
+// their Gaussians, in one L2.  Placement only affects speed.  Grid = 8 * ceil(groups / 8).
+__device__ __forceinline__ int xcd_tile_group(int num_groups) {
+    const int per_xcd = (num_groups + 7) >> 3;
+    return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+}
+
 struct Staged {          // what a lane derives from the Gaussian it gathered
     int mask;            // bit k set: the alpha >= 1/255 level set may reach 8x8 block k of the tile
     float gx, gy, hA, B, hC, lo;   // conic and opacity in the log2 domain
@@ -120,8 +144,8 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
         const float tau = s.lo + kLog2_255;            // sigma' <= tau  <=>  alpha >= 1/255
         if (tau >= -0.02f) {
             if (s.hA > 0.0f && s.hC > 0.0f) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {           // rolled: runs once per 64 entries, keeps VGPRs low
                     const float bx0 = X0 + (float)(8 * (k & 1)), by0 = Y0 + (float)(8 * (k >> 1));
                     const float xlo = s.gx - (bx0 + 7.0f), xhi = s.gx - bx0;
                     const float ylo = s.gy - (by0 + 7.0f), yhi = s.gy - by0;
@@ -142,14 +166,14 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
 // that position in each of the four blocks k of the 16x16 tile.
 template <int CH>
-__global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
+__global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
     const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ final_Ts, int* __restrict__ final_index) {
     __shared__ float4 lds_all[kWaves][64 * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWaves + wave;
+    const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
     if (tile >= num_tiles) return;
     float4* lds = lds_all[wave];
     const int tbx = cam.tile_bounds_x;
@@ -177,16 +201,27 @@ __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
 
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
 
+    // Software pipeline over 64-entry chunks: the id of chunk c+2 and the packed record of chunk
+    // c+1 are in flight while chunk c is composited (two dependent gathers = ~2 us of latency
+    // that a wave with ~3 co-resident waves per SIMD cannot hide otherwise).
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    int id_next = 0;
+    if (range.x + lane < range.y) {
+        const int g = ids_sorted[range.x + lane];
+        n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+    }
+    if (range.x + 64 + lane < range.y) id_next = ids_sorted[range.x + 64 + lane];
+
     for (int base = range.x; base < range.y && live != 0; base += 64) {
         const int i = base + lane;
         const bool have = i < range.y;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) {
-            const int g = ids_sorted[i];
-            q0 = splats[3 * (size_t)g];
-            q1 = splats[3 * (size_t)g + 1];
-            q2 = splats[3 * (size_t)g + 2];
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        if (i + 64 < range.y) {
+            const int g = id_next;
+            n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
+        if (i + 128 < range.y) id_next = ids_sorted[i + 128];
         const Staged s = stage_splat(have, q0, q1, X0, Y0);
         const bool keep = (s.mask & live) != 0;
         const unsigned long long mask = __ballot(keep);
@@ -198,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void raster_fwd_kernel(
             lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
         TS_WAVE_SYNC();
-        for (int j = 0; j < cnt; ++j) {
+        for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
             const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
             const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)) & live;
             if (bm == 0) continue;
@@ -285,7 +320,7 @@ __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
 }
 
 template <int CH>
-__global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
+__global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
     const float4* __restrict__ splats, const float* __restrict__ background,
@@ -294,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     float* __restrict__ partials) {
     __shared__ float4 lds_all[kWaves][64 * 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWaves + wave;
+    const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
     if (tile >= num_tiles) return;
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     if (range.y <= range.x) return;
@@ -341,16 +376,25 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
     }
     const int last = min(range.y - 1, fmax);
 
+    // same software pipeline as the forward kernel, walking the list back to front
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    int id_next = 0;
+    if (last - lane >= range.x) {
+        const int g = ids_sorted[last - lane];
+        n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+    }
+    if (last - 64 - lane >= range.x) id_next = ids_sorted[last - 64 - lane];
+
     for (int hi = last; hi >= range.x; hi -= 64) {
         const int i = hi - lane;
         const bool have = i >= range.x;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) {
-            const int g = ids_sorted[i];
-            q0 = splats[3 * (size_t)g];
-            q1 = splats[3 * (size_t)g + 1];
-            q2 = splats[3 * (size_t)g + 2];
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        if (i - 64 >= range.x) {
+            const int g = id_next;
+            n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
+        if (i - 128 >= range.x) id_next = ids_sorted[i - 128];
         Staged s = stage_splat(have, q0, q1, X0, Y0);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -367,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
             lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
         TS_WAVE_SYNC();
-        for (int j = 0; j < cnt; ++j) {
+        for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
             const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
             const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
             const int idx = __float_as_int(r2.z);
@@ -397,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
                 const float araw = __builtin_amdgcn_exp2f(r1.y - sg);  // opacity * exp(-sigma)
                 const float a = fminf(ts::kAlphaMax, araw);
                 const bool valid = (idx <= fidx[k]) && (sg >= 0.0f) && (a >= ts::kAlphaMin);
-                if (valid) {
+                if (valid && TS_ABLATE != 2) {
                     any = true;
                     const float ra = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tk = T[k] * ra;                 // transmittance in front of g
@@ -419,16 +463,21 @@ __global__ __launch_bounds__(kThreads) void raster_bwd_kernel(
                     syy = __builtin_fmaf(vdy, dy, syy);
                 }
             }
-            if (!__any(any)) continue;
+            if (!__any(any) || TS_ABLATE == 1) continue;
             const float v8[8] = {s_, sx, sy, sxx, sxy, syy, vc[0], vc[1]};
-            const float r8 = wave_sum8(v8, lane);
-            float rc[2] = {0.f, 0.f};
+            float r8, rc[2] = {0.f, 0.f};
+            if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
+                r8 = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+                rc[0] = vc[2];
+            } else {
+                r8 = wave_sum8(v8, lane);
 #pragma unroll
-            for (int c = 2; c < CH; ++c) rc[c - 2] = wave_sum_hi(vc[c]);
+                for (int c = 2; c < CH; ++c) rc[c - 2] = wave_sum_hi(vc[c]);
+            }
             const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
             if (w >= 0 && w < 6 + CH) {
                 const long long slot = (long long)__float_as_int(r2.w);
-                if (slot >= 0 && slot < num_isects) {
+                if (slot >= 0 && slot < num_isects && (TS_ABLATE != 5 || r8 == 123.456f)) {
                     float val = r8;
                     if (w == 8) val = rc[0];
                     if (CH == 4 && w == 9) val = rc[1];
@@ -491,7 +540,7 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam, const int32_t* tile_bi
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0) return 0;
     if (!tile_bins || !background || !out_img || !final_Ts || !final_index) return TS_E_BADARG;
-    const int grid = (nt + kWaves - 1) / kWaves;
+    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     if (channels == 3)
@@ -519,7 +568,7 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
     hipError_t e = hipMemsetAsync(partials, 0,
                                   (size_t)num_intersects * TS_PARTIAL_ROW_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    const int grid = (nt + kWaves - 1) / kWaves;
+    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
     if (channels == 3)
         hipLaunchKernelGGL(raster_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,

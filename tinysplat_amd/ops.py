@@ -261,6 +261,58 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -
     return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
 
 
+class _ShColors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use, means3d, origin, colors_dc, colors_rest):
+        dev = _need_hip(means3d, origin, colors_dc, colors_rest)
+        n = means3d.shape[0]
+        if means3d.shape != (n, 3) or colors_dc.shape != (n, 3) or origin.numel() != 3:
+            raise ValueError("means3d [N,3], origin [3], colors_dc [N,3] expected")
+        if colors_rest.dim() != 3 or colors_rest.shape[0] != n or colors_rest.shape[2] != 3:
+            raise ValueError("colors_rest must be [N, K-1, 3]")
+        nb = colors_rest.shape[1] + 1
+        stored = deg_from_sh(nb)
+        if degrees_to_use < 0 or degrees_to_use > stored:
+            raise ValueError(f"degrees_to_use={degrees_to_use} not in [0, {stored}]")
+        means3d, origin = _f32c(means3d), _f32c(origin)
+        colors_dc, colors_rest = _f32c(colors_dc), _f32c(colors_rest)
+        colors = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        mask = torch.empty((n,), dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, n, int(degrees_to_use), nb, _ptr(means3d),
+                  _ptr(origin), _ptr(colors_dc), _ptr(colors_rest) if nb > 1 else None, _ptr(colors),
+                  _ptr(mask), _stream(dev))
+        ctx.degree, ctx.nb = int(degrees_to_use), nb
+        ctx.save_for_backward(means3d, origin, mask)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        means3d, origin, mask = ctx.saved_tensors
+        dev = means3d.device
+        n = means3d.shape[0]
+        v_colors = _f32c(v_colors)
+        v_dc = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        v_rest = torch.empty((n, ctx.nb - 1, 3), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, n, ctx.degree, ctx.nb, _ptr(means3d),
+                  _ptr(origin), _ptr(mask), _ptr(v_colors), _ptr(v_dc),
+                  _ptr(v_rest) if ctx.nb > 1 else None, _stream(dev))
+        return None, None, None, v_dc, v_rest
+
+
+def sh_colors(degrees_to_use: int, means3d: Tensor, origin: Tensor, colors_dc: Tensor,
+              colors_rest: Tensor) -> Tensor:
+    """Fused colour stage of the render adapter: what rasterize.py:75-81 + :38-39 compute
+    (``clamp(spherical_harmonics(deg, normalize(means - origin), cat(dc, rest)) + 0.5, min=0)``)
+    without materialising the view directions or the 192 N-byte ``torch.cat``.  Differentiable
+    w.r.t. ``colors_dc`` and ``colors_rest`` (no gradient to ``means3d``, as in the reference where
+    the SH op returns none for the view directions)."""
+    return _ShColors.apply(degrees_to_use, means3d, origin, colors_dc, colors_rest)
+
+
 # --------------------------------------------------------------------------------------------------
 # rasterize_gaussians
 # --------------------------------------------------------------------------------------------------

@@ -62,14 +62,19 @@ class GaussianRasterizer:
     BLOCK_X = TILE
     BLOCK_Y = TILE
 
-    def __init__(self, model, cameras: Optional[Sequence] = None, device=torch.device("cuda:0")):
+    def __init__(self, model, cameras: Optional[Sequence] = None, device=torch.device("cuda:0"),
+                 fused_colors: bool = True):
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.model = model
         self.global_scale = torch.tensor([1.0])
+        # fused_colors: compute rasterize.py:75-81 + :38-39 (view dirs, cat, SH, +0.5, clamp) in one
+        # HIP kernel when the ops namespace offers it; False = the reference's op-by-op recipe
+        self.fused_colors = fused_colors
         # the three callables of the boundary; the product default is the HIP library
         self.ops = SimpleNamespace(project_gaussians=_hip_ops.project_gaussians,
                                    spherical_harmonics=_hip_ops.spherical_harmonics,
-                                   rasterize_gaussians=_hip_ops.rasterize_gaussians)
+                                   rasterize_gaussians=_hip_ops.rasterize_gaussians,
+                                   sh_colors=_hip_ops.sh_colors)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
@@ -81,8 +86,7 @@ class GaussianRasterizer:
         if xys.requires_grad:
             xys.retain_grad()          # model_gaussian.py:130-132 reads extras['xys'].grad
 
-        colors = ops.spherical_harmonics(*self.spherical_harmonics_inputs(camera))
-        colors = torch.clamp(colors + 0.5, min=0.0)
+        colors = self.colors(camera)
 
         rgb, _ = ops.rasterize_gaussians(*self.rasterize_forward_inputs(
             xys, depths, radii, conics, num_tiles, colors, dims))
@@ -95,6 +99,16 @@ class GaussianRasterizer:
         extras = {"depth": depth_img[:, :, 0], "radii": radii, "xys": xys,
                   "camera": {"height": camera.height, "width": camera.width}}
         return rgb, extras
+
+    def colors(self, camera):
+        """Per-Gaussian RGB handed to the rasterizer: clamp(SH(...) + 0.5, min=0)."""
+        fused = getattr(self.ops, "sh_colors", None) if self.fused_colors else None
+        if fused is not None:
+            m = self.model
+            origin = camera.view_matrix[:3, 3].to(self.device).contiguous()
+            return fused(m.active_sh_degree, m.means, origin, m.colors_dc, m.colors_rest)
+        colors = self.ops.spherical_harmonics(*self.spherical_harmonics_inputs(camera))
+        return torch.clamp(colors + 0.5, min=0.0)
 
     # the reference's method names, kept so callers/tests written against it keep working
     def project_forward_inputs(self, camera, dims):

@@ -58,8 +58,18 @@ def sum_grads_across_ranks(tensors, group=None):
     return _SumGradsAcrossRanks.apply(group, *tensors)
 
 
+def _colors(model, camera, ops, device, fused_colors):
+    fused = getattr(ops, "sh_colors", None) if fused_colors else None
+    if fused is not None:
+        origin = camera.view_matrix[:3, 3].to(device).contiguous()
+        return fused(model.active_sh_degree, model.means, origin, model.colors_dc, model.colors_rest)
+    colors = ops.spherical_harmonics(*sh_args(model, camera, device))
+    return torch.clamp(colors + 0.5, min=0.0)
+
+
 def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_size: int = 1,
-                      group=None, tile_rows: Optional[Tuple[int, int]] = None):
+                      group=None, tile_rows: Optional[Tuple[int, int]] = None,
+                      fused_colors: bool = True):
     """Steps 1-3 of the reference frame (rasterize.py:30-45: project, SH, clamp, rasterize RGB,
     clamp) for this rank's stripe.  Returns (rgb_stripe[rows,W,3], (row_begin_px, row_end_px), xys).
 
@@ -75,8 +85,7 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
     xys, depths, radii, conics, num_tiles, _ = ops.project_gaussians(*pa, **kw)
     if xys.requires_grad:
         xys.retain_grad()
-    colors = ops.spherical_harmonics(*sh_args(model, camera, device))
-    colors = torch.clamp(colors + 0.5, min=0.0)
+    colors = _colors(model, camera, ops, device, fused_colors)
     ra = raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims)
     if sharded:
         ra[0], ra[3], ra[5], ra[6] = sum_grads_across_ranks((ra[0], ra[3], ra[5], ra[6]), group)

@@ -319,6 +319,33 @@ __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
     return x;
 }
 
+// Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
+// (lanes 48.. each store one float of the 40/48-byte row).
+template <int CH>
+__device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
+                                          float* __restrict__ partials, int lane) {
+    float r8, rc[2] = {0.f, 0.f};
+    if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
+        r8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        rc[0] = v[8];
+    } else {
+        const float v8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        r8 = wave_sum8(v8, lane);
+#pragma unroll
+        for (int c = 8; c < 6 + CH; ++c) rc[c - 8] = wave_sum_hi(v[c]);
+    }
+    const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
+    if (w >= 0 && w < 6 + CH) {
+        const long long slot = (long long)slot_i;
+        if (slot < num_isects) {
+            float val = r8;
+            if (w == 8) val = rc[0];
+            if (CH == 4 && w == 9) val = rc[1];
+            partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
+        }
+    }
+}
+
 template <int CH>
 __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
@@ -346,7 +373,9 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < CH; ++c) bg[c] = background[c];
 
-    float T[4], tb[4], buf[4][CH], vo[4][CH];
+    // per pixel: T = transmittance behind the Gaussian being replayed; R = T_final*(v_alpha - bg.v_out)
+    // - sum over the Gaussians already replayed of fac * (colour . v_out)   (see the inner loop)
+    float T[4], R[4], vo[4][CH];
     int fidx[4], bmax[4];
     int fmax = -1;
 #pragma unroll
@@ -355,9 +384,9 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
         const bool inside = (px < W) && (py < H);
         fidx[k] = -1;
         T[k] = 1.0f;
-        tb[k] = 0.0f;
+        R[k] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { buf[k][c] = 0.0f; vo[k][c] = 0.0f; }
+        for (int c = 0; c < CH; ++c) vo[k][c] = 0.0f;
         if (inside) {
             const size_t pix = (size_t)(py - row_off) * W + px;
             fidx[k] = final_index[pix];
@@ -369,12 +398,19 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
                 dotbg += bg[c] * vo[k][c];
             }
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
-            tb[k] = T[k] * (va - dotbg);
+            R[k] = T[k] * (va - dotbg);
         }
         bmax[k] = wave_max_int(fidx[k]);            // last list index any pixel of block k used
         fmax = max(fmax, bmax[k]);
     }
     const int last = min(range.y - 1, fmax);
+
+    // per-lane sums over its (up to) four pixels for the Gaussian being replayed, updated in place
+    // by the block bodies and zeroed after each row is written:
+    // {S v, S v dx, S v dy, S v dx^2, S v dx dy, S v dy^2, v_c0, v_c1, ...}
+    float acc[6 + CH];
+#pragma unroll
+    for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
 
     // same software pipeline as the forward kernel, walking the list back to front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -428,10 +464,6 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
             if (CH == 4) col[CH - 1] = r2.y;
 
-            // per-lane sums over its (up to) four pixels
-            float s_ = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, vc[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) vc[c] = 0.0f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -441,48 +473,36 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
                 const float araw = __builtin_amdgcn_exp2f(r1.y - sg);  // opacity * exp(-sigma)
                 const float a = fminf(ts::kAlphaMax, araw);
                 const bool valid = (idx <= fidx[k]) && (sg >= 0.0f) && (a >= ts::kAlphaMin);
-                if (valid && TS_ABLATE != 2) {
-                    any = true;
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - a);
-                    const float Tk = T[k] * ra;                 // transmittance in front of g
-                    const float fac = a * Tk;
-                    float v_a = ra * tb[k];
+                if (!__any(valid)) continue;                          // wave-uniform
+                any = true;
+                // Straight-line, full-exec body: lanes that are not valid compute finite garbage
+                // (a <= 0.999, so 1 - a >= 1e-3) and are masked out of every accumulation through
+                // fac = v_sig = 0.  No divergent region => no exec save/restore, no phi copies.
+                const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+                const float Tk = T[k] * ra;                     // transmittance in front of g
+                const float fac = valid ? a * Tk : 0.0f;
+                float cv = col[0] * vo[k][0];                   // colour . v_out of this pixel
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        vc[c] = __builtin_fmaf(fac, vo[k][c], vc[c]);
-                        v_a = __builtin_fmaf(col[c] * Tk - buf[k][c] * ra, vo[k][c], v_a);
-                        buf[k][c] = __builtin_fmaf(col[c], fac, buf[k][c]);
-                    }
-                    T[k] = Tk;
-                    // d alpha / d sigma = -araw unless the 0.999 clamp is active (then 0)
-                    const float v_sig = (araw > ts::kAlphaMax) ? 0.0f : -araw * v_a;
-                    const float vdx = v_sig * dx, vdy = v_sig * dy;
-                    s_ += v_sig; sx += vdx; sy += vdy;
-                    sxx = __builtin_fmaf(vdx, dx, sxx);
-                    sxy = __builtin_fmaf(vdx, dy, sxy);
-                    syy = __builtin_fmaf(vdy, dy, syy);
-                }
-            }
-            if (!__any(any) || TS_ABLATE == 1) continue;
-            const float v8[8] = {s_, sx, sy, sxx, sxy, syy, vc[0], vc[1]};
-            float r8, rc[2] = {0.f, 0.f};
-            if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
-                r8 = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
-                rc[0] = vc[2];
-            } else {
-                r8 = wave_sum8(v8, lane);
+                for (int c = 1; c < CH; ++c) cv = __builtin_fmaf(col[c], vo[k][c], cv);
 #pragma unroll
-                for (int c = 2; c < CH; ++c) rc[c - 2] = wave_sum_hi(vc[c]);
+                for (int c = 0; c < CH; ++c) acc[6 + c] = __builtin_fmaf(fac, vo[k][c], acc[6 + c]);
+                // dL/dalpha = Tk (c . v_out) + ra (T_final (v_alpha - bg . v_out) - S_behind fac' c' . v_out)
+                const float v_a = __builtin_fmaf(Tk, cv, ra * R[k]);
+                R[k] = __builtin_fmaf(-fac, cv, R[k]);
+                T[k] = valid ? Tk : T[k];
+                // d alpha / d sigma = -araw unless the 0.999 clamp is active (then 0)
+                const float v_sig = (valid && !(araw > ts::kAlphaMax)) ? -araw * v_a : 0.0f;
+                const float vdx = v_sig * dx, vdy = v_sig * dy;
+                acc[0] += v_sig; acc[1] += vdx; acc[2] += vdy;
+                acc[3] = __builtin_fmaf(vdx, dx, acc[3]);
+                acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
+                acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
             }
-            const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
-            if (w >= 0 && w < 6 + CH) {
-                const long long slot = (long long)__float_as_int(r2.w);
-                if (slot >= 0 && slot < num_isects && (TS_ABLATE != 5 || r8 == 123.456f)) {
-                    float val = r8;
-                    if (w == 8) val = rc[0];
-                    if (CH == 4 && w == 9) val = rc[1];
-                    partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
-                }
+            if (any) {                                             // `any` is wave-uniform
+                flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
+                              partials, lane);
+#pragma unroll
+                for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
             }
         }
         TS_WAVE_SYNC();

@@ -110,7 +110,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 /* Tile bucketing without global atomics.  The Gaussians are cut into B = ts_bin_chunks(n) contiguous
  * chunks; bin_ws (>= ts_bin_ws_ints(n, num_tiles) int32, num_tiles = tile_rows * tile_bounds_x) holds
- * the B x num_tiles count matrix followed by num_tiles tile totals.  Stripe-local tile index
+ * the B x num_tiles count matrix, num_tiles tile totals and a 16 x num_tiles scratch for the column scan.  Stripe-local tile index
  * t = (ty - tile_row0) * tile_bounds_x + tx. */
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles);
 
@@ -151,19 +151,21 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam_host, const int32_t* ti
 /* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
  * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
  *   {S v_s, S v_s dx, S v_s dy, S v_s dx^2, S v_s dx dy, S v_s dy^2, v_c0, v_c1, v_c2, v_c3, -, -}
- * partials[I,12] is zeroed by this call first.  v_out_alpha may be NULL. */
+ * row_flags[I] (bytes) is zeroed by this call and set to 1 for every row written; rows whose flag
+ * stays 0 keep stale contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL. */
 int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam_host,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
-                  const float* v_out_img, const float* v_out_alpha, float* partials, void* stream);
+                  const float* v_out_img, const float* v_out_alpha, float* partials,
+                  uint8_t* row_flags, void* stream);
 
-/* Sums each Gaussian's rows (a contiguous range of `partials`, fixed order => run-to-run
+/* Sums each Gaussian's flagged rows (a contiguous range of `partials`, fixed order => run-to-run
  * bit-reproducible gradients), applies the conic / opacity factors read from `splats`, and writes
  * v_xy[n,2], v_conic[n,3] (true partials), v_colors[n,channels], v_opacity[n]. */
 int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
-                       const int32_t* cum_tiles_hit, const float* partials, const float* splats,
-                       float* v_xy, float* v_conic, float* v_colors, float* v_opacity,
-                       void* stream);
+                       const int32_t* cum_tiles_hit, const float* partials,
+                       const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
+                       float* v_colors, float* v_opacity, void* stream);
 
 #ifdef __cplusplus
 }

@@ -150,45 +150,93 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) dst[j] = hist[j];
 }
 
-// one lane per tile: exclusive scan down the chunk axis; tile_total[t] = column sum
-__global__ __launch_bounds__(kThreads) void column_scan_kernel(int num_tiles, int chunks,
-                                                               int* __restrict__ counts,
-                                                               int* __restrict__ tile_total) {
+// Column scan of the B x T count matrix in three small steps so that it runs on (tiles x groups)
+// lanes instead of one lane per tile: per-group column sums, the scan over the <= kScanGroups group
+// sums of a tile, the exclusive scan over tiles, then the per-group finish.
+constexpr int kScanGroups = 16;
+
+__global__ __launch_bounds__(kThreads) void column_group_sum_kernel(int num_tiles, int chunks,
+                                                                    int per_group,
+                                                                    const int* __restrict__ counts,
+                                                                    int* __restrict__ group_sum) {
     const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int g = blockIdx.y;
     if (t >= num_tiles) return;
-    int run = 0;
-    int* col = counts + t;
-#pragma unroll 8
-    for (int b = 0; b < chunks; ++b) {
-        const int c = col[(size_t)b * num_tiles];
-        col[(size_t)b * num_tiles] = run;
-        run += c;
-    }
-    tile_total[t] = run;
+    const int b0 = g * per_group, b1 = min(chunks, b0 + per_group);
+    int sum = 0;
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) sum += counts[(size_t)b * num_tiles + t];
+    group_sum[(size_t)g * num_tiles + t] = sum;
 }
 
-// single workgroup: exclusive scan over tiles -> tile_bins, and tile_total[t] becomes start[t]
+// one lane per tile: exclusive scan over its group sums -> group bases; tile_total[t] = column sum
+__global__ __launch_bounds__(kThreads) void column_group_scan_kernel(int num_tiles, int groups,
+                                                                     int* __restrict__ group_sum,
+                                                                     int* __restrict__ tile_total) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= num_tiles) return;
+    int c[kScanGroups];
+#pragma unroll
+    for (int g = 0; g < kScanGroups; ++g) c[g] = g < groups ? group_sum[(size_t)g * num_tiles + t] : 0;
+    int v = 0;
+#pragma unroll
+    for (int g = 0; g < kScanGroups; ++g) {
+        if (g < groups) group_sum[(size_t)g * num_tiles + t] = v;
+        v += c[g];
+    }
+    tile_total[t] = v;
+}
+
+// single workgroup, 8 tiles per lane and step: exclusive scan over tiles -> tile_bins;
+// tile_total[t] becomes start[t]
 __global__ __launch_bounds__(kThreads) void tile_offsets_kernel(int num_tiles,
                                                                 int* __restrict__ tile_total,
                                                                 int* __restrict__ tile_bins) {
+    constexpr int kPer = 8;
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < num_tiles; base += kThreads) {
-        const int t = base + threadIdx.x;
-        const int v = (t < num_tiles) ? tile_total[t] : 0;
+    for (int base = 0; base < num_tiles; base += kThreads * kPer) {
+        const int t0 = base + threadIdx.x * kPer;
+        int v[kPer], sum = 0;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+            v[e] = (t0 + e < num_tiles) ? tile_total[t0 + e] : 0;
+            sum += v[e];
+        }
         int total;
-        const int inc = block_inclusive_scan(v, &total);
-        const int c = carry;
-        if (t < num_tiles) {
-            const int start = c + inc - v;
-            tile_total[t] = start;
-            reinterpret_cast<int2*>(tile_bins)[t] = v > 0 ? make_int2(start, start + v)
-                                                          : make_int2(0, 0);
+        const int inc = block_inclusive_scan(sum, &total);
+        int start = carry + inc - sum;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+            if (t0 + e < num_tiles) {
+                tile_total[t0 + e] = start;
+                reinterpret_cast<int2*>(tile_bins)[t0 + e] =
+                    v[e] > 0 ? make_int2(start, start + v[e]) : make_int2(0, 0);
+            }
+            start += v[e];
         }
         __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
+        if (threadIdx.x == 0) carry += total;
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void column_finish_kernel(int num_tiles, int chunks,
+                                                                 int per_group,
+                                                                 int* __restrict__ counts,
+                                                                 const int* __restrict__ group_base) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int g = blockIdx.y;
+    if (t >= num_tiles) return;
+    const int b0 = g * per_group, b1 = min(chunks, b0 + per_group);
+    int run = group_base[(size_t)g * num_tiles + t];
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
+        int* p = counts + (size_t)b * num_tiles + t;
+        const int c = *p;
+        *p = run;
+        run += c;
     }
 }
 
@@ -231,20 +279,22 @@ __device__ __forceinline__ void cmpswap(Ptr a, int i, int j) {
 
 template <typename Ptr>
 __device__ __forceinline__ void bitonic_network(Ptr a, int n) {
-    int npad = 1;
-    while (npad < n) npad <<= 1;
-    const int half = npad >> 1;
-    for (int k = 2; k <= npad; k <<= 1) {
-        const int hk = k >> 1;
+    int lg = 0;                                   // npad = 2^lg >= n
+    while ((1 << lg) < n) ++lg;
+    const int half = (1 << lg) >> 1;
+    // all strides are powers of two: index arithmetic is shifts and masks (no integer division)
+    for (int lk = 1; lk <= lg; ++lk) {            // merge blocks of size k = 2^lk
+        const int k = 1 << lk, hk = k >> 1;
         for (int p = threadIdx.x; p < half; p += kThreads) {          // flip
-            const int blk = p / hk, off = p - blk * hk;
-            const int i = blk * k + off, j = blk * k + k - 1 - off;
+            const int base = (p >> (lk - 1)) << lk, off = p & (hk - 1);
+            const int i = base + off, j = base + k - 1 - off;
             if (j < n) cmpswap(a, i, j);
         }
         __syncthreads();
-        for (int d = k >> 2; d >= 1; d >>= 1) {                       // disperse
+        for (int ld = lk - 2; ld >= 0; --ld) {                        // disperse, stride d = 2^ld
+            const int d = 1 << ld;
             for (int p = threadIdx.x; p < half; p += kThreads) {
-                const int i = 2 * d * (p / d) + (p % d), j = i + d;
+                const int i = ((p >> ld) << (ld + 1)) | (p & (d - 1)), j = i + d;
                 if (j < n) cmpswap(a, i, j);
             }
             __syncthreads();
@@ -338,7 +388,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
     if (num_tiles < 0) num_tiles = 0;
-    return (int64_t)bin_num_chunks(n) * num_tiles + num_tiles + 1;
+    return (int64_t)(bin_num_chunks(n) + 1 + kScanGroups) * num_tiles + 1;
 }
 
 static size_t bin_lds_bytes(int num_tiles) {
@@ -370,11 +420,19 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     if (!bin_ws || !tile_bins) return TS_E_BADARG;
     const int chunks = bin_num_chunks(n);
     int* tile_total = bin_ws + (size_t)chunks * num_tiles;
+    int* group_sum = tile_total + num_tiles;
+    const int per_group = (chunks + kScanGroups - 1) / kScanGroups;
+    const int groups = (chunks + per_group - 1) / per_group;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(column_scan_kernel, dim3((num_tiles + kThreads - 1) / kThreads),
-                       dim3(kThreads), 0, s, num_tiles, chunks, bin_ws, tile_total);
+    const dim3 grid2((num_tiles + kThreads - 1) / kThreads, groups);
+    hipLaunchKernelGGL(column_group_sum_kernel, grid2, dim3(kThreads), 0, s, num_tiles, chunks,
+                       per_group, bin_ws, group_sum);
+    hipLaunchKernelGGL(column_group_scan_kernel, dim3((num_tiles + kThreads - 1) / kThreads),
+                       dim3(kThreads), 0, s, num_tiles, groups, group_sum, tile_total);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kThreads), 0, s, num_tiles, tile_total,
                        tile_bins);
+    hipLaunchKernelGGL(column_finish_kernel, grid2, dim3(kThreads), 0, s, num_tiles, chunks,
+                       per_group, bin_ws, group_sum);
     return launch_status();
 }
 

@@ -323,7 +323,8 @@ __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
 // (lanes 48.. each store one float of the 40/48-byte row).
 template <int CH>
 __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
-                                          float* __restrict__ partials, int lane) {
+                                          float* __restrict__ partials,
+                                          unsigned char* __restrict__ row_flags, int lane) {
     float r8, rc[2] = {0.f, 0.f};
     if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
         r8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
@@ -335,13 +336,15 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         for (int c = 8; c < 6 + CH; ++c) rc[c - 8] = wave_sum_hi(v[c]);
     }
     const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
-    if (w >= 0 && w < 6 + CH) {
-        const long long slot = (long long)slot_i;
-        if (slot < num_isects) {
+    const long long slot = (long long)slot_i;
+    if (w >= 0 && slot < num_isects) {
+        if (w < 6 + CH) {
             float val = r8;
             if (w == 8) val = rc[0];
             if (CH == 4 && w == 9) val = rc[1];
             partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
+        } else if (w == 6 + CH) {
+            row_flags[slot] = 1;                               // this row now holds data
         }
     }
 }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float4* __restrict__ splats, const float* __restrict__ background,
     const float* __restrict__ final_Ts, const int* __restrict__ final_index,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     __shared__ float4 lds_all[kWaves][64 * 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             }
             if (any) {                                             // `any` is wave-uniform
                 flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
-                              partials, lane);
+                              partials, row_flags, lane);
 #pragma unroll
                 for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
             }
@@ -515,15 +518,16 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
-    const float4* __restrict__ partials, const float4* __restrict__ splats,
-    float* __restrict__ v_xy, float* __restrict__ v_conic, float* __restrict__ v_colors,
-    float* __restrict__ v_opacity) {
+    const float4* __restrict__ partials, const unsigned char* __restrict__ row_flags,
+    const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
+    float* __restrict__ v_colors, float* __restrict__ v_opacity) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
     const long long end = cum_tiles_hit[i];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     for (long long s = end - cnt; s < end; ++s) {
+        if (!row_flags[s]) continue;          // never written this pass (stale contents)
         const float4 p0 = partials[3 * s], p1 = partials[3 * s + 1], p2 = partials[3 * s + 2];
         a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
         a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
@@ -577,37 +581,39 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam, const int32_t* tile_bi
 int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
-                  const float* v_out_img, const float* v_out_alpha, float* partials, void* stream) {
+                  const float* v_out_img, const float* v_out_alpha, float* partials,
+                  uint8_t* row_flags, void* stream) {
     if (!cam || (channels != 3 && channels != 4) || num_intersects < 0) return TS_E_BADARG;
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0 || num_intersects == 0) return 0;
     if (!tile_bins || !gaussian_ids_sorted || !splats || !background || !final_Ts || !final_index ||
-        !v_out_img || !partials)
+        !v_out_img || !partials || !row_flags)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(partials, 0,
-                                  (size_t)num_intersects * TS_PARTIAL_ROW_FLOATS * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects, s);
     if (e != hipSuccess) return (int)e;
     const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
     if (channels == 3)
         hipLaunchKernelGGL(raster_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials);
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials,
+                           row_flags);
     else
         hipLaunchKernelGGL(raster_bwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials);
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials,
+                           row_flags);
     return launch_status();
 }
 
 int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
-                       const int32_t* cum_tiles_hit, const float* partials, const float* splats,
-                       float* v_xy, float* v_conic, float* v_colors, float* v_opacity,
-                       void* stream) {
+                       const int32_t* cum_tiles_hit, const float* partials,
+                       const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
+                       float* v_colors, float* v_opacity, void* stream) {
     if (n < 0 || (channels != 3 && channels != 4)) return TS_E_BADARG;
     if (n == 0) return 0;
-    if (!num_tiles_hit || !cum_tiles_hit || !splats || !v_xy || !v_conic || !v_colors || !v_opacity)
+    if (!num_tiles_hit || !cum_tiles_hit || !row_flags || !splats || !v_xy || !v_conic || !v_colors || !v_opacity)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const float4* pr = reinterpret_cast<const float4*>(partials);
@@ -615,10 +621,10 @@ int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit
     const int grid = (n + 255) / 256;
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
-                           cum_tiles_hit, pr, sp, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
     else
         hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
-                           cum_tiles_hit, pr, sp, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
     return launch_status();
 }
 

@@ -450,15 +450,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         v_colors = torch.empty((n, ch), **f32)
         v_opacity = torch.empty((n,), **f32)
         partials = torch.empty((max(total, 1), 12), **f32)
+        row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):
             _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, b.cam, _ptr(b.tile_bins),
                                          _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
-                                         _ptr(v_out_alpha), _ptr(partials), s)
+                                         _ptr(v_out_alpha), _ptr(partials), _ptr(row_flags), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
-                                              _ptr(partials), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
+                                              _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                                               _ptr(v_colors), _ptr(v_opacity), s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
                 None, None, None, None)

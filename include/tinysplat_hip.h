@@ -59,19 +59,24 @@ typedef struct ts_camera {
 
 /* ============================ project_gaussians (rasterize.py:32) ============================ */
 
+/* flags: fold the adapter's argument preparation (rasterize.py:72-73) into the kernels */
+#define TS_PROJECT_LOG_SCALES 1  /* `scales` holds log-scales: the kernel uses exp(scales)          */
+#define TS_PROJECT_RAW_QUATS 2   /* `quats` is unnormalised: the kernel uses quats / |quats|;        */
+                                 /* backward then returns gradients w.r.t. the raw tensors           */
+
 /* Forward.  viewmat: 12 floats (rows of the 3x4 view matrix, rasterize.py:73 passes
  * view_matrix[:3,:]); projmat: 16 floats (P @ V).  Outputs are fully written for every Gaussian;
  * culled ones (z <= clip, singular cov2d, no tile hit) get zeros. */
 int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam_host,
-                   float* xys, float* depths, int32_t* radii, float* conics,
+                   int32_t flags, float* xys, float* depths, int32_t* radii, float* conics,
                    int32_t* num_tiles_hit, float* cov3d, void* stream);
 
 /* Backward.  v_conic uses the true-partial convention for the off-diagonal entry.  v_cov3d may be
  * NULL (tinysplat discards cov3d, rasterize.py:32).  Gaussians with radii == 0 receive zeros. */
 int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam_host,
-                   const int32_t* radii, const float* v_xy, const float* v_depth,
+                   int32_t flags, const int32_t* radii, const float* v_xy, const float* v_depth,
                    const float* v_conic, const float* v_cov3d,
                    float* v_means3d, float* v_scales, float* v_quats, void* stream);
 
@@ -133,11 +138,14 @@ int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_keys,
                   int32_t* gaussian_ids_sorted, void* stream);
 
+#define TS_RASTER_LOGIT_OPACITY 1 /* `opacity` holds logits: sigmoid (rasterize.py:86) is applied while */
+                                  /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */
+
 /* Packs the per-Gaussian operands of the compositing kernels into one 48-byte record:
  *   {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 | c2, c3, slot_base(int), bbox_w(int)}
  * channels = 3 (colors[n,3]; c3 = 0) or 4 (colors[n,4]).  slot_base/bbox_w locate the
  * (tile,Gaussian) row of the backward partial buffer: slot = slot_base + ty*bbox_w + tx. */
-int ts_pack_splats(int32_t n, int32_t channels, const float* xys, const int32_t* radii,
+int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys, const int32_t* radii,
                    const float* conics, const float* colors, const float* opacity,
                    const int32_t* cum_tiles_hit, const ts_camera* cam_host, float* splats,
                    void* stream);
@@ -162,7 +170,7 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
 /* Sums each Gaussian's flagged rows (a contiguous range of `partials`, fixed order => run-to-run
  * bit-reproducible gradients), applies the conic / opacity factors read from `splats`, and writes
  * v_xy[n,2], v_conic[n,3] (true partials), v_colors[n,channels], v_opacity[n]. */
-int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
+int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
                        float* v_colors, float* v_opacity, void* stream);

@@ -49,9 +49,9 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_sh_fwd(-1, 0, 1, None, None, None, None) == -1
     assert lib.ts_sh_fwd(4, 2, 4, None, None, None, None) == -2      # degree 2 needs 9 bases
     assert lib.ts_sh_fwd(4, 0, 5, None, None, None, None) == -2      # 5 is not a base count
-    assert lib.ts_project_fwd(-3, *([None] * 5), None, *([None] * 7)) == -1
+    assert lib.ts_project_fwd(-3, *([None] * 5), None, 0, *([None] * 7)) == -1
     cam = _lib.TsCamera(1, 1, 0, 0, 16, 16, 1, 1, 0, 1, 1.0, 0.01)
-    assert lib.ts_pack_splats(4, 5, *([None] * 6), cam, None, None) == -1
+    assert lib.ts_pack_splats(4, 5, 0, *([None] * 6), cam, None, None) == -1
     assert lib.ts_raster_fwd(2, cam, *([None] * 8)) == -1
 
 

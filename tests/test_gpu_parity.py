@@ -325,3 +325,51 @@ def test_fused_color_stage_equals_op_by_op_recipe(deg, stored):
         assert (restd.grad.cpu().double() - rest64.grad)[safe].abs().max() < 1e-5
         ka = O.num_sh_bases(deg)
         assert torch.all(restd.grad[:, ka - 1:, :] == 0)
+
+
+def test_fused_prep_flags_equal_op_by_op_recipe():
+    """log_scales / raw_quats (project) and logit_opacity (rasterize) against the adapter's
+    torch.exp / normalise / sigmoid followed by the plain ops: same integers, same values, and
+    gradients w.r.t. the RAW parameter tensors."""
+    n, w, h = 20000, 320, 200
+    model, cam = scene_args(n, 0, w, h, seed=31, scale_mult=2.5)
+    md = model.to(DEV).requires_grad_(True)
+    pa = _to_dev(project_args(md, cam, (w, h), DEV))
+    ref = ops.project_gaussians(*pa)
+    raw = list(pa)
+    raw[1], raw[3] = md.scales, md.quats
+    got = ops.project_gaussians(*raw, log_scales=True, raw_quats=True)
+    same = (ref[2] == got[2]).double().mean().item()
+    assert same > 0.999                       # exp / sqrt run in different libraries: ceil() may flip
+    ok = (ref[2] == got[2]) & (ref[4] == got[4])
+    for a, b, nm in zip(ref, got, ["xys", "depths", "radii", "conics", "nth", "cov3d"]):
+        if a.is_floating_point():
+            m = ok if a.dim() == 1 else ok[:, None]
+            assert ((a - b).abs() * m).max().item() <= 2e-5 * max(1.0, a.abs().max().item()), nm
+    g = torch.Generator().manual_seed(3)
+    v_xy, v_c = torch.randn(n, 2, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV)
+    okf = ok.float()
+    grads = []
+    for out in (ref, got):
+        for p in md.parameters():
+            p.grad = None
+        ((out[0] * v_xy * okf[:, None]).sum() + (out[3] * v_c * okf[:, None]).sum()
+         + (out[1] * okf).sum()).backward()
+        grads.append([md.means.grad.clone(), md.scales.grad.clone(), md.quats.grad.clone()])
+    for a, b, nm in zip(grads[0], grads[1], ["means", "log-scales", "raw quats"]):
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, a.abs().max().item()), nm
+    # logit opacity
+    xys, depths, radii, conics, nth, _ = [t.detach() for t in ref]
+    col = torch.rand(n, 3, generator=g).to(DEV)
+    bgc = torch.tensor([0.2, 0.1, 0.4], device=DEV)
+    outs = []
+    for logit in (False, True):
+        md.opacities.grad = None
+        op = md.opacities if logit else torch.sigmoid(md.opacities)
+        img, _ = ops.rasterize_gaussians(xys, depths, radii, conics, nth, col, op, h, w, bgc,
+                                         logit_opacity=logit)
+        img.square().sum().backward()
+        outs.append((img.detach(), md.opacities.grad.clone()))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4      # rare 1-ulp threshold flips
+    ga, gb = outs[0][1], outs[1][1]
+    assert ((ga - gb).abs() > 1e-4 * max(1.0, ga.abs().max().item())).float().mean().item() < 1e-3

@@ -30,8 +30,8 @@ _CAM = POINTER(TsCamera)
 # name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
 SIGNATURES = {
     "ts_abi_version": (c_int32, []),
-    "ts_project_fwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, _P, _P, _P, _P, _P, _P, _P]),
-    "ts_project_bwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_project_fwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_project_bwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sh_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
     "ts_sh_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
     "ts_sh_colors_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
@@ -43,10 +43,10 @@ SIGNATURES = {
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P]),
-    "ts_pack_splats": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P]),
+    "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ts_reduce_partials": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

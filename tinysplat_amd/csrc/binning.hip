@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
 }
 
 __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
-    int n, int channels, const float* __restrict__ xys, const int* __restrict__ radii,
+    int n, int channels, int flags, const float* __restrict__ xys, const int* __restrict__ radii,
     const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacity, const int* __restrict__ cum_tiles_hit, const ts_camera cam,
     float4* __restrict__ splats) {
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
         const int cnt = h > 0 ? w * h : 0;
         const int excl = cum_tiles_hit[i] - cnt;
         const int slot_base = excl - b.miny * w - b.minx;
-        q0 = make_float4(xy.x, xy.y, opacity[i], conics[3 * i]);
+        float op = opacity[i];
+        if (flags & TS_RASTER_LOGIT_OPACITY) op = 1.0f / (1.0f + expf(-op));   // sigmoid, rasterize.py:86
+        q0 = make_float4(xy.x, xy.y, op, conics[3 * i]);
         float c0, c1, c2, c3 = 0.0f;
         if (channels == 4) {
             const float4 c = reinterpret_cast<const float4*>(colors)[i];
@@ -468,7 +470,7 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_k
     return launch_status();
 }
 
-int ts_pack_splats(int32_t n, int32_t channels, const float* xys, const int32_t* radii,
+int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys, const int32_t* radii,
                    const float* conics, const float* colors, const float* opacity,
                    const int32_t* cum_tiles_hit, const ts_camera* cam, float* splats,
                    void* stream) {
@@ -477,7 +479,7 @@ int ts_pack_splats(int32_t n, int32_t channels, const float* xys, const int32_t*
     if (!xys || !radii || !conics || !colors || !opacity || !cum_tiles_hit || !splats)
         return TS_E_BADARG;
     hipLaunchKernelGGL(pack_splats_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       (hipStream_t)stream, n, channels, xys, radii, conics, colors, opacity,
+                       (hipStream_t)stream, n, channels, (int)flags, xys, radii, conics, colors, opacity,
                        cum_tiles_hit, *cam, reinterpret_cast<float4*>(splats));
     return launch_status();
 }

@@ -30,19 +30,33 @@ __device__ __forceinline__ ts::Cam load_cam(const float* __restrict__ viewmat,
     return C;
 }
 
+// The adapter-side argument preparation of rasterize.py:72-73 folded into the kernels on request:
+//   TS_PROJECT_LOG_SCALES  scales hold log-scales; use exp(scales)            (rasterize.py:72)
+//   TS_PROJECT_RAW_QUATS   quats are unnormalised; use quats / |quats|        (rasterize.py:73)
+// (the projection itself normalises its quaternion argument once more, as upstream does).
+__device__ __forceinline__ void prep_inputs(int flags, float s[3], float q[4], float* inv_norm) {
+    if (flags & TS_PROJECT_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+    if (flags & TS_PROJECT_RAW_QUATS) {
+        const float n = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+        q[0] = q[0] / n; q[1] = q[1] / n; q[2] = q[2] / n; q[3] = q[3] / n;
+        if (inv_norm) *inv_norm = 1.0f / n;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void project_fwd_kernel(
     int n, const float* __restrict__ means3d, const float* __restrict__ scales,
     const float* __restrict__ quats, const float* __restrict__ viewmat,
-    const float* __restrict__ projmat, const ts_camera cam, float* __restrict__ xys,
-    float* __restrict__ depths, int* __restrict__ radii, float* __restrict__ conics,
-    int* __restrict__ num_tiles_hit, float* __restrict__ cov3d) {
+    const float* __restrict__ projmat, const ts_camera cam, const int flags,
+    float* __restrict__ xys, float* __restrict__ depths, int* __restrict__ radii,
+    float* __restrict__ conics, int* __restrict__ num_tiles_hit, float* __restrict__ cov3d) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const ts::Cam C = load_cam(viewmat, projmat, cam);
     const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
-    const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
     const float4 qv = reinterpret_cast<const float4*>(quats)[i];
-    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    prep_inputs(flags, s, q, nullptr);
     ts::ProjOut o;
     ts::project_one(C, m, s, q, o);
     reinterpret_cast<float2*>(xys)[i] = make_float2(o.x, o.y);
@@ -59,8 +73,8 @@ __global__ __launch_bounds__(kThreads) void project_fwd_kernel(
 __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
     int n, const float* __restrict__ means3d, const float* __restrict__ scales,
     const float* __restrict__ quats, const float* __restrict__ viewmat,
-    const float* __restrict__ projmat, const ts_camera cam, const int* __restrict__ radii,
-    const float* __restrict__ v_xy, const float* __restrict__ v_depth,
+    const float* __restrict__ projmat, const ts_camera cam, const int flags,
+    const int* __restrict__ radii, const float* __restrict__ v_xy, const float* __restrict__ v_depth,
     const float* __restrict__ v_conic, const float* __restrict__ v_cov3d,
     float* __restrict__ v_means3d, float* __restrict__ v_scales, float* __restrict__ v_quats) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -71,9 +85,11 @@ __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
     if (radii[i] > 0) {
         const ts::Cam C = load_cam(viewmat, projmat, cam);
         const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
-        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
         const float4 qv = reinterpret_cast<const float4*>(quats)[i];
-        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        float inv_n = 1.0f;
+        prep_inputs(flags, s, q, &inv_n);
         const float2 vxy = reinterpret_cast<const float2*>(v_xy)[i];
         const float vx[2] = {vxy.x, vxy.y};
         const float vc[3] = {v_conic[3 * i], v_conic[3 * i + 1], v_conic[3 * i + 2]};
@@ -82,6 +98,14 @@ __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
             for (int k = 0; k < 6; ++k) vcov[k] = v_cov3d[6 * (size_t)i + k];
         }
         ts::project_one_vjp(C, m, s, q, vx, v_depth[i], vc, v_cov3d ? vcov : nullptr, g);
+        if (flags & TS_PROJECT_LOG_SCALES) {            // d exp(x) = exp(x) dx
+            g.v_scale[0] *= s[0]; g.v_scale[1] *= s[1]; g.v_scale[2] *= s[2];
+        }
+        if (flags & TS_PROJECT_RAW_QUATS) {             // q_hat = q / |q|
+            const float dotp = q[0] * g.v_quat[0] + q[1] * g.v_quat[1] + q[2] * g.v_quat[2] +
+                               q[3] * g.v_quat[3];
+            for (int k = 0; k < 4; ++k) g.v_quat[k] = (g.v_quat[k] - q[k] * dotp) * inv_n;
+        }
     }
     v_means3d[3 * i] = g.v_mean[0]; v_means3d[3 * i + 1] = g.v_mean[1];
     v_means3d[3 * i + 2] = g.v_mean[2];
@@ -307,7 +331,7 @@ int ts_abi_version(void) { return TS_ABI_VERSION; }
 
 int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam,
-                   float* xys, float* depths, int32_t* radii, float* conics,
+                   int32_t flags, float* xys, float* depths, int32_t* radii, float* conics,
                    int32_t* num_tiles_hit, float* cov3d, void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
@@ -316,14 +340,14 @@ int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const f
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
-                       means3d, scales, quats, viewmat, projmat, *cam, xys, depths, radii, conics,
-                       num_tiles_hit, cov3d);
+                       means3d, scales, quats, viewmat, projmat, *cam, (int)flags, xys, depths, radii,
+                       conics, num_tiles_hit, cov3d);
     return launch_status();
 }
 
 int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam,
-                   const int32_t* radii, const float* v_xy, const float* v_depth,
+                   int32_t flags, const int32_t* radii, const float* v_xy, const float* v_depth,
                    const float* v_conic, const float* v_cov3d, float* v_means3d, float* v_scales,
                    float* v_quats, void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
@@ -333,7 +357,7 @@ int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const f
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
-                       means3d, scales, quats, viewmat, projmat, *cam, radii, v_xy, v_depth,
+                       means3d, scales, quats, viewmat, projmat, *cam, (int)flags, radii, v_xy, v_depth,
                        v_conic, v_cov3d, v_means3d, v_scales, v_quats);
     return launch_status();
 }

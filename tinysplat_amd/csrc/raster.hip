@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 // with d = xy - pixel.  The conic / opacity factors are applied once per Gaussian here.
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
-    int n, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
+    int n, int flags, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
     const float4* __restrict__ partials, const unsigned char* __restrict__ row_flags,
     const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_opacity) {
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
         vx = A * a0.y + B * a0.z;
         vy = B * a0.y + C * a0.z;
         vop = op > 0.0f ? -a0.x / op : 0.0f;
+        if (flags & TS_RASTER_LOGIT_OPACITY) vop *= op * (1.0f - op);   // through the sigmoid
     }
     reinterpret_cast<float2*>(v_xy)[i] = make_float2(vx, vy);
     v_opacity[i] = vop;
@@ -607,7 +608,7 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
     return launch_status();
 }
 
-int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit,
+int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
                        float* v_colors, float* v_opacity, void* stream) {
@@ -620,10 +621,12 @@ int ts_reduce_partials(int32_t n, int32_t channels, const int32_t* num_tiles_hit
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int grid = (n + 255) / 256;
     if (channels == 3)
-        hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
+        hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags,
+                           num_tiles_hit,
                            cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
     else
-        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, num_tiles_hit,
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags,
+                           num_tiles_hit,
                            cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
     return launch_status();
 }

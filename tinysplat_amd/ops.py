@@ -148,7 +148,7 @@ def _tile_bounds(img_height: int, img_width: int) -> Tuple[int, int, int]:
 class _ProjectGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy,
-                img_height, img_width, tile_bounds, clip_thresh, tile_rows):
+                img_height, img_width, tile_bounds, clip_thresh, tile_rows, flags):
         dev = _need_hip(means3d, scales, quats, viewmat, projmat)
         n = means3d.shape[0]
         if means3d.shape != (n, 3) or scales.shape != (n, 3) or quats.shape != (n, 4):
@@ -170,9 +170,9 @@ class _ProjectGaussians(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
-                                          _ptr(projmat), cam, _ptr(xys), _ptr(depths), _ptr(radii),
+                                          _ptr(projmat), cam, int(flags), _ptr(xys), _ptr(depths), _ptr(radii),
                                           _ptr(conics), _ptr(nth), _ptr(cov3d), _stream(dev))
-        ctx.cam = cam
+        ctx.cam, ctx.flags = cam, int(flags)
         ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii)
         ctx.mark_non_differentiable(radii, nth)
         ctx.set_materialize_grads(False)
@@ -194,26 +194,32 @@ class _ProjectGaussians(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             _call("ts_project_bwd", lib.ts_project_bwd, n, _ptr(means3d), _ptr(scales), _ptr(quats), _ptr(viewmat),
-                                          _ptr(projmat), ctx.cam, _ptr(radii), _ptr(v_xys),
+                                          _ptr(projmat), ctx.cam, ctx.flags, _ptr(radii), _ptr(v_xys),
                                           _ptr(v_depths), _ptr(v_conics), _ptr(v_cov3d),
                                           _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
                                           _stream(dev))
-        return (v_means, v_scales, None, v_quats) + (None,) * 11
+        return (v_means, v_scales, None, v_quats) + (None,) * 12
 
 
 def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
                       viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
                       img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
                       clip_thresh: float = CLIP_THRESH,
-                      tile_rows: Optional[Tuple[int, int]] = None):
+                      tile_rows: Optional[Tuple[int, int]] = None, log_scales: bool = False,
+                      raw_quats: bool = False):
     """EWA projection of N Gaussians.  Same positional signature tinysplat calls at rasterize.py:32.
 
     Returns ``(xys[N,2], depths[N], radii[N] int32, conics[N,3], num_tiles_hit[N] int32,
     cov3d[N,6])``; differentiable w.r.t. ``means3d``, ``scales``, ``quats``.  ``tile_rows=(r0,r1)``
     (extension, multi-GPU stripes) restricts ``num_tiles_hit`` to tile rows [r0, r1).
+    ``log_scales`` / ``raw_quats`` (extensions) fold the adapter's ``exp(scales)`` and
+    ``quats / |quats|`` (rasterize.py:72-73) into the kernel; gradients are then w.r.t. the raw
+    tensors.
     """
+    flags = (1 if log_scales else 0) | (2 if raw_quats else 0)
     return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx,
-                                   cy, img_height, img_width, tile_bounds, clip_thresh, tile_rows)
+                                   cy, img_height, img_width, tile_bounds, clip_thresh, tile_rows,
+                                   flags)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -397,7 +403,7 @@ def _stripe_rows(cam: TsCamera) -> int:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
-                img_width, background, tile_rows):
+                img_width, background, tile_rows, logit_opacity):
         dev = _need_hip(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         n = xys.shape[0]
         if colors.dim() != 2 or colors.shape[0] != n or colors.shape[1] not in (3, 4):
@@ -421,7 +427,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):
-            _call("ts_pack_splats", lib.ts_pack_splats, n, ch, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
+            _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1 if logit_opacity else 0, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
                                           _ptr(colors_c), _ptr(opac_c), _ptr(b.cum_tiles_hit), cam,
                                           _ptr(splats), s)
             _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
@@ -429,6 +435,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _ptr(final_idx), s)
         out_alpha = 1.0 - final_Ts
         ctx.binning, ctx.ch, ctx.n = b, ch, n
+        ctx.logit = 1 if logit_opacity else 0
         ctx.opacity_shape = opacity.shape
         ctx.save_for_backward(splats, bg_c, final_Ts, final_idx)
         ctx.set_materialize_grads(False)
@@ -458,23 +465,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
                                          _ptr(v_out_alpha), _ptr(partials), _ptr(row_flags), s)
-            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
+            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, ctx.logit, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
                                               _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                                               _ptr(v_colors), _ptr(v_opacity), s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
                         num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
                         img_width: int, background: Tensor,
-                        tile_rows: Optional[Tuple[int, int]] = None):
+                        tile_rows: Optional[Tuple[int, int]] = None, logit_opacity: bool = False):
     """Tile-based alpha compositing; positional signature of the calls at rasterize.py:44,50.
 
     Returns the 2-tuple ``(out_img[H,W,C], out_alpha[H,W])`` that tinysplat unpacks
     (``rgbs, _ = rasterize_gaussians(*inputs)``).  Differentiable w.r.t. ``xys``, ``conics``,
     ``colors``, ``opacity``.  With ``tile_rows=(r0,r1)`` only that stripe of tile rows is rendered
-    and the outputs hold its pixel rows.
+    and the outputs hold its pixel rows.  ``logit_opacity=True`` (extension) takes opacity logits and
+    folds the adapter's ``sigmoid`` (rasterize.py:86) into the kernels.
     """
     return _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
-                                     img_height, img_width, background, tile_rows)
+                                     img_height, img_width, background, tile_rows, logit_opacity)

@@ -32,6 +32,27 @@ def tile_bounds(dims: Tuple[int, int]) -> Tuple[int, int, int]:
     return (-(-w // TILE), -(-h // TILE), 1)
 
 
+_cam_cache = {}
+
+
+def camera_on_device(camera, device):
+    """(view[4,4], proj @ view [4,4], origin[3]) on `device`, memoised on the identity/version of the
+    camera's two matrices: the reference re-uploads them every frame (rasterize.py:70-71), which on
+    a GPU is two pageable host->device copies and a 4x4 GEMM launch per frame."""
+    vm, pm = camera.view_matrix, camera.proj_matrix
+    key = (id(camera), str(device))
+    sig = (vm.data_ptr(), vm._version, pm.data_ptr(), pm._version)
+    hit = _cam_cache.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    view = vm.to(device)
+    out = (view, pm.to(device) @ view, view[:3, 3].contiguous())
+    if len(_cam_cache) > 64:
+        _cam_cache.clear()
+    _cam_cache[key] = (sig, out, vm, pm)     # keep the tensors alive so data_ptr stays unique
+    return out
+
+
 def project_args(model, camera, dims, device):
     """The 13 positional arguments of project_gaussians (rasterize.py:64-73)."""
     w, h = dims
@@ -68,44 +89,66 @@ class GaussianRasterizer:
         self.model = model
         self.global_scale = torch.tensor([1.0])
         # fused_colors: compute rasterize.py:75-81 + :38-39 (view dirs, cat, SH, +0.5, clamp) in one
-        # HIP kernel when the ops namespace offers it; False = the reference's op-by-op recipe
+        # HIP kernel when the ops namespace offers it; False = the reference's op-by-op recipe.
+        # fused_prep: likewise fold exp(scales), quats/|quats| (rasterize.py:72-73) and
+        # sigmoid(opacities) (rasterize.py:86) into the projection / packing kernels.
         self.fused_colors = fused_colors
+        self.fused_prep = fused_colors
         # the three callables of the boundary; the product default is the HIP library
         self.ops = SimpleNamespace(project_gaussians=_hip_ops.project_gaussians,
                                    spherical_harmonics=_hip_ops.spherical_harmonics,
                                    rasterize_gaussians=_hip_ops.rasterize_gaussians,
-                                   sh_colors=_hip_ops.sh_colors)
+                                   sh_colors=_hip_ops.sh_colors, fused_prep=True)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
             dims = (camera.width, camera.height)
         ops = self.ops
 
-        xys, depths, radii, conics, num_tiles, _cov3d = ops.project_gaussians(
-            *self.project_forward_inputs(camera, dims))
+        prep = self.fused_prep and getattr(ops, "fused_prep", False)
+        if prep:
+            w, h = dims
+            _, projview, _ = camera_on_device(camera, self.device)
+            view = camera_on_device(camera, self.device)[0]
+            model = self.model
+            xys, depths, radii, conics, num_tiles, _cov3d = ops.project_gaussians(
+                model.means, model.scales, 1., model.quats, view[:3, :], projview, camera.f_x,
+                camera.f_y, w / 2, h / 2, h, w, tile_bounds(dims), log_scales=True, raw_quats=True)
+            rkw = {"logit_opacity": True}
+        else:
+            xys, depths, radii, conics, num_tiles, _cov3d = ops.project_gaussians(
+                *self.project_forward_inputs(camera, dims))
+            rkw = {}
         if xys.requires_grad:
             xys.retain_grad()          # model_gaussian.py:130-132 reads extras['xys'].grad
 
         colors = self.colors(camera)
 
-        rgb, _ = ops.rasterize_gaussians(*self.rasterize_forward_inputs(
-            xys, depths, radii, conics, num_tiles, colors, dims))
+        rgb, _ = ops.rasterize_gaussians(*self._raster_inputs(
+            xys, depths, radii, conics, num_tiles, colors, dims, prep), **rkw)
         rgb = torch.clamp(rgb, max=1.0)
 
         depth_as_color = depths[:, None].repeat(1, 3)
-        depth_img, _ = ops.rasterize_gaussians(*self.rasterize_forward_inputs(
-            xys, depths, radii, conics, num_tiles, depth_as_color, dims))
+        depth_img, _ = ops.rasterize_gaussians(*self._raster_inputs(
+            xys, depths, radii, conics, num_tiles, depth_as_color, dims, prep), **rkw)
 
         extras = {"depth": depth_img[:, :, 0], "radii": radii, "xys": xys,
                   "camera": {"height": camera.height, "width": camera.width}}
         return rgb, extras
+
+    def _raster_inputs(self, xys, depths, radii, conics, num_tiles, colors, dims, prep):
+        if not prep:
+            return self.rasterize_forward_inputs(xys, depths, radii, conics, num_tiles, colors, dims)
+        w, h = dims
+        return [xys, depths, radii, conics, num_tiles, colors, self.model.opacities, h, w,
+                self.model.background]
 
     def colors(self, camera):
         """Per-Gaussian RGB handed to the rasterizer: clamp(SH(...) + 0.5, min=0)."""
         fused = getattr(self.ops, "sh_colors", None) if self.fused_colors else None
         if fused is not None:
             m = self.model
-            origin = camera.view_matrix[:3, 3].to(self.device).contiguous()
+            origin = camera_on_device(camera, self.device)[2]
             return fused(m.active_sh_degree, m.means, origin, m.colors_dc, m.colors_rest)
         colors = self.ops.spherical_harmonics(*self.spherical_harmonics_inputs(camera))
         return torch.clamp(colors + 0.5, min=0.0)

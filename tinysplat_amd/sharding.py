@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .rasterizer import project_args, raster_args, sh_args
+from .rasterizer import camera_on_device, project_args, raster_args, sh_args, tile_bounds
 
 
 def stripe_rows(tile_rows_total: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -61,7 +61,7 @@ def sum_grads_across_ranks(tensors, group=None):
 def _colors(model, camera, ops, device, fused_colors):
     fused = getattr(ops, "sh_colors", None) if fused_colors else None
     if fused is not None:
-        origin = camera.view_matrix[:3, 3].to(device).contiguous()
+        origin = camera_on_device(camera, device)[2]
         return fused(model.active_sh_degree, model.means, origin, model.colors_dc, model.colors_rest)
     colors = ops.spherical_harmonics(*sh_args(model, camera, device))
     return torch.clamp(colors + 0.5, min=0.0)
@@ -76,17 +76,28 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
     world_size == 1 renders the whole frame and involves no collective.
     """
     w, h = dims
-    pa = project_args(model, camera, dims, device)
-    tby = pa[12][1]
+    tby = tile_bounds(dims)[1]
     if tile_rows is None:
         tile_rows = stripe_rows(tby, world_size, rank)
     sharded = world_size > 1
     kw = {"tile_rows": tile_rows} if (sharded or tile_rows != (0, tby)) else {}
-    xys, depths, radii, conics, num_tiles, _ = ops.project_gaussians(*pa, **kw)
+    prep = fused_colors and getattr(ops, "fused_prep", False)
+    if prep:      # exp / normalise / sigmoid folded into the kernels (see GaussianRasterizer)
+        view, projview, _ = camera_on_device(camera, device)
+        pa = [model.means, model.scales, 1., model.quats, view[:3, :], projview, camera.f_x,
+              camera.f_y, w / 2, h / 2, h, w, tile_bounds(dims)]
+        xys, depths, radii, conics, num_tiles, _ = ops.project_gaussians(
+            *pa, log_scales=True, raw_quats=True, **kw)
+    else:
+        pa = project_args(model, camera, dims, device)
+        xys, depths, radii, conics, num_tiles, _ = ops.project_gaussians(*pa, **kw)
     if xys.requires_grad:
         xys.retain_grad()
     colors = _colors(model, camera, ops, device, fused_colors)
     ra = raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims)
+    if prep:
+        ra[6] = model.opacities
+        kw = dict(kw, logit_opacity=True)
     if sharded:
         ra[0], ra[3], ra[5], ra[6] = sum_grads_across_ranks((ra[0], ra[3], ra[5], ra[6]), group)
     rgb, _ = ops.rasterize_gaussians(*ra, **kw)

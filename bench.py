@@ -40,6 +40,8 @@ def alg_bytes(entry: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3) -
         "ts_project_bwd": 104.0 * n,                      # R 40+4+24 N, W 40 N  (no v_cov3d)
         "ts_sh_fwd": (24.0 + 12.0 * k) * n,
         "ts_sh_bwd": (24.0 + 12.0 * k) * n,
+        "ts_sh_colors_fwd": (24.0 + 12.0 * k) * n,        # same stage, view dirs + clamp fused
+        "ts_sh_colors_bwd": (24.0 + 12.0 * k) * n,
         "ts_scan_tiles": 8.0 * n,
         "ts_bin_count": 12.0 * n + 4.0 * t,
         "ts_tile_offsets": 16.0 * t,

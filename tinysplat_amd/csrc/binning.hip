@@ -10,9 +10,9 @@
 //   tile_offsets    column scan of the matrix (per-chunk bases) + exclusive scan over tiles -> tile_bins
 //   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 8-byte key stores
 //                   key = depth_bits << 32 | gaussian_id   (unique inside a tile)
-//   sort_tiles      one workgroup per tile: LDS bitonic network (flip/disperse form, all compares
-//                   ascending, so the tail of a non-power-of-two list needs no padding storage);
-//                   buckets larger than the LDS budget run the same network in global memory
+//   sort_tiles      one workgroup per tile: bitonic network with the keys in registers (in-thread
+//                   stages), 64-bit lane exchanges (in-wave stages) and LDS only for the few
+//                   cross-wave stages; buckets > 4096 keys run a flip/disperse network in global memory
 //   pack_splats     gathers the compositing operands of a Gaussian into one 48-byte record
 // Traffic: 8 I written + 8 I read + 4 I written (+ 8 B T for the count matrix) against the 36 I a 3-pass 64-bit
 // LSD radix sort of key+payload would move at minimum.
@@ -302,6 +302,75 @@ __device__ __forceinline__ void bitonic_network(Ptr a, int n) {
     }
 }
 
+// Register-resident bitonic sort of one tile bucket by a 256-thread workgroup: thread t holds the E
+// consecutive keys t*E .. t*E+E-1 (padded with +inf to npad = 256*E).  Compare-exchange partners at
+// distance j are in the same thread (j < E: pure register work), in the same wave (E <= j < 64 E:
+// 64-bit lane exchange through the LDS crossbar, no barrier) or in another wave (j >= 64 E: one LDS
+// round trip with a barrier - at most 3 of the 55 stages of a 1024-key sort).
+template <int E>
+__device__ __forceinline__ void sort_tile_regs(const unsigned long long* __restrict__ g,
+                                               int* __restrict__ out, int n,
+                                               unsigned long long* lds) {
+    constexpr int NPAD = kThreads * E;
+    const int t = threadIdx.x, lane = t & 63;
+    unsigned long long k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t * E + e;
+        k[e] = i < n ? g[i] : ~0ull;
+    }
+    int npad = 2;
+    while (npad < n) npad <<= 1;                     // stages beyond npad only see +inf padding
+    if (npad > NPAD) npad = NPAD;
+    for (int kk = 2; kk <= npad; kk <<= 1) {
+        for (int j = kk >> 1; j >= E && j >= 1; j >>= 1) {
+            if (j >= 64 * E) {                       // partner in another wave
+#pragma unroll
+                for (int e = 0; e < E; ++e) lds[t * E + e] = k[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = t * E + e;
+                    const unsigned long long o = lds[i ^ j];
+                    const bool keep_min = ((i & j) == 0) == ((i & kk) == 0);
+                    k[e] = keep_min ? (k[e] < o ? k[e] : o) : (k[e] > o ? k[e] : o);
+                }
+                __syncthreads();
+            } else {                                 // partner lane = lane ^ (j / E), same register
+                const int m = j / E;
+                const bool lower = (lane & m) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = t * E + e;
+                    const unsigned long long o = __shfl_xor(k[e], m, 64);
+                    const bool keep_min = lower == ((i & kk) == 0);
+                    k[e] = keep_min ? (k[e] < o ? k[e] : o) : (k[e] > o ? k[e] : o);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // in-thread stages (compile-time register ids)
+            if (jj < kk) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & jj) == 0) {
+                        const bool asc = (((t * E + e) & kk) == 0);
+                        const unsigned long long x = k[e], y = k[e | jj];
+                        const bool sw = (x > y) == asc;
+                        k[e] = sw ? y : x;
+                        k[e | jj] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t * E + e;
+        if (i < n) out[i] = (int)(unsigned int)k[e];
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
     const int* __restrict__ tile_bins, unsigned long long* __restrict__ keys,
     int* __restrict__ ids_sorted) {
@@ -311,14 +380,14 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
     if (n <= 0) return;
     unsigned long long* g = keys + range.x;
     int* out = ids_sorted + range.x;
-    if (n <= kSortCap) {
-        for (int i = threadIdx.x; i < n; i += kThreads) lk[i] = g[i];
-        __syncthreads();
-        bitonic_network(lk, n);
-        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = (int)(unsigned int)lk[i];
-    } else {
-        // one workgroup, one CU: the vector L1 is write-through and shared by the workgroup, a
-        // workgroup-scope fence + barrier orders the stages
+    if (n <= kThreads) sort_tile_regs<1>(g, out, n, lk);
+    else if (n <= 2 * kThreads) sort_tile_regs<2>(g, out, n, lk);
+    else if (n <= 4 * kThreads) sort_tile_regs<4>(g, out, n, lk);
+    else if (n <= 8 * kThreads) sort_tile_regs<8>(g, out, n, lk);
+    else if (n <= kSortCap) sort_tile_regs<16>(g, out, n, lk);
+    else {
+        // larger than the register/LDS budget: the flip/disperse network in global memory (one
+        // workgroup, one CU: the vector L1 is shared and write-through, barriers order the stages)
         volatile unsigned long long* vg = g;
         __syncthreads();
         bitonic_network(vg, n);

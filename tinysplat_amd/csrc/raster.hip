@@ -128,10 +128,30 @@ struct Staged {          // what a lane derives from the Gaussian it gathered
     float gx, gy, hA, B, hC, lo;   // conic and opacity in the log2 domain
 };
 
+// Bounding rectangle (in lane coordinates 0..7) of the pixels of an 8x8 block selected by a 64-bit
+// lane mask (bit = ly*8 + lx).  Pure scalar bit arithmetic on the ballot.  Returns false if empty.
+struct BlockRect { float x0, x1, y0, y1; };          // inclusive sample-position bounds
+__device__ __forceinline__ bool mask_rect(unsigned long long m, int& xmin, int& xmax, int& ymin,
+                                          int& ymax) {
+    if (m == 0ull) return false;
+    ymin = __builtin_ctzll(m) >> 3;
+    ymax = (63 - __builtin_clzll(m)) >> 3;
+    unsigned int c = (unsigned int)(m | (m >> 32));
+    c |= c >> 16;
+    c |= c >> 8;
+    c &= 0xffu;
+    xmin = __builtin_ctz(c);
+    xmax = 31 - __builtin_clz(c);
+    return true;
+}
+
 // gather + exact cull against the four 8x8 pixel blocks of the tile (block k: bx = k&1, by = k>>1).
-// (X0,Y0) = sample position of the tile's first pixel.
+// rects[k] = sample-position bounding rectangle of the pixels of block k that still matter (all of
+// the block at first; it shrinks as pixels saturate in the forward pass / covers only the pixels
+// whose lists have started in the backward pass), kept in LDS so that the rolled loop can index it.
+// blocks = bit mask of the blocks whose rectangle is non-empty.
 __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const float4 q1,
-                                              float X0, float Y0) {
+                                              const float4* __restrict__ rects, int blocks) {
     Staged s;
     s.gx = q0.x; s.gy = q0.y;
     const float A = q0.w, Bc = q1.x, Cc = q1.y, op = q0.z;
@@ -146,9 +166,10 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
             if (s.hA > 0.0f && s.hC > 0.0f) {
 #pragma unroll 1
                 for (int k = 0; k < 4; ++k) {           // rolled: runs once per 64 entries, keeps VGPRs low
-                    const float bx0 = X0 + (float)(8 * (k & 1)), by0 = Y0 + (float)(8 * (k >> 1));
-                    const float xlo = s.gx - (bx0 + 7.0f), xhi = s.gx - bx0;
-                    const float ylo = s.gy - (by0 + 7.0f), yhi = s.gy - by0;
+                    if (!(blocks & (1 << k))) continue;
+                    const float4 r = rects[k];          // {x0, x1, y0, y1}, wave-uniform
+                    const float xlo = s.gx - r.y, xhi = s.gx - r.x;
+                    const float ylo = s.gy - r.w, yhi = s.gy - r.z;
                     const float m = min_form_on_rect(s.hA, s.B, s.hC, xlo, xhi, ylo, yhi);
                     const float dxm = fmaxf(fabsf(xlo), fabsf(xhi));
                     const float dym = fmaxf(fabsf(ylo), fabsf(yhi));
@@ -156,11 +177,31 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
                     if (m <= tau + 0.02f + 4.0e-6f * mag) s.mask |= (1 << k);
                 }
             } else {
-                s.mask = 15;                            // not a PSD conic: no geometric cull
+                s.mask = blocks;                        // not a PSD conic: no geometric cull
             }
         }
     }
     return s;
+}
+
+// Writes rects[k] for the pixels selected by `sel[k]` (one bool per lane and block) and returns the
+// mask of non-empty blocks.  Lane 0 stores; callers fence before reading.
+__device__ __forceinline__ int update_rects(const bool sel[4], float X0, float Y0, float4* rects,
+                                            int lane) {
+    int blocks = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(sel[k]);
+        int xmin, xmax, ymin, ymax;
+        if (mask_rect(m, xmin, xmax, ymin, ymax)) {
+            blocks |= (1 << k);
+            const float bx = X0 + (float)(8 * (k & 1)), by = Y0 + (float)(8 * (k >> 1));
+            if (lane == 0)
+                rects[k] = make_float4(bx + (float)xmin, bx + (float)xmax, by + (float)ymin,
+                                       by + (float)ymax);
+        }
+    }
+    return blocks;
 }
 
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
@@ -172,10 +213,12 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ final_Ts, int* __restrict__ final_index) {
     __shared__ float4 lds_all[kWaves][64 * 3];
+    __shared__ float4 rect_all[kWaves][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
     if (tile >= num_tiles) return;
     float4* lds = lds_all[wave];
+    float4* rects = rect_all[wave];
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
     const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
@@ -222,8 +265,17 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
         if (i + 128 < range.y) id_next = ids_sorted[i + 128];
-        const Staged s = stage_splat(have, q0, q1, X0, Y0);
-        const bool keep = (s.mask & live) != 0;
+        {   // rectangle of the still-unfinished pixels of each block: saturated pixels need no more
+            // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
+            bool sel[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sel[k] = T[k] != 0.0f;
+            live = update_rects(sel, X0, Y0, rects, lane);
+            TS_WAVE_SYNC();
+            if (live == 0) break;
+        }
+        const Staged s = stage_splat(have, q0, q1, rects, live);
+        const bool keep = s.mask != 0;
         const unsigned long long mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
@@ -235,8 +287,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         TS_WAVE_SYNC();
         for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
             const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
-            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)) & live;
-            if (bm == 0) continue;
+            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
             const int idx = __float_as_int(r2.z);
             float dxv[2], dyv[2], Ax[2], Bx[2], Cy[2];
             dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
@@ -268,10 +319,6 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             }
         }
         TS_WAVE_SYNC();
-        // per-block early out: a block whose 64 pixels are all finished is skipped from now on
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((live & (1 << k)) && !__any(T[k] != 0.0f)) live &= ~(1 << k);
     }
 
     float bg[CH];
@@ -358,9 +405,11 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     __shared__ float4 lds_all[kWaves][64 * 4];
+    __shared__ float4 rect_all[kWaves][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
     if (tile >= num_tiles) return;
+    float4* rects = rect_all[wave];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     if (range.y <= range.x) return;
     float4* lds = lds_all[wave];
@@ -434,7 +483,15 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
         if (i - 128 >= range.x) id_next = ids_sorted[i - 128];
-        Staged s = stage_splat(have, q0, q1, X0, Y0);
+        int blocks;
+        {   // rectangle of the pixels whose forward list reaches into this chunk (fidx >= chunk low)
+            bool sel[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sel[k] = fidx[k] >= hi - 63;
+            blocks = update_rects(sel, X0, Y0, rects, lane);
+            TS_WAVE_SYNC();
+        }
+        Staged s = stage_splat(have, q0, q1, rects, blocks);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (i > bmax[k]) s.mask &= ~(1 << k);   // nothing in block k got this far in forward

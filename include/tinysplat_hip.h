@@ -127,16 +127,16 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_cam
  * writes tile_bins[t] = {start, end} (both 0 for an empty tile). */
 int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins, void* stream);
 
-/* Writes key = (float_bits(depth) << 32 | gaussian_id) of every (Gaussian, covered tile) pair into
- * the tile's bucket of isect_keys (order inside a bucket is arbitrary until ts_sort_tiles). */
-int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
-                   const ts_camera* cam_host, const int32_t* bin_ws, uint64_t* isect_keys,
-                   void* stream);
+/* Writes the id of every Gaussian into the bucket of each tile its rectangle covers (bucket_ids[I];
+ * order inside a bucket is arbitrary until ts_sort_tiles). */
+int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
+                   const int32_t* bin_ws, int32_t* bucket_ids, void* stream);
 
 /* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort
- * of (tile<<32 | depth-bits) keys emitted Gaussian-major - and writes gaussian_ids_sorted[I]. */
-int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_keys,
-                  int32_t* gaussian_ids_sorted, void* stream);
+ * of (tile<<32 | depth-bits) keys emitted Gaussian-major - reading bucket_ids[I] and depths[n] and
+ * writing gaussian_ids_sorted[I] (a different buffer). */
+int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
+                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, void* stream);
 
 #define TS_RASTER_LOGIT_OPACITY 1 /* `opacity` holds logits: sigmoid (rasterize.py:86) is applied while */
                                   /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */

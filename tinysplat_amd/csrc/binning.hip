@@ -8,13 +8,14 @@
 //   scan_tiles      wave-scan (DPP-free __shfl_up ladder inside a wave, LDS across the 4 waves)
 //   bin_count       per-chunk tile histograms in LDS (ds_add), B x T count matrix, no global atomics
 //   tile_offsets    column scan of the matrix (per-chunk bases) + exclusive scan over tiles -> tile_bins
-//   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 8-byte key stores
-//                   key = depth_bits << 32 | gaussian_id   (unique inside a tile)
+//   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 4-byte id stores
+//                   (the sort gathers depth by id from the 4 N-byte, L2-resident depth array;
+//                   sort key = depth_bits << 32 | gaussian_id, unique inside a tile)
 //   sort_tiles      one workgroup per tile: bitonic network with the keys in registers (in-thread
 //                   stages), 64-bit lane exchanges (in-wave stages) and LDS only for the few
 //                   cross-wave stages; buckets > 4096 keys run a flip/disperse network in global memory
 //   pack_splats     gathers the compositing operands of a Gaussian into one 48-byte record
-// Traffic: 8 I written + 8 I read + 4 I written (+ 8 B T for the count matrix) against the 36 I a 3-pass 64-bit
+// Traffic: 4 I written + 4 I read (+ gathers) + 4 I written (+ 8 B T for the count matrix) against the 36 I a 3-pass 64-bit
 // LSD radix sort of key+payload would move at minimum.
 #include <hip/hip_runtime.h>
 
@@ -241,10 +242,10 @@ __global__ __launch_bounds__(kThreads) void column_finish_kernel(int num_tiles, 
 }
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
-    int n, int chunk, const float* __restrict__ xys, const float* __restrict__ depths,
+    int n, int chunk, const float* __restrict__ xys,
     const int* __restrict__ radii, const ts_camera cam, int num_tiles,
     const int* __restrict__ bases, const int* __restrict__ tile_start,
-    unsigned long long* __restrict__ keys) {
+    int* __restrict__ bucket_ids) {
     extern __shared__ int cursor[];
     const int t0 = blockIdx.y * kBinWindow;
     const int tw = min(num_tiles - t0, kBinWindow);
@@ -258,12 +259,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        const unsigned long long key =
-            ((unsigned long long)__float_as_uint(depths[i]) << 32) | (unsigned int)i;
         for (int ty = b.miny; ty < b.maxy; ++ty)
             for (int tx = b.minx; tx < b.maxx; ++tx) {
                 const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
-                if ((unsigned)t < (unsigned)tw) keys[atomicAdd(&cursor[t], 1)] = key;
+                if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
             }
     }
 }
@@ -271,10 +270,19 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
 // ---- per-tile bitonic sort ---------------------------------------------------------------------
 constexpr int kSortCap = 4096;   // keys held in LDS (32 KiB); larger buckets sort in global memory
 
-template <typename Ptr>
-__device__ __forceinline__ void cmpswap(Ptr a, int i, int j) {
-    const unsigned long long x = a[i], y = a[j];
-    if (x > y) { a[i] = y; a[j] = x; }
+// sort key of a bucket entry: depth bits (positive floats order like their bit patterns) then id
+__device__ __forceinline__ unsigned long long make_key(const float* __restrict__ depths, int id) {
+    return ((unsigned long long)__float_as_uint(depths[id]) << 32) | (unsigned int)id;
+}
+
+struct IdKeyArray {                 // in-place view of a bucket of ids compared through their keys
+    volatile int* ids;
+    const float* depths;
+};
+
+__device__ __forceinline__ void cmpswap(IdKeyArray a, int i, int j) {
+    const int x = a.ids[i], y = a.ids[j];
+    if (make_key(a.depths, x) > make_key(a.depths, y)) { a.ids[i] = y; a.ids[j] = x; }
 }
 
 template <typename Ptr>
@@ -308,7 +316,8 @@ __device__ __forceinline__ void bitonic_network(Ptr a, int n) {
 // 64-bit lane exchange through the LDS crossbar, no barrier) or in another wave (j >= 64 E: one LDS
 // round trip with a barrier - at most 3 of the 55 stages of a 1024-key sort).
 template <int E>
-__device__ __forceinline__ void sort_tile_regs(const unsigned long long* __restrict__ g,
+__device__ __forceinline__ void sort_tile_regs(const int* __restrict__ g,
+                                               const float* __restrict__ depths,
                                                int* __restrict__ out, int n,
                                                unsigned long long* lds) {
     constexpr int NPAD = kThreads * E;
@@ -317,7 +326,7 @@ __device__ __forceinline__ void sort_tile_regs(const unsigned long long* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = t * E + e;
-        k[e] = i < n ? g[i] : ~0ull;
+        k[e] = i < n ? make_key(depths, g[i]) : ~0ull;
     }
     int npad = 2;
     while (npad < n) npad <<= 1;                     // stages beyond npad only see +inf padding
@@ -372,26 +381,27 @@ __device__ __forceinline__ void sort_tile_regs(const unsigned long long* __restr
 }
 
 __global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
-    const int* __restrict__ tile_bins, unsigned long long* __restrict__ keys,
-    int* __restrict__ ids_sorted) {
+    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
     __shared__ unsigned long long lk[kSortCap];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
     const int n = range.y - range.x;
     if (n <= 0) return;
-    unsigned long long* g = keys + range.x;
+    const int* g = bucket_ids + range.x;
     int* out = ids_sorted + range.x;
-    if (n <= kThreads) sort_tile_regs<1>(g, out, n, lk);
-    else if (n <= 2 * kThreads) sort_tile_regs<2>(g, out, n, lk);
-    else if (n <= 4 * kThreads) sort_tile_regs<4>(g, out, n, lk);
-    else if (n <= 8 * kThreads) sort_tile_regs<8>(g, out, n, lk);
-    else if (n <= kSortCap) sort_tile_regs<16>(g, out, n, lk);
+    if (n <= kThreads) sort_tile_regs<1>(g, depths, out, n, lk);
+    else if (n <= 2 * kThreads) sort_tile_regs<2>(g, depths, out, n, lk);
+    else if (n <= 4 * kThreads) sort_tile_regs<4>(g, depths, out, n, lk);
+    else if (n <= 8 * kThreads) sort_tile_regs<8>(g, depths, out, n, lk);
+    else if (n <= kSortCap) sort_tile_regs<16>(g, depths, out, n, lk);
     else {
-        // larger than the register/LDS budget: the flip/disperse network in global memory (one
-        // workgroup, one CU: the vector L1 is shared and write-through, barriers order the stages)
-        volatile unsigned long long* vg = g;
+        // larger than the register/LDS budget: copy the ids and run the flip/disperse network in
+        // place in global memory, comparing through gathered depths (one workgroup, one CU: the
+        // vector L1 is shared and write-through, barriers order the stages)
+        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = g[i];
         __syncthreads();
-        bitonic_network(vg, n);
-        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = (int)(unsigned int)vg[i];
+        IdKeyArray a{out, depths};
+        bitonic_network(a, n);
     }
 }
 
@@ -507,12 +517,11 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     return launch_status();
 }
 
-int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32_t* radii,
-                   const ts_camera* cam, const int32_t* bin_ws, uint64_t* isect_keys,
-                   void* stream) {
+int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
+                   const int32_t* bin_ws, int32_t* bucket_ids, void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
-    if (!xys || !depths || !radii || !bin_ws || !isect_keys) return TS_E_BADARG;
+    if (!xys || !radii || !bin_ws || !bucket_ids) return TS_E_BADARG;
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0) return 0;
     const int chunks = bin_num_chunks(n);
@@ -523,19 +532,18 @@ int ts_bin_scatter(int32_t n, const float* xys, const float* depths, const int32
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_scatter_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
-                       (hipStream_t)stream, n, chunk, xys, depths, radii, *cam, nt, bin_ws,
-                       bin_ws + (size_t)chunks * nt, reinterpret_cast<unsigned long long*>(isect_keys));
+                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, bin_ws,
+                       bin_ws + (size_t)chunks * nt, bucket_ids);
     return launch_status();
 }
 
-int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, uint64_t* isect_keys,
-                  int32_t* gaussian_ids_sorted, void* stream) {
+int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
+                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, void* stream) {
     if (num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
-    if (!tile_bins || !isect_keys || !gaussian_ids_sorted) return TS_E_BADARG;
+    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted) return TS_E_BADARG;
     hipLaunchKernelGGL(sort_tiles_kernel, dim3(num_tiles), dim3(kThreads), 0, (hipStream_t)stream,
-                       tile_bins, reinterpret_cast<unsigned long long*>(isect_keys),
-                       gaussian_ids_sorted);
+                       tile_bins, depths, bucket_ids, gaussian_ids_sorted);
     return launch_status();
 }
 

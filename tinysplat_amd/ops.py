@@ -372,15 +372,15 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
         total = int(cum[-1].item()) if n > 0 else 0          # the one host sync of the path
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-        keys = torch.empty((max(total, 1),), dtype=torch.int64, device=dev)
+        bucket_ids = torch.empty((max(total, 1),), **i32)
         ids = torch.empty((max(total, 1),), **i32)
         _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys_c), _ptr(radii_c), cam, _ptr(bin_ws), s)
         _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
         if total > 0:
-            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
-                  cam, _ptr(bin_ws), _ptr(keys), s)
-            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(keys),
-                  _ptr(ids), s)
+            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys_c), _ptr(radii_c), cam,
+                  _ptr(bin_ws), _ptr(bucket_ids), s)
+            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths_c),
+                  _ptr(bucket_ids), _ptr(ids), s)
     b.num_intersects = total
     b.cum_tiles_hit = cum
     b.tile_bins = tile_bins[:num_tiles]

@@ -92,13 +92,17 @@ class GaussianRasterizer:
         # HIP kernel when the ops namespace offers it; False = the reference's op-by-op recipe.
         # fused_prep: likewise fold exp(scales), quats/|quats| (rasterize.py:72-73) and
         # sigmoid(opacities) (rasterize.py:86) into the projection / packing kernels.
+        # fused_depth: composite RGB and depth in ONE 4-channel pass (the kernels are templated on
+        # the channel count) instead of two 3-channel passes over the same lists.
         self.fused_colors = fused_colors
         self.fused_prep = fused_colors
+        self.fused_depth = fused_colors
         # the three callables of the boundary; the product default is the HIP library
         self.ops = SimpleNamespace(project_gaussians=_hip_ops.project_gaussians,
                                    spherical_harmonics=_hip_ops.spherical_harmonics,
                                    rasterize_gaussians=_hip_ops.rasterize_gaussians,
-                                   sh_colors=_hip_ops.sh_colors, fused_prep=True)
+                                   sh_colors=_hip_ops.sh_colors, fused_prep=True,
+                                   four_channels=True)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
@@ -124,15 +128,26 @@ class GaussianRasterizer:
 
         colors = self.colors(camera)
 
-        rgb, _ = ops.rasterize_gaussians(*self._raster_inputs(
-            xys, depths, radii, conics, num_tiles, colors, dims, prep), **rkw)
-        rgb = torch.clamp(rgb, max=1.0)
+        if self.fused_depth and getattr(ops, "four_channels", False):
+            # one 4-channel compositing pass instead of the reference's two 3-channel ones
+            # (rasterize.py:44 and :50): channel 3 carries the depth, its background is
+            # background[0] exactly as in the reference's depth pass (rasterize.py:86)
+            ra = self._raster_inputs(xys, depths, radii, conics, num_tiles,
+                                     torch.cat([colors, depths[:, None]], dim=1), dims, prep)
+            ra[9] = torch.cat([ra[9], ra[9][:1]])
+            out, _ = ops.rasterize_gaussians(*ra, **rkw)
+            rgb = torch.clamp(out[:, :, :3], max=1.0)
+            depth_map = out[:, :, 3]
+        else:
+            rgb, _ = ops.rasterize_gaussians(*self._raster_inputs(
+                xys, depths, radii, conics, num_tiles, colors, dims, prep), **rkw)
+            rgb = torch.clamp(rgb, max=1.0)
+            depth_as_color = depths[:, None].repeat(1, 3)
+            depth_img, _ = ops.rasterize_gaussians(*self._raster_inputs(
+                xys, depths, radii, conics, num_tiles, depth_as_color, dims, prep), **rkw)
+            depth_map = depth_img[:, :, 0]
 
-        depth_as_color = depths[:, None].repeat(1, 3)
-        depth_img, _ = ops.rasterize_gaussians(*self._raster_inputs(
-            xys, depths, radii, conics, num_tiles, depth_as_color, dims, prep), **rkw)
-
-        extras = {"depth": depth_img[:, :, 0], "radii": radii, "xys": xys,
+        extras = {"depth": depth_map, "radii": radii, "xys": xys,
                   "camera": {"height": camera.height, "width": camera.width}}
         return rgb, extras
 

@@ -160,6 +160,10 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
     s.hC = 0.5f * kLog2e * Cc;
     s.lo = __log2f(op);
     s.mask = 0;
+    // bit 4 ("general"): the per-pixel code must test sigma >= 0 and apply the 0.999 clamp.  For a
+    // positive-definite conic and opacity <= 0.99 neither can trigger (sigma >= 0 up to rounding,
+    // alpha = opacity * exp(-sigma) <= opacity), and the kernels take a leaner wave-uniform path.
+    const bool general = !(s.hA > 0.0f && s.hC > 0.0f && 4.0f * s.hA * s.hC > s.B * s.B && op <= 0.99f);
     if (have && op > 0.0f) {
         const float tau = s.lo + kLog2_255;            // sigma' <= tau  <=>  alpha >= 1/255
         if (tau >= -0.02f) {
@@ -179,6 +183,7 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
             } else {
                 s.mask = blocks;                        // not a PSD conic: no geometric cull
             }
+            if (s.mask != 0 && general) s.mask |= 16;
         }
     }
     return s;
@@ -204,6 +209,63 @@ __device__ __forceinline__ int update_rects(const bool sel[4], float X0, float Y
     return blocks;
 }
 
+using mask64 = unsigned long long;
+#define TS_BALLOT(c) __builtin_amdgcn_ballot_w64(c)          // lane condition -> 64-bit scalar mask
+#define TS_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)    // scalar mask -> lane condition
+
+// Composites the `cnt` staged Gaussians of one chunk into the wave's tile (forward).
+//   per pixel and block k: T > 0 = transmittance of an unfinished pixel; T < 0 = finished (or
+//   outside the image) with final transmittance |T|; fidx = list index of the last Gaussian
+//   composited; acc = colour.
+// vis = |T_old| - |T_new| equals alpha*T up to one rounding of T, is 0 for the stopping Gaussian
+// and for finished pixels, and makes the weights telescope (sum of vis = 1 - T_final exactly).
+// GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
+// positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
+template <int CH, bool GENERAL>
+__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
+                                          float fpy0, float (&T)[4], int (&fidx)[4],
+                                          float (&acc)[4][CH]) {
+    for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
+        const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
+        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
+        const int idx = __float_as_int(r2.z);
+        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
+        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+        const float neg_lo = -r1.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Ax[h] = (r0.z * dxv[h]) * dxv[h];
+            Bx[h] = r0.w * dxv[h];
+            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
+        }
+        float col[CH];
+        col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
+        if (CH == 4) col[CH - 1] = r2.y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(bm & (1 << k))) continue;                           // wave-uniform
+            // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
+            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dyv[k >> 1]);
+            float a = __builtin_amdgcn_exp2f(-sgl);
+            bool ok = (a >= ts::kAlphaMin) & (T[k] > 0.0f);
+            if (GENERAL) {
+                a = fminf(ts::kAlphaMax, a);
+                ok = ok & (sgl >= neg_lo);                            // sigma >= 0
+            }
+            const float ae = ok ? a : 0.0f;
+            const float nT = __builtin_fmaf(-ae, T[k], T[k]);
+            const bool stop = (nT <= ts::kTEps) & ok;
+            const float Tn = stop ? -T[k] : nT;       // the stopping Gaussian is not composited
+            const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
+            fidx[k] = (ok & !stop) ? idx : fidx[k];
+            T[k] = Tn;
+        }
+    }
+}
+
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
 // that position in each of the four blocks k of the 16x16 tile.
 template <int CH>
@@ -226,16 +288,15 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
 
-    // T = live transmittance (0 once the pixel is finished), Tout = transmittance to report
-    float T[4], Tout[4], acc[4][CH];
+    // T > 0: transmittance of an unfinished pixel; T < 0: finished or outside, final value |T|
+    float T[4], acc[4][CH];
     int fidx[4];
     bool inside[4];
     int live = 0;                                   // blocks that still have unfinished pixels
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H);
-        T[k] = inside[k] ? 1.0f : 0.0f;
-        Tout[k] = 1.0f;
+        T[k] = inside[k] ? 1.0f : -1.0f;
         fidx[k] = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[k][c] = 0.0f;
@@ -269,7 +330,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
             bool sel[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sel[k] = T[k] != 0.0f;
+            for (int k = 0; k < 4; ++k) sel[k] = T[k] > 0.0f;
             live = update_rects(sel, X0, Y0, rects, lane);
             TS_WAVE_SYNC();
             if (live == 0) break;
@@ -285,39 +346,12 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
         TS_WAVE_SYNC();
-        for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
-            const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
-            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
-            const int idx = __float_as_int(r2.z);
-            float dxv[2], dyv[2], Ax[2], Bx[2], Cy[2];
-            dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
-            dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                Ax[h] = (r0.z * dxv[h]) * dxv[h];
-                Bx[h] = r0.w * dxv[h];
-                Cy[h] = (r1.x * dyv[h]) * dyv[h];
-            }
-            float col[CH];
-            col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
-            if (CH == 4) col[CH - 1] = r2.y;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!(bm & (1 << k))) continue;                       // wave-uniform
-                const float sg = sigma_l2(Ax[k & 1] + Cy[k >> 1], Bx[k & 1], dyv[k >> 1]);
-                const float a = fminf(ts::kAlphaMax, __builtin_amdgcn_exp2f(r1.y - sg));
-                const bool ok = (sg >= 0.0f) && (a >= ts::kAlphaMin);
-                const float ae = ok ? a : 0.0f;
-                const float nT = __builtin_fmaf(-ae, T[k], T[k]);
-                const bool stop = nT <= ts::kTEps;                    // also true once T == 0
-                const float vis = stop ? 0.0f : ae * T[k];            // the stopping Gaussian is not composited
-#pragma unroll
-                for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
-                fidx[k] = (ok && !stop) ? idx : fidx[k];
-                Tout[k] = stop ? Tout[k] : nT;
-                T[k] = stop ? 0.0f : nT;
-            }
-        }
+        // bit 4 of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
+        // once per chunk so that the common case runs a loop without those tests
+        if (__ballot(keep && (s.mask & 16)) != 0ull)
+            fwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, fidx, acc);
+        else
+            fwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, fidx, acc);
         TS_WAVE_SYNC();
     }
 
@@ -329,11 +363,12 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     for (int k = 0; k < 4; ++k) {
         if (!inside[k]) continue;
         const size_t pix = (size_t)(py0 + 8 * (k >> 1) - row_off) * W + (px0 + 8 * (k & 1));
-        final_Ts[pix] = Tout[k];
+        const float Tf = __builtin_fabsf(T[k]);
+        final_Ts[pix] = Tf;
         final_index[pix] = fidx[k];
         float* o = out_img + pix * CH;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + Tout[k] * bg[c];
+        for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + Tf * bg[c];
     }
 }
 
@@ -392,6 +427,83 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
             partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
         } else if (w == 6 + CH) {
             row_flags[slot] = 1;                               // this row now holds data
+        }
+    }
+}
+
+// Replays the `cnt` staged Gaussians of one chunk back to front (backward).
+//   per pixel and block k: T = transmittance behind the Gaussian being replayed, R = T_final *
+//   (v_alpha - bg . v_out) - sum over the Gaussians already replayed of fac * (colour . v_out),
+//   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
+// Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
+// (ra = 1, fac = 0, v_sig = 0) and changes nothing.
+template <int CH, bool GENERAL>
+__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
+                                          float fpy0, float (&T)[4], float (&R)[4],
+                                          const float (&vo)[4][CH], const int (&fidx)[4],
+                                          float (&acc)[6 + CH], long long num_isects,
+                                          float* __restrict__ partials,
+                                          unsigned char* __restrict__ row_flags, int lane) {
+    for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
+        const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
+        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
+        const int idx = __float_as_int(r2.z);
+        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
+        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+        const float neg_lo = -r1.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Ax[h] = (r0.z * dxv[h]) * dxv[h];
+            Bx[h] = r0.w * dxv[h];
+            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
+        }
+        float col[CH];
+        col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
+        if (CH == 4) col[CH - 1] = r2.y;
+
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(bm & (1 << k))) continue;                           // wave-uniform
+            const float dx = dxv[k & 1], dy = dyv[k >> 1];
+            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dy);
+            const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
+            float a = araw;
+            mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx[k]);
+            if (GENERAL) {
+                a = fminf(ts::kAlphaMax, araw);
+                validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
+            }
+            if (validm == 0ull) continue;                              // wave-uniform
+            any = true;
+            const float am = TS_LANE(validm) ? a : 0.0f;
+            const float ra = __builtin_amdgcn_rcpf(1.0f - am);
+            const float Tk = T[k] * ra;                 // transmittance in front of the Gaussian
+            const float fac = am * Tk;
+            float cv = col[0] * vo[k][0];               // colour . v_out of this pixel
+#pragma unroll
+            for (int c = 1; c < CH; ++c) cv = __builtin_fmaf(col[c], vo[k][c], cv);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[6 + c] = __builtin_fmaf(fac, vo[k][c], acc[6 + c]);
+            // dL/dalpha = Tk (c . v_out) + ra (T_final (v_alpha - bg . v_out) - S_behind fac' c' . v_out)
+            const float v_a = __builtin_fmaf(Tk, cv, ra * R[k]);
+            R[k] = __builtin_fmaf(-fac, cv, R[k]);
+            T[k] = Tk;
+            // d alpha / d sigma = -alpha, or 0 where the 0.999 clamp is active
+            float v_sig = -am * v_a;
+            if (GENERAL) v_sig = TS_LANE(TS_BALLOT(araw > ts::kAlphaMax)) ? 0.0f : v_sig;
+            const float vdx = v_sig * dx, vdy = v_sig * dy;
+            acc[0] += v_sig; acc[1] += vdx; acc[2] += vdy;
+            acc[3] = __builtin_fmaf(vdx, dx, acc[3]);
+            acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
+            acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
+        }
+        if (any) {                                                     // `any` is wave-uniform
+            flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
+                          partials, row_flags, lane);
+#pragma unroll
+            for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
         }
     }
 }
@@ -507,64 +619,12 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
         TS_WAVE_SYNC();
-        for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
-            const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
-            const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
-            const int idx = __float_as_int(r2.z);
-            float dxv[2], dyv[2], Ax[2], Bx[2], Cy[2];
-            dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
-            dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                Ax[h] = (r0.z * dxv[h]) * dxv[h];
-                Bx[h] = r0.w * dxv[h];
-                Cy[h] = (r1.x * dyv[h]) * dyv[h];
-            }
-            float col[CH];
-            col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
-            if (CH == 4) col[CH - 1] = r2.y;
-
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!(bm & (1 << k))) continue;                       // wave-uniform
-                const float dx = dxv[k & 1], dy = dyv[k >> 1];
-                const float sg = sigma_l2(Ax[k & 1] + Cy[k >> 1], Bx[k & 1], dy);
-                const float araw = __builtin_amdgcn_exp2f(r1.y - sg);  // opacity * exp(-sigma)
-                const float a = fminf(ts::kAlphaMax, araw);
-                const bool valid = (idx <= fidx[k]) && (sg >= 0.0f) && (a >= ts::kAlphaMin);
-                if (!__any(valid)) continue;                          // wave-uniform
-                any = true;
-                // Straight-line, full-exec body: lanes that are not valid compute finite garbage
-                // (a <= 0.999, so 1 - a >= 1e-3) and are masked out of every accumulation through
-                // fac = v_sig = 0.  No divergent region => no exec save/restore, no phi copies.
-                const float ra = __builtin_amdgcn_rcpf(1.0f - a);
-                const float Tk = T[k] * ra;                     // transmittance in front of g
-                const float fac = valid ? a * Tk : 0.0f;
-                float cv = col[0] * vo[k][0];                   // colour . v_out of this pixel
-#pragma unroll
-                for (int c = 1; c < CH; ++c) cv = __builtin_fmaf(col[c], vo[k][c], cv);
-#pragma unroll
-                for (int c = 0; c < CH; ++c) acc[6 + c] = __builtin_fmaf(fac, vo[k][c], acc[6 + c]);
-                // dL/dalpha = Tk (c . v_out) + ra (T_final (v_alpha - bg . v_out) - S_behind fac' c' . v_out)
-                const float v_a = __builtin_fmaf(Tk, cv, ra * R[k]);
-                R[k] = __builtin_fmaf(-fac, cv, R[k]);
-                T[k] = valid ? Tk : T[k];
-                // d alpha / d sigma = -araw unless the 0.999 clamp is active (then 0)
-                const float v_sig = (valid && !(araw > ts::kAlphaMax)) ? -araw * v_a : 0.0f;
-                const float vdx = v_sig * dx, vdy = v_sig * dy;
-                acc[0] += v_sig; acc[1] += vdx; acc[2] += vdy;
-                acc[3] = __builtin_fmaf(vdx, dx, acc[3]);
-                acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
-                acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
-            }
-            if (any) {                                             // `any` is wave-uniform
-                flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
-                              partials, row_flags, lane);
-#pragma unroll
-                for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
-            }
-        }
+        if (__ballot(keep && (s.mask & 16)) != 0ull)
+            bwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+                                row_flags, lane);
+        else
+            bwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+                                 row_flags, lane);
         TS_WAVE_SYNC();
     }
 }

@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--depth", action="store_true", help="also run the depth rasterize pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gradient all-reduce even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +126,9 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from tinysplat_amd import ops
@@ -148,12 +152,13 @@ def main():
             rgb, extras = adapter(cam, (w, h), sh)
             loss = (rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()
         else:
-            rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev, rank, world)
+            rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev, rank, world,
+                                                 collective=True if args.force_dist else None)
             loss = (rgb * w_rgb[y0:y1]).sum()
         loss.backward()
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -232,7 +237,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

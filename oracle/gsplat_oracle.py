@@ -397,7 +397,9 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
         con = conics[g]
         dx, dy = gx - PX, gy - PY
         sigma = 0.5 * (con[:, 0][None] * dx * dx + con[:, 2][None] * dy * dy) + con[:, 1][None] * dx * dy
-        raw = opacity[g][None, :] * torch.exp(-sigma)
+        # exp on a safe argument: sigma < 0 entries are skipped below, and exp(+large) = inf would turn
+        # their (masked) gradient into 0 * inf = NaN under autograd
+        raw = opacity[g][None, :] * torch.exp(-torch.where(sigma >= 0, sigma, torch.zeros_like(sigma)))
         alpha = torch.clamp(raw, max=ALPHA_MAX)
         valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
         a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))

@@ -373,3 +373,81 @@ def test_fused_prep_flags_equal_op_by_op_recipe():
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4      # rare 1-ulp threshold flips
     ga, gb = outs[0][1], outs[1][1]
     assert ((ga - gb).abs() > 1e-4 * max(1.0, ga.abs().max().item())).float().mean().item() < 1e-3
+
+
+def _raster_parity(args, h, w, atol_img=1e-5, use_alpha=True, seed=5):
+    """fwd + bwd of rasterize_gaussians through the C ABI vs autograd of the float64 oracle."""
+    a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in args]
+    leaves64 = {i: a64[i].clone().requires_grad_(True) for i in (0, 3, 5, 6)}
+    for i, t in leaves64.items():
+        a64[i] = t
+    ref_img, ref_alpha, aux = O.rasterize_gaussians(*a64, return_aux=True)
+    stable = aux["margin"] > MARGIN
+    assert (~stable).double().mean() < 5e-3
+    g = torch.Generator().manual_seed(seed)
+    ch = ref_img.shape[-1]
+    w_img = torch.rand(h, w, ch, generator=g) * stable[..., None]
+    w_a = torch.rand(h, w, generator=g) * stable * (1.0 if use_alpha else 0.0)
+    ((ref_img * w_img).sum() + (ref_alpha * w_a).sum()).backward()
+    da = _to_dev(args)
+    leaves = {i: da[i].clone().requires_grad_(True) for i in (0, 3, 5, 6)}
+    for i, t in leaves.items():
+        da[i] = t
+    img, alpha = ops.rasterize_gaussians(*da)
+    ((img * w_img.to(DEV)).sum() + (alpha * w_a.to(DEV)).sum()).backward()
+    assert_close_masked(img, ref_img, atol_img, stable, what="out_img")
+    assert_close_masked(alpha, ref_alpha, 1e-5, stable, what="out_alpha")
+    for i, nm in ((0, "v_xy"), (3, "v_conic"), (5, "v_colors"), (6, "v_opacity")):
+        ref, got = leaves64[i].grad, leaves[i].grad.cpu().double()
+        tol = 1e-5 * max(1.0, ref.abs().max().item())
+        bad = ((got - ref).abs() > tol).double().mean().item()
+        assert bad < 1e-4, f"{nm}: {bad:.2e} entries off by more than {tol:.2e}; max {(got - ref).abs().max():.3e}"
+
+
+def test_raster_four_channels():
+    """colors[N,4] (RGB + depth in one pass, what the adapter's fused depth mode uses)."""
+    model, args = _raster_inputs(12000, 208, 144, 17, 3.0)
+    args[5] = torch.cat([args[5], args[1][:, None]], dim=1)          # 4th channel = depth
+    args[9] = torch.tensor([0.3, 0.5, 0.7, 0.3])
+    _raster_parity(args, 144, 208, atol_img=1e-4)
+
+
+def test_raster_general_path_high_opacity_and_odd_conics():
+    """Opacities up to 1.0 (0.999 clamp active, opacity > 0.99 takes the general per-pixel code)
+    and a few hand-made conics that are not positive definite (no geometric cull, sigma < 0 skip)."""
+    model, args = _raster_inputs(6000, 160, 112, 23, 4.0)
+    g = torch.Generator().manual_seed(9)
+    n = args[0].shape[0]
+    args[6] = (0.9 + 0.1 * torch.rand(n, 1, generator=g)).clamp(max=1.0)
+    args[6][:50] = 1.0
+    con = args[3].clone()
+    odd = torch.randperm(n, generator=g)[:40]
+    con[odd, 1] = con[odd, 1] + 3.0 * torch.sqrt(con[odd, 0] * con[odd, 2])    # |b| > sqrt(a c)
+    args[3] = con
+    _raster_parity(args, 112, 160)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2])
+def test_tiny_inputs(n):
+    w, h = 48, 40
+    model, cam = scene_args(max(n, 1), 1, w, h, seed=4, scale_mult=30.0)
+    md = model.to(DEV)
+    if n == 0:
+        for nm in ("means", "scales", "quats", "opacities", "colors_dc", "colors_rest"):
+            setattr(md, nm, getattr(md, nm)[:0])
+    md.background = torch.tensor([0.5, 0.25, 0.125], device=DEV)
+    md.requires_grad_(True)
+    r = GaussianRasterizer(md, None, device=torch.device(DEV))
+    rgb, extras = r(cam, (w, h), 1)
+    (rgb.sum() + extras["depth"].sum()).backward()
+    assert rgb.shape == (h, w, 3) and extras["depth"].shape == (h, w)
+    assert extras["radii"].shape == (n,) and md.means.grad.shape == (n, 3)
+    if n == 0:
+        assert torch.allclose(rgb.cpu(), torch.tensor([0.5, 0.25, 0.125]).expand(h, w, 3))
+    else:
+        ref = oracle_frame(scene_args(n, 1, w, h, seed=4, scale_mult=30.0)[0].__class__(
+            *[p.detach().cpu() for p in md.parameters()], active_sh_degree=1,
+            background=md.background.cpu()), cam, (w, h))
+        assert torch.equal(extras["radii"].cpu(), ref["radii"])
+        stable = ref["aux"]["margin"] > MARGIN
+        assert_close_masked(rgb, ref["rgb"], 1e-5, stable, what="rgb")

@@ -69,7 +69,7 @@ def _colors(model, camera, ops, device, fused_colors):
 
 def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_size: int = 1,
                       group=None, tile_rows: Optional[Tuple[int, int]] = None,
-                      fused_colors: bool = True):
+                      fused_colors: bool = True, collective: Optional[bool] = None):
     """Steps 1-3 of the reference frame (rasterize.py:30-45: project, SH, clamp, rasterize RGB,
     clamp) for this rank's stripe.  Returns (rgb_stripe[rows,W,3], (row_begin_px, row_end_px), xys).
 
@@ -79,7 +79,7 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
     tby = tile_bounds(dims)[1]
     if tile_rows is None:
         tile_rows = stripe_rows(tby, world_size, rank)
-    sharded = world_size > 1
+    sharded = (world_size > 1) if collective is None else collective   # run the grad all-reduce?
     kw = {"tile_rows": tile_rows} if (sharded or tile_rows != (0, tby)) else {}
     prep = fused_colors and getattr(ops, "fused_prep", False)
     if prep:      # exp / normalise / sigmoid folded into the kernels (see GaussianRasterizer)

@@ -370,6 +370,9 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
         ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
         _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth_c), _ptr(cum), _ptr(ws), s)
         total = int(cum[-1].item()) if n > 0 else 0          # the one host sync of the path
+        if total < 0:
+            raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
+                                "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
         bucket_ids = torch.empty((max(total, 1),), **i32)

@@ -60,6 +60,27 @@ def frame_alg_bytes(n, i, p, t, k, depth):
     return 736.0 * n + 160.0 * i + 44.0 * p + 16.0 * t
 
 
+def measure_read_bandwidth(dev, gib: float = 2.0, reps: int = 10) -> float:
+    """Achievable HBM read bandwidth (GB/s) of this GPU: ts_bench_stream_read over a buffer far larger
+    than the 256 MiB Infinity Cache, best of `reps` (BW_read_measured)."""
+    from tinysplat_amd import _lib
+    lib = _lib.load()
+    n = int(gib * (1 << 30)) // 4
+    buf = torch.ones(n, dtype=torch.float32, device=dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    best = 0.0
+    for _ in range(reps + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(lib.ts_bench_stream_read(buf.data_ptr(), n, sink.data_ptr(), s), "ts_bench_stream_read")
+        b.record()
+        b.synchronize()
+        best = max(best, 4.0 * n / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del buf
+    return best
+
+
 def cpu_baseline(seconds_budget: float = 20.0):
     """Times the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the
     same workload: same scene generator / camera / SH degree, fwd+bwd of the RGB frame, scaled down
@@ -115,7 +136,14 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
+    ap.add_argument("--config", type=int, default=None,
+                    help="BASELINE.json config shortcut: 2 = 100k/1080p, 3 = 1M/1080p (default), "
+                         "5 = 5M/4K with depth")
     args = ap.parse_args()
+    if args.config == 2:
+        args.n = 100_000
+    elif args.config == 5:
+        args.n, args.width, args.height, args.depth = 5_000_000, 3840, 2160, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,6 +239,7 @@ def main():
                 traffic = json.loads(tf.read_text()).get(dom_name)
             except Exception:
                 traffic = None
+        bw_meas = measure_read_bandwidth(dev)
         out = {
             "metric": "Gaussians*pixels/s fwd+bwd",
             "value": value, "unit": "Gaussians*pixels/s", "n_gpus": world, "steps": args.steps,
@@ -227,10 +256,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": a_bytes,
-                         "kernel_ms": dom_ms, "launches_per_step": dom_launches / max(1, args.profile_steps)},
+                         "kernel_ms": dom_ms, "launches_per_step": dom_launches / max(1, args.profile_steps),
+                         "peak_read_measured": bw_meas, "frac_of_measured": achieved / bw_meas},
             "frame_roofline": {"alg_bytes": frame_bytes, "achieved": frame_bytes / (ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "frac": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "peak_read_measured": bw_meas,
+                               "frac_of_measured": frame_bytes / (ms * 1e-3) / 1e9 / bw_meas},
             "entries_ms": {k_: round(v[1] * v[0] / max(1, args.profile_steps), 4)
                            for k_, v in sorted(per_entry.items())},
         }

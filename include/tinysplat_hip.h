@@ -175,6 +175,11 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
                        float* v_colors, float* v_opacity, void* stream);
 
+/* ======================================= measurement utility ================================== */
+/* Streaming read of n_floats float32 (16-byte loads, grid-stride): the read-bandwidth microbenchmark
+ * that SURVEY.md 8(d) D1 asks the roofline to be quoted against as well.  sink: >= 1 float. */
+int ts_bench_stream_read(const float* src, int64_t n_floats, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

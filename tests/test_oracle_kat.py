@@ -224,3 +224,13 @@ def test_gradcheck_float64():
 
     ins = [t.requires_grad_(True) for t in (means, scales, quats, coeffs, opac)]
     assert torch.autograd.gradcheck(f, ins, eps=1e-6, atol=1e-5, rtol=1e-4, nondet_tol=0.0)
+
+
+def test_baseline_config1_cpu_forward():
+    """BASELINE.json configs[0]: 10k random Gaussians, SH degree 0, 256x256, CPU forward (plumbing)."""
+    model, cam = scene_args(10_000, 0, 256, 256, seed=0)
+    with torch.no_grad():
+        f = oracle_frame(model, cam, (256, 256), depth=False)
+    assert f["rgb"].shape == (256, 256, 3) and torch.isfinite(f["rgb"]).all()
+    assert int(f["nth"].sum()) == 16389 and int((f["radii"] > 0).sum()) == 8723
+    assert 0.0 <= f["rgb"].min() and f["rgb"].max() <= 1.0

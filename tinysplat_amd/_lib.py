@@ -46,6 +46,7 @@ SIGNATURES = {
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_bench_stream_read": (c_int32, [_P, c_int64, _P, _P]),
     "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -321,6 +321,30 @@ __global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
     }
 }
 
+// Measurement utility (bench.py): streaming read of n16 16-byte words with a
+// grid-stride loop, 4 independent loads in flight per lane; the per-lane sums are folded into
+// sink[] so that the loads cannot be elided.  Gives the achievable HBM read bandwidth of this GPU.
+__global__ __launch_bounds__(kThreads) void stream_read_kernel(const float4* __restrict__ src,
+                                                               size_t n16, float* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+        c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w;
+        d.x += v3.x; d.y += v3.y; d.z += v3.z; d.w += v3.w;
+    }
+    for (; i < n16; i += stride) {
+        const float4 v0 = src[i];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    const float t = (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) +
+                    (d.x + d.y + d.z + d.w);
+    if (t == 123456.789f) sink[0] = t;          // practically never true: keeps the loads alive
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -486,6 +510,14 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
         default: TS_SHC_BWD(4); break;
     }
 #undef TS_SHC_BWD
+    return launch_status();
+}
+
+int ts_bench_stream_read(const float* src, int64_t n_floats, float* sink, void* stream) {
+    if (!src || !sink || n_floats < 4) return TS_E_BADARG;
+    const size_t n16 = (size_t)n_floats / 4;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(kThreads), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), n16, sink);
     return launch_status();
 }
 

@@ -1,0 +1,126 @@
+"""Size-independent properties at BASELINE.json's full configuration (config 3: 1 M Gaussians, SH 3,
+1920x1080), where the CPU oracle is too slow to run: sortedness and partition of the binning,
+idempotence / bit-reproducibility, linearity in the colours, the telescoping weight checksum
+(colour == 1 renders exactly the alpha image), consistency of the culling flags, and gradient
+finiteness.  All through the C ABI."""
+import pytest
+import torch
+
+from tinysplat_amd import ops
+from tinysplat_amd.rasterizer import project_args, raster_args, sh_args
+
+from helpers import scene_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N, W, H, SH = 1_000_000, 1920, 1080, 3
+
+
+@pytest.fixture(scope="module")
+def frame():
+    model, cam = scene_args(N, SH, W, H, seed=0)
+    md = model.to(DEV)
+    with torch.no_grad():
+        proj = ops.project_gaussians(*project_args(md, cam, (W, H), DEV))
+        col = torch.clamp(ops.spherical_harmonics(*sh_args(md, cam, DEV)) + 0.5, min=0.0)
+    return md, cam, proj, col
+
+
+def test_projection_flags_consistent(frame):
+    md, cam, (xys, depths, radii, conics, nth, cov3d), col = frame
+    culled = radii == 0
+    assert torch.equal(culled, nth == 0)
+    assert torch.all(xys[culled] == 0) and torch.all(conics[culled] == 0) and torch.all(depths[culled] == 0)
+    assert torch.all(depths[~culled] > 0.01)
+    live = ~culled
+    assert torch.all(conics[live, 0] > 0) and torch.all(conics[live, 2] > 0)
+    assert torch.all(conics[live, 0] * conics[live, 2] > conics[live, 1] ** 2)        # positive definite
+    assert torch.all(nth <= 120 * 68) and 0.8 < live.float().mean() < 0.9
+
+
+def test_binning_sorted_and_partitioned(frame):
+    md, cam, (xys, depths, radii, conics, nth, _), col = frame
+    b = ops.bin_gaussians(xys, depths, radii, nth, H, W, use_cache=False)
+    I = b.num_intersects
+    assert I == int(nth.sum().item()) == int(b.cum_tiles_hit[-1].item())
+    bins, ids = b.tile_bins.long(), b.gaussian_ids_sorted.long()
+    cnt = bins[:, 1] - bins[:, 0]
+    nz = bins[cnt > 0]
+    assert nz[0, 0] == 0 and nz[-1, 1] == I and torch.all(nz[1:, 0] == nz[:-1, 1])     # partition of [0, I)
+    assert ids.min() >= 0 and ids.max() < N and torch.all(radii[ids] > 0)
+    # every list ascending in (depth bits, id): compare neighbours inside a tile
+    key_d = depths[ids].view(torch.int32).long()
+    same_tile = torch.ones(I - 1, dtype=torch.bool, device=DEV)
+    same_tile[(nz[1:, 0] - 1)] = False                                                # tile boundaries
+    d_ok = key_d[1:] > key_d[:-1]
+    tie_ok = (key_d[1:] == key_d[:-1]) & (ids[1:] > ids[:-1])
+    assert torch.all(d_ok | tie_ok | ~same_tile)
+    # each Gaussian appears exactly num_tiles_hit times
+    assert torch.equal(torch.bincount(ids, minlength=N), nth.long())
+    # tile membership: the tile of every entry lies inside the Gaussian's tile rectangle
+    tile_of = torch.repeat_interleave(torch.arange(bins.shape[0], device=DEV), cnt)
+    tx, ty = tile_of % 120, tile_of // 120
+    cx, cy, r = xys[ids, 0] / 16, xys[ids, 1] / 16, radii[ids].float() / 16
+    assert torch.all((tx >= torch.trunc(cx - r).clamp(0, 120)) & (tx < torch.trunc(cx + r + 1).clamp(0, 120)))
+    assert torch.all((ty >= torch.trunc(cy - r).clamp(0, 68)) & (ty < torch.trunc(cy + r + 1).clamp(0, 68)))
+
+
+def _render(md, proj, col, bg, grad=False):
+    xys, depths, radii, conics, nth, _ = proj
+    ra = raster_args(md, xys, depths, radii, conics, nth, col, (W, H))
+    ra[9] = bg
+    if grad:
+        for i in (0, 3, 5, 6):
+            ra[i] = ra[i].detach().clone().requires_grad_(True)
+    img, alpha = ops.rasterize_gaussians(*ra)
+    return img, alpha, ra
+
+
+def test_idempotent_and_bit_reproducible(frame):
+    md, cam, proj, col = frame
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    g = torch.Generator().manual_seed(0)
+    w = torch.rand(H, W, 3, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        ops.clear_binning_cache()
+        img, alpha, ra = _render(md, proj, col, bg, grad=True)
+        (img * w).sum().backward()
+        outs.append((img.detach(), alpha.detach(), [ra[i].grad for i in (0, 3, 5, 6)]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert outs[0][2][0].abs().max() > 0
+
+
+def test_linearity_in_colours_and_weight_checksum(frame):
+    md, cam, proj, col = frame
+    zero = torch.zeros(3, device=DEV)
+    c1 = col
+    c2 = torch.rand_like(col)
+    i1, a1, _ = _render(md, proj, c1, zero)
+    i2, _, _ = _render(md, proj, c2, zero)
+    i12, _, _ = _render(md, proj, c1 + 2.0 * c2, zero)
+    assert (i12 - (i1 + 2.0 * i2)).abs().max() < 2e-5          # the compositing weights do not depend on colour
+    ones, a_one, _ = _render(md, proj, torch.ones_like(col), zero)
+    # weights telescope: sum_i alpha_i T_i == 1 - T_final, so colour == 1 renders the alpha image
+    assert (ones[:, :, 0] - a_one).abs().max() < 2e-6
+    assert torch.equal(a1, a_one)
+    assert (a_one >= 0).all() and (a_one <= 1 - 1e-4 + 1e-6).all()
+    # background enters as T_final * bg
+    bg = torch.tensor([0.25, 0.5, 0.75], device=DEV)
+    ib, ab, _ = _render(md, proj, c1, bg)
+    assert (ib - (i1 + (1 - ab)[..., None] * bg)).abs().max() < 1e-6
+
+
+def test_gradient_of_colours_is_the_weight_image(frame):
+    """d(sum of out_img channel 0)/d colours[:,0] = per-Gaussian total weight >= 0, and the weights
+    summed over Gaussians equal the summed alpha image (another telescoping checksum)."""
+    md, cam, proj, col = frame
+    zero = torch.zeros(3, device=DEV)
+    img, alpha, ra = _render(md, proj, col, zero, grad=True)
+    img[:, :, 0].sum().backward()
+    wgt = ra[5].grad[:, 0]
+    assert (wgt >= 0).all() and torch.all(ra[5].grad[:, 1:] == 0)
+    tot, ref = wgt.double().sum().item(), alpha.double().sum().item()
+    assert abs(tot - ref) / ref < 1e-5

@@ -333,27 +333,26 @@ __device__ __forceinline__ void sort_tile_regs(const int* __restrict__ g,
     if (npad > NPAD) npad = NPAD;
     for (int kk = 2; kk <= npad; kk <<= 1) {
         for (int j = kk >> 1; j >= E && j >= 1; j >>= 1) {
+            // for j >= E the direction bit (i & kk) and the side bit (i & j) depend on t only
+            const bool asc = ((t * E) & kk) == 0;
             if (j >= 64 * E) {                       // partner in another wave
 #pragma unroll
                 for (int e = 0; e < E; ++e) lds[t * E + e] = k[e];
                 __syncthreads();
+                const bool keep_min = (((t * E) & j) == 0) == asc;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const int i = t * E + e;
-                    const unsigned long long o = lds[i ^ j];
-                    const bool keep_min = ((i & j) == 0) == ((i & kk) == 0);
-                    k[e] = keep_min ? (k[e] < o ? k[e] : o) : (k[e] > o ? k[e] : o);
+                    const unsigned long long o = lds[(t * E + e) ^ j];
+                    k[e] = ((o < k[e]) == keep_min) ? o : k[e];       // keys are unique: no ties
                 }
                 __syncthreads();
             } else {                                 // partner lane = lane ^ (j / E), same register
                 const int m = j / E;
-                const bool lower = (lane & m) == 0;
+                const bool keep_min = ((lane & m) == 0) == asc;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const int i = t * E + e;
                     const unsigned long long o = __shfl_xor(k[e], m, 64);
-                    const bool keep_min = lower == ((i & kk) == 0);
-                    k[e] = keep_min ? (k[e] < o ? k[e] : o) : (k[e] > o ? k[e] : o);
+                    k[e] = ((o < k[e]) == keep_min) ? o : k[e];
                 }
             }
         }

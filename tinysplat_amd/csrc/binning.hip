@@ -112,10 +112,15 @@ __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restri
 // memory traffic), the B x T count matrix is column-scanned into per-(chunk,tile) bases, and the
 // scatter pass replays the chunk with LDS cursors preloaded from those bases.  The order inside a
 // bucket is arbitrary (LDS atomic order); sort_tiles makes it canonical.
+// Block (b, w) replays chunk b and touches the tiles of window w.  Measured on config 3 / config 5:
+// one window per chunk (as long as the tile count fits the LDS) with 4096-Gaussian chunks is the
+// fastest split - larger chunks with several tile windows make the runs written into a bucket
+// longer but re-read every Gaussian once per window and lost 10-30 %.
 constexpr int kBinThreads = 512;
 constexpr int kBinChunkMin = 4096;        // Gaussians per chunk (at least)
 constexpr int kBinMaxChunks = 512;
-constexpr int kBinWindow = 36864;         // tiles per LDS window (144 KiB of the 160 KiB LDS)
+constexpr int kBinWindowMax = 36864;      // tiles per LDS window (144 KiB of the 160 KiB LDS)
+constexpr int kBinTargetBlocks = 1;       // chunks x windows aimed at (1 = no extra windows)
 
 __host__ __device__ inline int bin_num_chunks(int n) {
     int b = (n + kBinChunkMin - 1) / kBinChunkMin;
@@ -124,13 +129,26 @@ __host__ __device__ inline int bin_num_chunks(int n) {
     return b;
 }
 
+// tiles per window: enough windows to reach kBinTargetBlocks workgroups, never above the LDS budget
+inline int bin_window_tiles(int n, int num_tiles) {
+    const int chunks = bin_num_chunks(n);
+    int nwin = (kBinTargetBlocks + chunks - 1) / chunks;
+    const int max_win = (num_tiles + 255) / 256;           // keep windows >= 256 tiles
+    if (nwin > max_win) nwin = max_win;
+    if (nwin < 1) nwin = 1;
+    int window = (num_tiles + nwin - 1) / nwin;
+    window = (window + 63) & ~63;
+    if (window > kBinWindowMax) window = kBinWindowMax;
+    return window;
+}
+
 // grid = (chunks, windows); counts[b * T + t]
 __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
-    const ts_camera cam, int num_tiles, int* __restrict__ counts) {
+    const ts_camera cam, int num_tiles, int window, int* __restrict__ counts) {
     extern __shared__ int hist[];
-    const int t0 = blockIdx.y * kBinWindow;
-    const int tw = min(num_tiles - t0, kBinWindow);
+    const int t0 = blockIdx.y * window;
+    const int tw = min(num_tiles - t0, window);
     for (int j = threadIdx.x; j < tw; j += kBinThreads) hist[j] = 0;
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
@@ -243,12 +261,12 @@ __global__ __launch_bounds__(kThreads) void column_finish_kernel(int num_tiles, 
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
     int n, int chunk, const float* __restrict__ xys,
-    const int* __restrict__ radii, const ts_camera cam, int num_tiles,
+    const int* __restrict__ radii, const ts_camera cam, int num_tiles, int window,
     const int* __restrict__ bases, const int* __restrict__ tile_start,
     int* __restrict__ bucket_ids) {
     extern __shared__ int cursor[];
-    const int t0 = blockIdx.y * kBinWindow;
-    const int tw = min(num_tiles - t0, kBinWindow);
+    const int t0 = blockIdx.y * window;
+    const int tw = min(num_tiles - t0, window);
     const int* src = bases + (size_t)blockIdx.x * num_tiles + t0;
     for (int j = threadIdx.x; j < tw; j += kBinThreads) cursor[j] = tile_start[t0 + j] + src[j];
     __syncthreads();
@@ -471,9 +489,7 @@ int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
     return (int64_t)(bin_num_chunks(n) + 1 + kScanGroups) * num_tiles + 1;
 }
 
-static size_t bin_lds_bytes(int num_tiles) {
-    return (size_t)(num_tiles < kBinWindow ? num_tiles : kBinWindow) * sizeof(int);
-}
+
 
 int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
                  int32_t* bin_ws, void* stream) {
@@ -483,13 +499,14 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_cam
     if (n > 0 && (!xys || !radii)) return TS_E_BADARG;
     const int chunks = bin_num_chunks(n);
     const int chunk = n > 0 ? (n + chunks - 1) / chunks : 1;
-    const int windows = (nt + kBinWindow - 1) / kBinWindow;
-    const size_t lds = bin_lds_bytes(nt);
+    const int window = bin_window_tiles(n, nt);
+    const int windows = (nt + window - 1) / window;
+    const size_t lds = (size_t)window * sizeof(int);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_count_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_count_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
-                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, bin_ws);
+                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, window, bin_ws);
     return launch_status();
 }
 
@@ -525,13 +542,14 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_c
     if (nt <= 0) return 0;
     const int chunks = bin_num_chunks(n);
     const int chunk = (n + chunks - 1) / chunks;
-    const int windows = (nt + kBinWindow - 1) / kBinWindow;
-    const size_t lds = bin_lds_bytes(nt);
+    const int window = bin_window_tiles(n, nt);
+    const int windows = (nt + window - 1) / window;
+    const size_t lds = (size_t)window * sizeof(int);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_scatter_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
-                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, bin_ws,
+                       (hipStream_t)stream, n, chunk, xys, radii, *cam, nt, window, bin_ws,
                        bin_ws + (size_t)chunks * nt, bucket_ids);
     return launch_status();
 }

@@ -234,15 +234,27 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
         const size_t row = 3 * (size_t)(num_bases - 1);
         const float* src = rest + (size_t)g0 * row;
         if (num_bases == KA && cnt == kThreads && ((kThreads * RS) & 3) == 0) {
+            // all 16-byte loads of the span are issued before the first LDS write, so every lane
+            // has its ~RS/4 requests in flight at once (the kernel is a pure HBM stream)
             const float4* src4 = reinterpret_cast<const float4*>(src);
             constexpr int total4 = kThreads * RS / 4;
-            for (int f4 = tid; f4 < total4; f4 += kThreads) {
-                const float4 v = src4[f4];
-                const float e[4] = {v.x, v.y, v.z, v.w};
+            constexpr int per = (total4 + kThreads - 1) / kThreads;
+            float4 v[per > 0 ? per : 1];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ff = 4 * f4 + u;
-                    lds[(ff / RS) * RSP + (ff % RS)] = e[u];
+            for (int u = 0; u < per; ++u) {
+                const int f4 = tid + u * kThreads;
+                v[u] = f4 < total4 ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < per; ++u) {
+                const int f4 = tid + u * kThreads;
+                if (f4 < total4) {
+                    const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int ff = 4 * f4 + c;
+                        lds[(ff / RS) * RSP + (ff % RS)] = e[c];
+                    }
                 }
             }
         } else {

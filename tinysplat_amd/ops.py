@@ -455,10 +455,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         v_out_img = _f32c(v_out_img)
         v_out_alpha = None if v_out_alpha is None else _f32c(v_out_alpha)
         total = b.num_intersects
-        v_xy = torch.empty((n, 2), **f32)
-        v_conic = torch.empty((n, 3), **f32)
-        v_colors = torch.empty((n, ch), **f32)
-        v_opacity = torch.empty((n,), **f32)
+        # the four 2-D gradients are views of ONE allocation, in this order, so that the multi-GPU
+        # path can all-reduce them in place as a single buffer (sharding._SumGradsAcrossRanks)
+        flat = torch.empty((n * (6 + ch),), **f32)
+        v_xy = flat[:2 * n].view(n, 2)
+        v_conic = flat[2 * n:5 * n].view(n, 3)
+        v_colors = flat[5 * n:(5 + ch) * n].view(n, ch)
+        v_opacity = flat[(5 + ch) * n:]
         partials = torch.empty((max(total, 1), 12), **f32)
         row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
         lib = _lib.load()

@@ -28,6 +28,19 @@ def stripe_rows(tile_rows_total: int, world_size: int, rank: int) -> Tuple[int, 
     return r0, r0 + q + (1 if rank < r else 0)
 
 
+def _shared_flat_base(tensors):
+    """The common 1-D base tensor if `tensors` are contiguous views that tile it exactly, in order."""
+    base = getattr(tensors[0], "_base", None)
+    if base is None or base.dim() != 1 or not base.is_contiguous():
+        return None
+    off = base.storage_offset()
+    for t in tensors:
+        if getattr(t, "_base", None) is not base or not t.is_contiguous() or t.storage_offset() != off:
+            return None
+        off += t.numel()
+    return base if off == base.storage_offset() + base.numel() else None
+
+
 class _SumGradsAcrossRanks(torch.autograd.Function):
     """Identity in forward; in backward packs the incoming gradients into one flat buffer, sums it
     over the process group with a single all-reduce, and unpacks."""
@@ -41,6 +54,10 @@ class _SumGradsAcrossRanks(torch.autograd.Function):
     def backward(ctx, *grads):
         live = [g for g in grads if g is not None]
         if not live:
+            return (None,) + grads
+        base = _shared_flat_base(live)
+        if base is not None:          # already one contiguous buffer (ops._RasterizeGaussians.backward)
+            dist.all_reduce(base, op=dist.ReduceOp.SUM, group=ctx.group)
             return (None,) + grads
         flat = torch.cat([g.reshape(-1) for g in live])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)

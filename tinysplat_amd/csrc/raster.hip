@@ -15,8 +15,17 @@
 //     are unchanged).  Gaussians that can reach a still-unfinished block are compacted into LDS
 //     with a wave ballot + prefix count, carrying a 4-bit block mask; the inner loop reads each
 //     survivor back with wave-uniform (broadcast) ds_read_b128s and runs the per-pixel math only
-//     for the blocks in its mask (scalar branches).  Finished blocks (all 64 pixels saturated)
-//     drop out of the mask, so dense scenes stop early block by block.
+//     for the blocks in its mask (scalar branches).  The rectangle a Gaussian is tested against is
+//     not the whole block but the bounding box of the block's pixels that still matter (forward:
+//     not yet saturated; backward: list already started), recomputed per chunk from a ballot with
+//     scalar bit arithmetic, so dense scenes shed work pixel row by pixel row and stop early.
+//   * Per-pixel bodies are branch free inside a block and lean: log2(opacity) is folded into the
+//     exponent, the compositing weight is T_old - T_new (telescoping), a finished pixel is marked
+//     by the sign of T, and Gaussians that need the sigma >= 0 / 0.999-clamp tests are flagged at
+//     staging so that the common chunk runs a loop without them.  Both kernels are VALU-issue
+//     bound (~4 cycles per wave64 VALU op), so instruction count is what sets their time; this
+//     file is built with -fno-slp-vectorize because the SLP packer's register shuffles cost more
+//     issue slots than its v_pk_* ops save.
 //   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
 //     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
 //     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot

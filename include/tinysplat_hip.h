@@ -175,6 +175,31 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
                        float* v_colors, float* v_opacity, void* stream);
 
+/* ============ training-step ops around the path (scripts/train.py:58-63,97) ===== */
+
+/* Photometric loss of the training step and its gradient w.r.t. the rendered image:
+ *   L = c_l1 * mean|X - Y| + c_ssim * (1 - SSIM(X, Y))     (train.py:58-63 with c = 1-lambda, lambda)
+ * X = image[H,W,3], Y = target[H,W,3], HWC float32.  SSIM as pytorch_msssim.SSIM(data_range=1,
+ * size_average=True, channel=3) (model_gaussian.py:57): 11-tap Gaussian window (sigma 1.5), valid
+ * filtering, K = (0.01, 0.03).  The entry writes per-block partial sums to the tail of `ws`
+ * (2 floats per 32x32 tile: SSIM-map sum, |X-Y| sum) and, if v_image != NULL,
+ *   v_image = w_l1 * sign(X - Y) + w_ssim * dSSIMsum/dX      (caller passes w_l1 = c_l1 / (3 H W),
+ *                                                             w_ssim = -c_ssim / (3 (H-10)(W-10))).
+ * ws: >= ts_photometric_ws_floats(H, W) floats; the partial sums start at ws + 9 (H-10)(W-10). */
+int64_t ts_photometric_ws_floats(int32_t height, int32_t width);
+int ts_photometric_loss(int32_t height, int32_t width, const float* image, const float* target,
+                        float w_l1, float w_ssim, float* ws, float* v_image, void* stream);
+
+/* torch.optim.Adam (defaults: no amsgrad, no weight decay; train.py:26) on up to TS_ADAM_MAX_TENSORS
+ * tensors with per-tensor learning rates (model_gaussian.py:112-120) in one launch.  The pointer
+ * tables are HOST arrays of device pointers.  steps_host[i] >= 1 is tensor i's own 1-based step count
+ * (torch keeps it per parameter: a tensor without a gradient is skipped and does not age). */
+#define TS_ADAM_MAX_TENSORS 8
+int ts_adam_step(int32_t num_tensors, float* const* params_host, const float* const* grads_host,
+                 float* const* exp_avg_host, float* const* exp_avg_sq_host, const int64_t* numel_host,
+                 const float* lr_host, const int32_t* steps_host, float beta1, float beta2, float eps,
+                 void* stream);
+
 /* ======================================= measurement utility ================================== */
 /* Streaming read of n_floats float32 (16-byte loads, grid-stride): the read-bandwidth microbenchmark
  * that SURVEY.md 8(d) D1 asks the roofline to be quoted against as well.  sink: >= 1 float. */

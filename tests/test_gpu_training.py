@@ -1,0 +1,76 @@
+"""Training-step ops through the C ABI: photometric loss + gradient against
+autograd of the oracle restatement, Adam against torch.optim.Adam itself, and a short optimisation
+run that must reduce the loss."""
+import pytest
+import torch
+
+from oracle import train_oracle as TO
+from tinysplat_amd.training import Adam, TrainStep, photometric_loss
+from tinysplat_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("h,w,lam", [(64, 96, 0.2), (77, 131, 0.5), (200, 333, 0.0), (40, 40, 1.0)])
+def test_photometric_loss_and_gradient(h, w, lam):
+    g = torch.Generator().manual_seed(h * w)
+    img = torch.rand(h, w, 3, generator=g)
+    tgt = (img + 0.2 * torch.randn(h, w, 3, generator=g)).clamp(0, 1)
+    x64 = img.double().requires_grad_(True)
+    ref, ref_l1, ref_s = TO.photometric_loss(x64, tgt.double(), lam)
+    ref.backward()
+    xd = img.to(DEV).requires_grad_(True)
+    loss, l1, s = photometric_loss(xd, tgt.to(DEV), lam)
+    (3.0 * loss).backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 and abs(l1.item() - ref_l1.item()) < 2e-6
+    assert abs(s.item() - ref_s.item()) < 2e-6
+    err = (xd.grad.cpu().double() / 3.0 - x64.grad).abs().max().item()
+    assert err < 1e-5 * max(1.0, x64.grad.abs().max().item() * 1e3), err
+    assert err < 2e-8 + 1e-4 * x64.grad.abs().max().item()
+
+
+def test_ssim_of_identical_images_is_one():
+    img = torch.rand(50, 70, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    loss, l1, s = photometric_loss(img, img.clone(), 0.2)
+    assert abs(s.item() - 1.0) < 1e-6 and l1.item() == 0.0 and abs(loss.item()) < 1e-6
+
+
+def test_adam_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    shapes = {"means": (1001, 3), "colors_dc": (1001, 3), "colors_rest": (1001, 15, 3),
+              "scales": (1001, 3), "quats": (1001, 4), "opacities": (1001, 1)}
+    lrs = {"means": 0.00016, "colors_dc": 0.0025, "colors_rest": 0.000125, "scales": 0.005,
+           "quats": 0.001, "opacities": 0.05}
+    mine = {n: torch.randn(s, generator=g).to(DEV).requires_grad_(True) for n, s in shapes.items()}
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in mine.items()}
+    opt = Adam(mine, lrs)
+    topt = torch.optim.Adam([{"params": [ref[n]], "lr": lrs[n]} for n in shapes])
+    for step in range(5):
+        for n in shapes:
+            gr = torch.randn(shapes[n], generator=g).to(DEV) * (10.0 ** (step - 2))
+            mine[n].grad = gr.clone()
+            ref[n].grad = gr.clone()
+        if step == 3:
+            mine["quats"].grad = None
+            ref["quats"].grad = None          # a tensor without gradient is skipped, as in torch
+        opt.step()
+        topt.step()
+    for n in shapes:
+        assert torch.allclose(mine[n], ref[n], rtol=2e-6, atol=2e-7), n
+
+
+def test_train_step_reduces_the_loss():
+    w, h, n = 160, 112, 4000
+    target_model, cam = make_scene(n, 1, w, h, seed=5, scale_mult=4.0)
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    with torch.no_grad():
+        tgt, extras = GaussianRasterizer(target_model.to(DEV), None, device=torch.device(DEV))(cam, None, 1)
+    model = target_model.to(DEV)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    model.colors_dc = (model.colors_dc + 0.5 * torch.randn(n, 3, generator=gen).to(DEV))
+    model.means = model.means + 0.02 * torch.randn(n, 3, generator=gen).to(DEV)
+    step = TrainStep(model, DEV)
+    losses = [step(cam, tgt, extras["depth"])["loss"].item() for _ in range(30)]
+    assert losses[-1] < 0.7 * losses[0], losses[::5]
+    assert all(torch.isfinite(p).all() for p in model.parameters())

@@ -18,6 +18,7 @@ SOURCES = [
     # it with register shuffles (v_mov) that cost more VALU issue slots than the packing saves
     # (measured: raster_bwd 0.87 -> 0.67 ms with it off)
     ("raster.hip", ["-fno-slp-vectorize"]),
+    ("train.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

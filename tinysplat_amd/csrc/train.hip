@@ -1,0 +1,302 @@
+// train.hip - the two ops that sit directly around the render path in tinysplat's training step
+// (/root/reference/scripts/train.py:58-63, :97):
+//
+//   * photometric loss  (1 - lambda) * L1 + lambda * (1 - SSIM)  and its gradient w.r.t. the rendered
+//     image.  SSIM follows pytorch_msssim.SSIM(data_range=1, size_average=True, channel=3) as
+//     constructed at tinysplat/splatting/model_gaussian.py:57: 11-tap Gaussian window (sigma 1.5),
+//     separable "valid" filtering, K = (0.01, 0.03), mean over the (H-10) x (W-10) x 3 map.
+//     Images are HWC float32 exactly as the rasterizer writes them (no permute / unsqueeze copy).
+//   * Adam update of the six parameter tensors (torch.optim.Adam defaults, train.py:26) in ONE
+//     launch over a table of tensors with per-tensor learning rates (model_gaussian.py:112-120).
+//
+// Both are HBM-bound streaming kernels; the SSIM kernels stage a (32+10) x (32+10) pixel patch in
+// LDS and run the two 11-tap passes from there, so each image byte is read from HBM ~1.7x.
+#include <hip/hip_runtime.h>
+
+#include "../../include/tinysplat_hip.h"
+
+namespace {
+
+constexpr int kWin = 11, kHalo = kWin - 1;     // valid filtering: output is (H-10) x (W-10)
+constexpr int kTile = 32;                      // output tile edge
+constexpr int kPatch = kTile + kHalo;          // 42
+constexpr int kThreads = 256;
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ void gauss_window(float* g) {
+    // exp(-(i-5)^2 / (2 * 1.5^2)), normalised (pytorch_msssim._fspecial_gauss_1d(11, 1.5))
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kWin; ++i) {
+        const float d = (float)(i - kWin / 2);
+        g[i] = expf(-(d * d) / (2.0f * 1.5f * 1.5f));
+        s += g[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kWin; ++i) g[i] /= s;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    const float t = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return t;
+}
+
+// Pass 1: per 32x32 tile of the SSIM map: the five filtered maps, the SSIM value (summed per block
+// into sums[block*2+0]) and the three partial-derivative maps dS/d filt(X), dS/d filt(X^2),
+// dS/d filt(XY) written to dmaps[3][Ho][Wo][3].  Also the L1 sum of the tile's own 32x32 pixels
+// (image tiles of the same grid cover the whole image; sums[block*2+1]).
+__global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, const float* __restrict__ X,
+                                                            const float* __restrict__ Y,
+                                                            float* __restrict__ dmaps,
+                                                            float* __restrict__ sums) {
+    __shared__ float px[kPatch][kPatch + 1], py[kPatch][kPatch + 1];
+    __shared__ float h0[kPatch][kTile + 1], h1[kPatch][kTile + 1], h2[kPatch][kTile + 1],
+        h3[kPatch][kTile + 1], h4[kPatch][kTile + 1];
+    __shared__ float scratch[4];
+    float g[kWin];
+    gauss_window(g);
+    const int Ho = H - kHalo, Wo = W - kHalo;
+    const int ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
+    float ssim_sum = 0.0f, l1_sum = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        for (int i = threadIdx.x; i < kPatch * kPatch; i += kThreads) {
+            const int r = i / kPatch, q = i % kPatch;
+            const int y = oy0 + r, x = ox0 + q;
+            float a = 0.0f, b = 0.0f;
+            if (y < H && x < W) {
+                a = X[((size_t)y * W + x) * 3 + c];
+                b = Y[((size_t)y * W + x) * 3 + c];
+                if (r < kTile && q < kTile) l1_sum += fabsf(a - b);
+            }
+            px[r][q] = a; py[r][q] = b;
+        }
+        __syncthreads();
+        // horizontal pass: 42 rows x 32 columns, five quantities
+        for (int i = threadIdx.x; i < kPatch * kTile; i += kThreads) {
+            const int r = i / kTile, q = i % kTile;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float a = px[r][q + k], b = py[r][q + k], w = g[k];
+                s0 += w * a; s1 += w * b; s2 += w * a * a; s3 += w * b * b; s4 += w * a * b;
+            }
+            h0[r][q] = s0; h1[r][q] = s1; h2[r][q] = s2; h3[r][q] = s3; h4[r][q] = s4;
+        }
+        __syncthreads();
+        // vertical pass + SSIM
+        for (int i = threadIdx.x; i < kTile * kTile; i += kThreads) {
+            const int r = i / kTile, q = i % kTile;
+            const int y = oy0 + r, x = ox0 + q;
+            if (y >= Ho || x >= Wo) continue;
+            float m1 = 0.f, m2 = 0.f, q1 = 0.f, q2 = 0.f, r12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float w = g[k];
+                m1 += w * h0[r + k][q]; m2 += w * h1[r + k][q]; q1 += w * h2[r + k][q];
+                q2 += w * h3[r + k][q]; r12 += w * h4[r + k][q];
+            }
+            const float s1 = q1 - m1 * m1, s2 = q2 - m2 * m2, s12 = r12 - m1 * m2;
+            const float A1 = 2.0f * m1 * m2 + kC1, A2 = 2.0f * s12 + kC2;
+            const float B1 = m1 * m1 + m2 * m2 + kC1, B2 = s1 + s2 + kC2;
+            const float inv = 1.0f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            ssim_sum += S;
+            const size_t o = ((size_t)y * Wo + x) * 3 + c;
+            const size_t plane = (size_t)Ho * Wo * 3;
+            dmaps[o] = 2.0f * m2 * (A2 - A1) * inv - 2.0f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/d filt(X)
+            dmaps[plane + o] = -S / B2;                                                        // d/d filt(X^2)
+            dmaps[2 * plane + o] = 2.0f * A1 * inv;                                            // d/d filt(XY)
+        }
+        __syncthreads();
+    }
+    const float ts = block_sum(ssim_sum, scratch);
+    const float tl = block_sum(l1_sum, scratch);
+    if (threadIdx.x == 0) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        sums[2 * b] = ts;
+        sums[2 * b + 1] = tl;
+    }
+}
+
+// Pass 2: gradient w.r.t. X.  The transpose of the valid filter is a full correlation of the three
+// partial maps (zero outside the (Ho, Wo) map):  gX = F^T dm + 2 X F^T dq + Y F^T dr, scaled by
+// w_ssim, plus w_l1 * sign(X - Y).
+__global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, const float* __restrict__ X,
+                                                            const float* __restrict__ Y,
+                                                            const float* __restrict__ dmaps,
+                                                            float w_l1, float w_ssim,
+                                                            float* __restrict__ gX) {
+    __shared__ float p0[kPatch][kPatch + 1], p1[kPatch][kPatch + 1], p2[kPatch][kPatch + 1];
+    __shared__ float h0[kPatch][kTile + 1], h1[kPatch][kTile + 1], h2[kPatch][kTile + 1];
+    float g[kWin];
+    gauss_window(g);
+    const int Ho = H - kHalo, Wo = W - kHalo;
+    const size_t plane = (size_t)Ho * Wo * 3;
+    const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;     // image tile
+    for (int c = 0; c < 3; ++c) {
+        // map patch needed: rows y0-10 .. y0+31, cols x0-10 .. x0+31
+        for (int i = threadIdx.x; i < kPatch * kPatch; i += kThreads) {
+            const int r = i / kPatch, q = i % kPatch;
+            const int y = y0 - kHalo + r, x = x0 - kHalo + q;
+            float a = 0.f, b = 0.f, d = 0.f;
+            if (y >= 0 && y < Ho && x >= 0 && x < Wo) {
+                const size_t o = ((size_t)y * Wo + x) * 3 + c;
+                a = dmaps[o]; b = dmaps[plane + o]; d = dmaps[2 * plane + o];
+            }
+            p0[r][q] = a; p1[r][q] = b; p2[r][q] = d;
+        }
+        __syncthreads();
+        // pixel (y, x) receives from map locations (y - k, x - l): flipped window == same (symmetric)
+        for (int i = threadIdx.x; i < kPatch * kTile; i += kThreads) {
+            const int r = i / kTile, q = i % kTile;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float w = g[k];
+                s0 += w * p0[r][q + k]; s1 += w * p1[r][q + k]; s2 += w * p2[r][q + k];
+            }
+            h0[r][q] = s0; h1[r][q] = s1; h2[r][q] = s2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kTile * kTile; i += kThreads) {
+            const int r = i / kTile, q = i % kTile;
+            const int y = y0 + r, x = x0 + q;
+            if (y >= H || x >= W) continue;
+            float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float w = g[k];
+                a += w * h0[r + k][q]; b += w * h1[r + k][q]; d += w * h2[r + k][q];
+            }
+            const size_t o = ((size_t)y * W + x) * 3 + c;
+            const float xv = X[o], yv = Y[o];
+            const float diff = xv - yv;
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            gX[o] = w_l1 * sgn + w_ssim * (a + 2.0f * xv * b + yv * d);
+        }
+        __syncthreads();
+    }
+}
+
+struct AdamTable {
+    float* p[TS_ADAM_MAX_TENSORS];
+    const float* g[TS_ADAM_MAX_TENSORS];
+    float* m[TS_ADAM_MAX_TENSORS];
+    float* v[TS_ADAM_MAX_TENSORS];
+    long long n[TS_ADAM_MAX_TENSORS];
+    float step_size[TS_ADAM_MAX_TENSORS];     // lr / (1 - beta1^step)
+    float bc2_sqrt[TS_ADAM_MAX_TENSORS];      // sqrt(1 - beta2^step)
+    int count;
+};
+
+// grid.y = tensor index; 16-byte accesses when the element count allows (all six tinysplat tensors
+// have element counts divisible by 4 for N % 4 == 0; the tail is handled element-wise)
+__global__ __launch_bounds__(kThreads) void adam_kernel(const AdamTable t, float beta1, float beta2,
+                                                        float eps) {
+    const int ti = blockIdx.y;
+    const long long n = t.n[ti];
+    float* __restrict__ p = t.p[ti];
+    const float* __restrict__ g = t.g[ti];
+    float* __restrict__ m = t.m[ti];
+    float* __restrict__ v = t.v[ti];
+    const float step = t.step_size[ti];
+    const float bc2_sqrt = t.bc2_sqrt[ti];
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            M[k] = beta1 * M[k] + (1.0f - beta1) * G[k];
+            V[k] = beta2 * V[k] + (1.0f - beta2) * G[k] * G[k];
+            P[k] -= step * (M[k] / (sqrtf(V[k]) / bc2_sqrt + eps));
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) {
+            const float gi = g[i];
+            const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+            const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            p[i] -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+    }
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t ts_photometric_ws_floats(int32_t height, int32_t width) {
+    if (height <= kHalo || width <= kHalo) return 0;
+    const int64_t ho = height - kHalo, wo = width - kHalo;
+    const int64_t tiles = (int64_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    return 3 * ho * wo * 3 + 2 * tiles;
+}
+
+int ts_photometric_loss(int32_t height, int32_t width, const float* image, const float* target,
+                        float w_l1, float w_ssim, float* ws, float* v_image, void* stream) {
+    if (height <= kHalo || width <= kHalo) return TS_E_BADARG;
+    if (!image || !target || !ws) return TS_E_BADARG;
+    const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);
+    const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, image, target, ws,
+                       ws + plane3);
+    if (v_image)
+        hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width, image, target,
+                           ws, w_l1, w_ssim, v_image);
+    return launch_status();
+}
+
+int ts_adam_step(int32_t num_tensors, float* const* params, const float* const* grads,
+                 float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                 const float* lr, const int32_t* steps, float beta1, float beta2, float eps,
+                 void* stream) {
+    if (num_tensors < 0 || num_tensors > TS_ADAM_MAX_TENSORS) return TS_E_BADARG;
+    if (num_tensors == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !steps) return TS_E_BADARG;
+    AdamTable t;
+    long long maxn = 0;
+    t.count = num_tensors;
+    for (int i = 0; i < TS_ADAM_MAX_TENSORS; ++i) {
+        const bool on = i < num_tensors;
+        t.p[i] = on ? params[i] : nullptr; t.g[i] = on ? grads[i] : nullptr;
+        t.m[i] = on ? exp_avg[i] : nullptr; t.v[i] = on ? exp_avg_sq[i] : nullptr;
+        t.n[i] = on ? numel[i] : 0;
+        t.step_size[i] = 0.0f; t.bc2_sqrt[i] = 1.0f;
+        if (!on) continue;
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0 || steps[i] < 1)
+            return TS_E_BADARG;
+        // double-precision bias corrections as torch.optim.Adam computes them on the host; the step
+        // count is per tensor because torch skips (and does not age) tensors without a gradient
+        const double b1p = __builtin_pow((double)beta1, (double)steps[i]);
+        const double b2p = __builtin_pow((double)beta2, (double)steps[i]);
+        t.step_size[i] = (float)((double)lr[i] / (1.0 - b1p));
+        t.bc2_sqrt[i] = (float)__builtin_sqrt(1.0 - b2p);
+        if (t.n[i] > maxn) maxn = t.n[i];
+    }
+    if (maxn == 0) return 0;
+    long long blocks = (maxn / 4 + kThreads - 1) / kThreads;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, num_tensors), dim3(kThreads), 0,
+                       (hipStream_t)stream, t, beta1, beta2, eps);
+    return launch_status();
+}
+
+}  // extern "C"

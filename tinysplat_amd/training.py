@@ -1,0 +1,136 @@
+"""Training step around the render path.
+
+Mirrors one iteration of /root/reference/scripts/train.py:45-106 without the dataset / viewer /
+densification policy: render -> (1 - lambda) L1 + lambda (1 - SSIM) (train.py:58-63), optional depth
+L1 (train.py:65-69), backward, Adam on the six parameter groups with the reference's learning rates
+(train.py:187-193, model_gaussian.py:112-120).  The photometric loss + its image gradient and the
+Adam update are HIP kernels behind the C ABI (csrc/train.hip); nothing here falls back to PyTorch
+math for them.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .ops import _call, _f32c, _need_hip, _ptr, _stream
+from .rasterizer import GaussianRasterizer
+
+# learning-rate defaults of scripts/train.py:187-193, in the order of SplatModel.parameters()
+DEFAULT_LRS = {"means": 0.00016, "colors_dc": 0.0025, "colors_rest": 0.000125, "scales": 0.005,
+               "quats": 0.001, "opacities": 0.05}
+PARAM_ORDER = ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities")
+
+
+class _PhotometricLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, target, lambda_dssim):
+        dev = _need_hip(image, target)
+        if image.dim() != 3 or image.shape[2] != 3 or image.shape != target.shape:
+            raise ValueError("image and target must both be [H, W, 3]")
+        h, w = image.shape[0], image.shape[1]
+        if h <= 10 or w <= 10:
+            raise ValueError("SSIM with an 11-tap window needs H, W > 10")
+        image, target = _f32c(image), _f32c(target)
+        lib = _lib.load()
+        ws = torch.empty((int(lib.ts_photometric_ws_floats(h, w)),), dtype=torch.float32, device=dev)
+        v_image = torch.empty_like(image) if ctx.needs_input_grad[0] else None
+        ho, wo = h - 10, w - 10
+        lam = float(lambda_dssim)
+        with torch.cuda.device(dev):
+            _call("ts_photometric_loss", lib.ts_photometric_loss, h, w, _ptr(image), _ptr(target),
+                  (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo), _ptr(ws), _ptr(v_image),
+                  _stream(dev))
+        sums = ws[9 * ho * wo:].view(-1, 2).sum(dim=0, dtype=torch.float64)
+        ssim = sums[0] / (3.0 * ho * wo)
+        l1 = sums[1] / (3.0 * h * w)
+        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim)).to(torch.float32)
+        ctx.save_for_backward(v_image)
+        ctx.mark_non_differentiable(l1, ssim)
+        return loss, l1.to(torch.float32), ssim.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, v_loss, _v_l1, _v_ssim):
+        (v_image,) = ctx.saved_tensors
+        return (None if v_image is None else v_image * v_loss), None, None
+
+
+def photometric_loss(image: Tensor, target: Tensor, lambda_dssim: float = 0.2):
+    """``(1 - lambda) * mean|image - target| + lambda * (1 - SSIM(image, target))`` on HWC images
+    (the loss of train.py:58-63).  Returns ``(loss, l1, ssim)``; differentiable w.r.t. ``image``."""
+    return _PhotometricLoss.apply(image, target, lambda_dssim)
+
+
+class Adam:
+    """torch.optim.Adam (defaults) over the six parameter tensors, one HIP launch per step."""
+
+    def __init__(self, params: Dict[str, Tensor], lrs: Optional[Dict[str, float]] = None,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        self.names = [n for n in PARAM_ORDER if n in params] + [n for n in params if n not in PARAM_ORDER]
+        if len(self.names) > 8:
+            raise ValueError("at most 8 tensors per Adam table")
+        self.params = {n: params[n] for n in self.names}
+        self.lrs = dict(DEFAULT_LRS)
+        if lrs:
+            self.lrs.update(lrs)
+        self.betas, self.eps = betas, eps
+        self.steps = {n: 0 for n in self.names}       # per tensor, as torch.optim.Adam's state['step']
+        self.exp_avg = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        self.exp_avg_sq = {n: torch.zeros_like(p) for n, p in self.params.items()}
+
+    @torch.no_grad()
+    def step(self) -> None:
+        names = [n for n in self.names if self.params[n].grad is not None]
+        if not names:
+            return
+        ps = [self.params[n] for n in names]
+        dev = _need_hip(*ps)
+        gs = [_f32c(self.params[n].grad) for n in names]
+        for p in ps:
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError("Adam parameters must be contiguous float32")
+        for n in names:
+            self.steps[n] += 1
+        k = len(names)
+        PtrArr, LArr, FArr = ctypes.c_void_p * k, ctypes.c_int64 * k, ctypes.c_float * k
+        IArr = ctypes.c_int32 * k
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _call("ts_adam_step", lib.ts_adam_step, k, PtrArr(*[p.data_ptr() for p in ps]),
+                  PtrArr(*[g.data_ptr() for g in gs]),
+                  PtrArr(*[self.exp_avg[n].data_ptr() for n in names]),
+                  PtrArr(*[self.exp_avg_sq[n].data_ptr() for n in names]),
+                  LArr(*[p.numel() for p in ps]), FArr(*[self.lrs.get(n, 1e-3) for n in names]),
+                  IArr(*[self.steps[n] for n in names]), self.betas[0], self.betas[1], self.eps,
+                  _stream(dev))
+
+    def zero_grad(self) -> None:
+        for p in self.params.values():
+            p.grad = None
+
+
+class TrainStep:
+    """render -> loss -> backward -> Adam, one call per iteration (train.py:45-106 minus policy)."""
+
+    def __init__(self, model, device, lambda_dssim: float = 0.2, lambda_depth: float = 0.2,
+                 lrs: Optional[Dict[str, float]] = None):
+        self.model, self.device = model, torch.device(device)
+        self.lambda_dssim, self.lambda_depth = lambda_dssim, lambda_depth
+        self.rasterizer = GaussianRasterizer(model, None, device=self.device)
+        model.requires_grad_(True)
+        self.optimizer = Adam({n: getattr(model, n) for n in PARAM_ORDER}, lrs)
+
+    def __call__(self, camera, target_rgb: Tensor, target_depth: Optional[Tensor] = None):
+        rgb, extras = self.rasterizer(camera, None, self.model.active_sh_degree)
+        loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
+        if target_depth is not None:                          # train.py:65-69
+            loss = loss + self.lambda_depth * (extras["depth"] - target_depth).abs().mean()
+        loss.backward()
+        self.optimizer.step()
+        xys_grad = extras["xys"].grad                          # consumed by densification (F2)
+        self.optimizer.zero_grad()
+        return {"loss": loss.detach(), "l1": l1, "ssim": ssim, "radii": extras["radii"],
+                "xys_grad": xys_grad}

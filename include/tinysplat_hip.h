@@ -134,9 +134,11 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_c
 
 /* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort
  * of (tile<<32 | depth-bits) keys emitted Gaussian-major - reading bucket_ids[I] and depths[n] and
- * writing gaussian_ids_sorted[I] (a different buffer). */
+ * writing gaussian_ids_sorted[I] (a different buffer).  sort_ws: >= num_tiles + 1 int32 of scratch
+ * (bin_ws may be passed: its contents are dead once ts_bin_scatter has run). */
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
-                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, void* stream);
+                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
+                  void* stream);
 
 #define TS_RASTER_LOGIT_OPACITY 1 /* `opacity` holds logits: sigmoid (rasterize.py:86) is applied while */
                                   /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */

@@ -90,10 +90,12 @@ def _binning_case(n, w, h, seed, mult):
 
 
 @pytest.mark.parametrize("n,w,h,seed,mult", [(20000, 256, 256, 0, 2.0), (30000, 640, 360, 1, 1.5),
-                                             (60000, 64, 48, 2, 12.0), (3, 40, 40, 3, 1.0)])
+                                             (60000, 64, 48, 2, 12.0), (3, 40, 40, 3, 1.0),
+                                             (200000, 64, 48, 4, 12.0), (40000, 128, 96, 5, 8.0)])
 def test_binning_bit_exact(n, w, h, seed, mult):
     """tile_bins and gaussian_ids_sorted equal the stable (tile, depth-bits) sort of the oracle.
-    The (60000, 64x48, x12) case puts > 4096 entries in single tiles -> global-memory sort path."""
+    Tile sizes span the register network (<= 1024 keys), the per-tile sample sort with 256 samples
+    (60000 / 40000 cases: ~1.5k-5k keys per tile) and with 1024 samples (200000 case: > 8192)."""
     _, _, f = _binning_case(n, w, h, seed, mult)
     xys, depths, radii, nth = f["xys"].detach(), f["depths"].detach(), f["radii"], f["nth"]
     tb = tile_bounds((w, h))
@@ -104,8 +106,27 @@ def test_binning_bit_exact(n, w, h, seed, mult):
     assert torch.equal(b.cum_tiles_hit.cpu(), cum)
     assert torch.equal(b.tile_bins.cpu(), bins)
     assert torch.equal(b.gaussian_ids_sorted.cpu(), ids)
-    if mult >= 12.0:
+    if n == 60000:
         assert (bins[:, 1] - bins[:, 0]).max() > 4096
+    if n == 200000:
+        assert (bins[:, 1] - bins[:, 0]).max() > 8192
+
+
+def test_binning_many_equal_depths():
+    """Thousands of Gaussians share a handful of depth values (a wall facing the camera): ordering
+    then rests on the id tie-break, and no sub-bucket of the sample sort may blow up."""
+    n, w, h = 50000, 96, 64
+    _, _, f = _binning_case(n, w, h, 6, 10.0)
+    xys, radii, nth = f["xys"].detach(), f["radii"], f["nth"]
+    g = torch.Generator().manual_seed(0)
+    depths = torch.tensor([2.0, 2.5, 2.5000002, 7.0])[torch.randint(0, 4, (n,), generator=g)]
+    depths = torch.where(radii > 0, depths, torch.zeros_like(depths))
+    tb = tile_bounds((w, h))
+    cum, keys, ids, bins = O.bin_and_sort(xys, depths, radii, nth, tb)
+    b = ops.bin_gaussians(xys.to(DEV), depths.to(DEV), radii.to(DEV), nth.to(DEV), h, w, use_cache=False)
+    assert (bins[:, 1] - bins[:, 0]).max() > 2048
+    assert torch.equal(b.tile_bins.cpu(), bins)
+    assert torch.equal(b.gaussian_ids_sorted.cpu(), ids)
 
 
 def test_binning_empty():

@@ -11,9 +11,11 @@
 //   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 4-byte id stores
 //                   (the sort gathers depth by id from the 4 N-byte, L2-resident depth array;
 //                   sort key = depth_bits << 32 | gaussian_id, unique inside a tile)
-//   sort_tiles      one workgroup per tile: bitonic network with the keys in registers (in-thread
-//                   stages), 64-bit lane exchanges (in-wave stages) and LDS only for the few
-//                   cross-wave stages; buckets > 4096 keys run a flip/disperse network in global memory
+//   sort_tiles      one workgroup per tile.  <= 1024 keys: bitonic network with the keys in registers
+//                   (in-thread stages), 64-bit lane exchanges (in-wave stages) and LDS only for the
+//                   few cross-wave stages.  Larger tiles: per-tile sample sort (splitters from a
+//                   sorted sample, LDS histogram + cursors, then every wave sorts sub-buckets of
+//                   <= 256 keys on its own) - O(n log n), no size limit
 //   pack_splats     gathers the compositing operands of a Gaussian into one 48-byte record
 // Traffic: 4 I written + 4 I read (+ gathers) + 4 I written (+ 8 B T for the count matrix) against the 36 I a 3-pass 64-bit
 // LSD radix sort of key+payload would move at minimum.
@@ -333,27 +335,19 @@ __device__ __forceinline__ void bitonic_network(Ptr a, int n) {
 // distance j are in the same thread (j < E: pure register work), in the same wave (E <= j < 64 E:
 // 64-bit lane exchange through the LDS crossbar, no barrier) or in another wave (j >= 64 E: one LDS
 // round trip with a barrier - at most 3 of the 55 stages of a 1024-key sort).
-template <int E>
-__device__ __forceinline__ void sort_tile_regs(const int* __restrict__ g,
-                                               const float* __restrict__ depths,
-                                               int* __restrict__ out, int n,
-                                               unsigned long long* lds) {
-    constexpr int NPAD = kThreads * E;
-    const int t = threadIdx.x, lane = t & 63;
-    unsigned long long k[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = t * E + e;
-        k[e] = i < n ? make_key(depths, g[i]) : ~0ull;
-    }
-    int npad = 2;
-    while (npad < n) npad <<= 1;                     // stages beyond npad only see +inf padding
-    if (npad > NPAD) npad = NPAD;
+// Bitonic network over GROUP threads (GROUP = 256: the workgroup, with LDS + barriers for the
+// cross-wave stages; GROUP = 64: one wave, shuffles only, no barrier).  Thread t of the group holds
+// the E consecutive keys t*E .. t*E+E-1; npad (a power of two <= GROUP*E) bounds the stages that can
+// see anything but +inf padding.
+template <int E, int GROUP>
+__device__ __forceinline__ void bitonic_regs(unsigned long long (&k)[E], int t, int npad,
+                                             unsigned long long* lds) {
+    const int lane = t & 63;
     for (int kk = 2; kk <= npad; kk <<= 1) {
         for (int j = kk >> 1; j >= E && j >= 1; j >>= 1) {
             // for j >= E the direction bit (i & kk) and the side bit (i & j) depend on t only
             const bool asc = ((t * E) & kk) == 0;
-            if (j >= 64 * E) {                       // partner in another wave
+            if (GROUP > 64 && j >= 64 * E) {         // partner in another wave
 #pragma unroll
                 for (int e = 0; e < E; ++e) lds[t * E + e] = k[e];
                 __syncthreads();
@@ -390,6 +384,30 @@ __device__ __forceinline__ void sort_tile_regs(const int* __restrict__ g,
             }
         }
     }
+}
+
+__device__ __forceinline__ int pow2_at_least(int n) {
+    int p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Register-resident bitonic sort of one bucket of ids by the whole workgroup (n <= 256 E): in-thread
+// stages are pure register work, in-wave stages 64-bit lane exchanges through the LDS crossbar, and
+// only partner distances >= 64 E (at most 3 of the 55 stages of a 1024-key sort) take an LDS round
+// trip with a barrier.  `g` and `out` may alias (everything is loaded before anything is stored).
+template <int E>
+__device__ __forceinline__ void sort_tile_regs(const int* g, const float* __restrict__ depths,
+                                               int* out, int n, unsigned long long* lds) {
+    const int t = threadIdx.x;
+    unsigned long long k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t * E + e;
+        k[e] = i < n ? make_key(depths, g[i]) : ~0ull;
+    }
+    __syncthreads();                                  // aliasing callers: all loads before any store
+    bitonic_regs<E, kThreads>(k, t, min(pow2_at_least(n), kThreads * E), lds);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = t * E + e;
@@ -397,28 +415,159 @@ __device__ __forceinline__ void sort_tile_regs(const int* __restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(kThreads) void sort_tiles_kernel(
+__device__ __forceinline__ void sort_bucket_block(const int* g, const float* __restrict__ depths,
+                                                  int* out, int n, unsigned long long* lds) {
+    if (n <= kThreads) sort_tile_regs<1>(g, depths, out, n, lds);
+    else if (n <= 2 * kThreads) sort_tile_regs<2>(g, depths, out, n, lds);
+    else if (n <= 4 * kThreads) sort_tile_regs<4>(g, depths, out, n, lds);
+    else if (n <= 8 * kThreads) sort_tile_regs<8>(g, depths, out, n, lds);
+    else sort_tile_regs<16>(g, depths, out, n, lds);
+}
+
+// Tiles of more than kSampleMin keys (beyond the register network): per-tile SAMPLE SORT,
+// O(n log n), streaming the tile's ids from global memory.  Measured on config 5 (2.5 k keys per
+// tile) the network with its 16 independent keys per lane is 3x faster than this latency-chained
+// scheme, so the network keeps every tile it can hold; the sample sort is the robust path for very
+// dense tiles, replacing a global-memory network whose every stage is a barrier plus HBM round trips.
+//   1. a regular sample of NS keys (256, or 1024 for n > 8192) is sorted with the network;
+//   2. B - 1 splitters taken evenly from the sorted sample cut the key range into B sub-buckets of
+//      ~96 keys on average (keys are unique, so equal depths cannot pile up in one sub-bucket);
+//   3. two passes over the tile's ids: LDS histogram of sub-bucket sizes, then LDS cursors scatter
+//      the ids into `out` grouped by sub-bucket;
+//   4. each wave sorts whole sub-buckets (<= 256 keys) on its own, in place; the rare larger ones are
+//      sorted afterwards by the whole workgroup.
+// LDS (u64 units): scratch[4096] sample[1024] tables[1024] = 48 KiB.
+constexpr int kSampleMin = kSortCap;      // tiles up to this size use the plain network
+constexpr int kMaxSub = 512;              // sub-buckets per tile
+constexpr int kSubTarget = 96;            // mean keys per sub-bucket aimed at
+constexpr int kLargeLdsU64 = kSortCap + 2048;
+
+__device__ __forceinline__ void sort_tile_sample(const int* __restrict__ g,
+                                                 const float* __restrict__ depths,
+                                                 int* __restrict__ out, int n,
+                                                 unsigned long long* lds) {
+    unsigned long long* scratch = lds;
+    unsigned long long* smp = lds + kSortCap;
+    int* start = reinterpret_cast<int*>(lds + kSortCap + 1024);       // [kMaxSub + 1]
+    int* cursor = start + (kMaxSub + 1);                              // [kMaxSub]
+    int* big = cursor + kMaxSub;                                      // [kMaxSub] oversize list
+    __shared__ int nbig;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ns = n > 8192 ? 1024 : 256;
+    int nb = n / kSubTarget;
+    nb = nb < 2 ? 2 : (nb > kMaxSub ? kMaxSub : nb);
+
+    if (ns == 1024) {                                                 // sorted sample
+        unsigned long long k[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            k[e] = make_key(depths, g[(int)(((long long)(t * 4 + e) * n) >> 10)]);
+        bitonic_regs<4, kThreads>(k, t, 1024, scratch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) smp[t * 4 + e] = k[e];
+    } else {
+        unsigned long long k[1];
+        k[0] = make_key(depths, g[(int)(((long long)t * n) >> 8)]);
+        bitonic_regs<1, kThreads>(k, t, 256, scratch);
+        smp[t] = k[0];
+    }
+    for (int b = t; b < nb; b += kThreads) cursor[b] = 0;
+    if (t == 0) nbig = 0;
+    __syncthreads();
+
+    // sub-bucket of a key = number of splitters <= key; splitter j = smp[((j + 1) * ns) / nb]
+    auto sub_of = [&](unsigned long long key) {
+        int lo = 0, hi = nb - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (smp[((mid + 1) * ns) / nb] <= key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    for (int i = t; i < n; i += kThreads) atomicAdd(&cursor[sub_of(make_key(depths, g[i]))], 1);
+    __syncthreads();
+    {   // exclusive scan of nb <= 512 counts: two per thread
+        const int c0 = (2 * t < nb) ? cursor[2 * t] : 0, c1 = (2 * t + 1 < nb) ? cursor[2 * t + 1] : 0;
+        int total;
+        const int inc = block_inclusive_scan(c0 + c1, &total);
+        const int ex = inc - (c0 + c1);
+        if (2 * t < nb) start[2 * t] = ex;
+        if (2 * t + 1 < nb) start[2 * t + 1] = ex + c0;
+        if (t == 0) start[nb] = n;
+    }
+    __syncthreads();
+    for (int b = t; b < nb; b += kThreads) cursor[b] = start[b];
+    __syncthreads();
+    for (int i = t; i < n; i += kThreads) {
+        const int id = g[i];
+        out[atomicAdd(&cursor[sub_of(make_key(depths, id))], 1)] = id;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int b = wave; b < nb; b += kThreads / 64) {                 // wave-level sorts, in place
+        const int s0 = start[b], m = start[b + 1] - s0;
+        if (m <= 1) continue;
+        if (m <= 256) {
+            unsigned long long k[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = lane * 4 + e;
+                k[e] = i < m ? make_key(depths, out[s0 + i]) : ~0ull;
+            }
+            bitonic_regs<4, 64>(k, lane, min(pow2_at_least(m), 256), nullptr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = lane * 4 + e;
+                if (i < m) out[s0 + i] = (int)(unsigned int)k[e];
+            }
+        } else if (lane == 0) {
+            big[atomicAdd(&nbig, 1)] = b;
+        }
+    }
+    __syncthreads();
+    const int nbg = nbig;
+    for (int q = 0; q < nbg; ++q) {                                   // rare: oversize sub-buckets
+        const int b = big[q];
+        const int s0 = start[b], m = start[b + 1] - s0;
+        __syncthreads();
+        if (m <= kSortCap) {
+            sort_bucket_block(out + s0, depths, out + s0, m, scratch);
+        } else {
+            IdKeyArray a{out + s0, depths};
+            bitonic_network(a, m);
+        }
+        __syncthreads();
+    }
+}
+
+// Two launches so that the common small tiles keep a small LDS footprint (occupancy): the first
+// kernel sorts every tile the network can hold and appends the others to a list; the second one is
+// a small persistent grid that walks that (normally empty) list.
+__global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     const int* __restrict__ tile_bins, const float* __restrict__ depths,
-    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_list) {
     __shared__ unsigned long long lk[kSortCap];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
     const int n = range.y - range.x;
     if (n <= 0) return;
-    const int* g = bucket_ids + range.x;
-    int* out = ids_sorted + range.x;
-    if (n <= kThreads) sort_tile_regs<1>(g, depths, out, n, lk);
-    else if (n <= 2 * kThreads) sort_tile_regs<2>(g, depths, out, n, lk);
-    else if (n <= 4 * kThreads) sort_tile_regs<4>(g, depths, out, n, lk);
-    else if (n <= 8 * kThreads) sort_tile_regs<8>(g, depths, out, n, lk);
-    else if (n <= kSortCap) sort_tile_regs<16>(g, depths, out, n, lk);
-    else {
-        // larger than the register/LDS budget: copy the ids and run the flip/disperse network in
-        // place in global memory, comparing through gathered depths (one workgroup, one CU: the
-        // vector L1 is shared and write-through, barriers order the stages)
-        for (int i = threadIdx.x; i < n; i += kThreads) out[i] = g[i];
+    if (n > kSampleMin) {
+        if (threadIdx.x == 0) large_list[1 + atomicAdd(&large_list[0], 1)] = blockIdx.x;
+        return;
+    }
+    sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lk);
+}
+
+__global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
+    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted,
+    const int* __restrict__ large_list) {
+    __shared__ unsigned long long lds_large[kLargeLdsU64];
+    const int count = large_list[0];
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int2 range = reinterpret_cast<const int2*>(tile_bins)[large_list[1 + q]];
         __syncthreads();
-        IdKeyArray a{out, depths};
-        bitonic_network(a, n);
+        sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, range.y - range.x,
+                         lds_large);
     }
 }
 
@@ -555,12 +704,19 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_c
 }
 
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
-                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, void* stream) {
+                  const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
+                  void* stream) {
     if (num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
-    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted) return TS_E_BADARG;
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(num_tiles), dim3(kThreads), 0, (hipStream_t)stream,
-                       tile_bins, depths, bucket_ids, gaussian_ids_sorted);
+    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted || !sort_ws) return TS_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins,
+                       depths, bucket_ids, gaussian_ids_sorted, sort_ws);
+    const int grid = num_tiles < 768 ? num_tiles : 768;
+    hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
+                       bucket_ids, gaussian_ids_sorted, sort_ws);
     return launch_status();
 }
 

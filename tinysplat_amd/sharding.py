@@ -111,10 +111,11 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
     if xys.requires_grad:
         xys.retain_grad()
     colors = _colors(model, camera, ops, device, fused_colors)
-    ra = raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims)
-    if prep:
-        ra[6] = model.opacities
+    if prep:      # opacity logits go in as they are: no torch.sigmoid kernel
+        ra = [xys, depths, radii, conics, num_tiles, colors, model.opacities, h, w, model.background]
         kw = dict(kw, logit_opacity=True)
+    else:
+        ra = raster_args(model, xys, depths, radii, conics, num_tiles, colors, dims)
     if sharded:
         ra[0], ra[3], ra[5], ra[6] = sum_grads_across_ranks((ra[0], ra[3], ra[5], ra[6]), group)
     rgb, _ = ops.rasterize_gaussians(*ra, **kw)

@@ -45,8 +45,8 @@ def alg_bytes(entry: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3) -
         "ts_scan_tiles": 8.0 * n,
         "ts_bin_count": 12.0 * n + 4.0 * t,
         "ts_tile_offsets": 16.0 * t,
-        "ts_bin_scatter": 16.0 * n + 8.0 * i,
-        "ts_sort_tiles": 12.0 * i + 8.0 * t,
+        "ts_bin_scatter": 12.0 * n + 4.0 * i,
+        "ts_sort_tiles": 8.0 * i + 8.0 * t,
         "ts_pack_splats": (36.0 + 4.0 + 4.0 + 48.0) * n,
         "ts_raster_fwd": 40.0 * i + 20.0 * p + 8.0 * t,   # D5 "raster fwd"
         "ts_raster_bwd": 24.0 * p + 76.0 * i + 36.0 * n,  # D5 "raster bwd" (incl. reduce)

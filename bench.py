@@ -51,6 +51,8 @@ def alg_bytes(entry: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3) -
         "ts_raster_fwd": 40.0 * i + 20.0 * p + 8.0 * t,   # D5 "raster fwd"
         "ts_raster_bwd": 24.0 * p + 76.0 * i + 36.0 * n,  # D5 "raster bwd" (incl. reduce)
         "ts_reduce_partials": 48.0 * i + 36.0 * n,
+        "ts_photometric_loss": 36.0 * p,                  # read X, Y, write gX (3 channels)
+        "ts_adam_step": 28.0 * (14.0 + 3.0 * k) * n,      # p, g, m, v read; p, m, v written
     }[entry]
 
 
@@ -134,6 +136,9 @@ def main():
     ap.add_argument("--depth", action="store_true", help="also run the depth rasterize pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--train-step", action="store_true",
+                    help="time the whole training step of SURVEY 8(f) F1 instead: render RGB+depth, "
+                         "L1 + DSSIM (+ depth L1) loss, backward, Adam (single GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
     ap.add_argument("--config", type=int, default=None,
@@ -171,7 +176,20 @@ def main():
     w_rgb, w_d = w_rgb.to(dev), w_d.to(dev)
     adapter = GaussianRasterizer(model, None, device=dev)
 
+    trainer = None
+    if args.train_step:
+        if world > 1:
+            raise SystemExit("--train-step is a single-GPU mode")
+        from tinysplat_amd.training import TrainStep
+        trainer = TrainStep(model, dev)
+        g_ = torch.Generator().manual_seed(2)
+        tgt_rgb = torch.rand(h, w, 3, generator=g_).to(dev)
+        tgt_depth = (2.0 + 8.0 * torch.rand(h, w, generator=g_)).to(dev)
+
     def step():
+        if trainer is not None:
+            trainer(cam, tgt_rgb, tgt_depth)
+            return
         for p_ in model.parameters():
             p_.grad = None
         if args.depth:
@@ -241,7 +259,8 @@ def main():
                 traffic = None
         bw_meas = measure_read_bandwidth(dev)
         out = {
-            "metric": "Gaussians*pixels/s fwd+bwd",
+            "metric": "Gaussians*pixels/s fwd+bwd" if not args.train_step else
+                      "Gaussians*pixels/s of a full training step (render RGB+depth, loss, backward, Adam)",
             "value": value, "unit": "Gaussians*pixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",

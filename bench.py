@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="time the whole training step of SURVEY 8(f) F1 instead: render RGB+depth, "
                          "L1 + DSSIM (+ depth L1) loss, backward, Adam (single GPU)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="time the no_grad forward frame only (the viewer path, SURVEY 8(f) F4)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
     ap.add_argument("--config", type=int, default=None,
@@ -192,6 +194,10 @@ def main():
             return
         for p_ in model.parameters():
             p_.grad = None
+        if args.forward_only:
+            with torch.no_grad():
+                adapter(cam, (w, h), sh)
+            return
         if args.depth:
             if world > 1:
                 raise SystemExit("--depth is a single-GPU mode")
@@ -259,7 +265,8 @@ def main():
                 traffic = None
         bw_meas = measure_read_bandwidth(dev)
         out = {
-            "metric": "Gaussians*pixels/s fwd+bwd" if not args.train_step else
+            "metric": "Gaussians*pixels/s forward only (no_grad, RGB+depth)" if args.forward_only else
+                      "Gaussians*pixels/s fwd+bwd" if not args.train_step else
                       "Gaussians*pixels/s of a full training step (render RGB+depth, loss, backward, Adam)",
             "value": value, "unit": "Gaussians*pixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,

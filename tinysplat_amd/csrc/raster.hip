@@ -127,7 +127,11 @@ __device__ __forceinline__ float sigma_l2(float diag, float Bdx, float dy) {
 // every XCD has a private 4 MiB L2.  Handing XCD x the x-th contiguous eighth of the tile groups
 // (a band of tile rows) keeps the packed-record gathers of neighbouring tiles, which share most of
 // their Gaussians, in one L2.  Placement only affects speed.  Grid = 8 * ceil(groups / 8).
+#ifndef TS_XCD_MAP
+#define TS_XCD_MAP 1
+#endif
 __device__ __forceinline__ int xcd_tile_group(int num_groups) {
+    if (!TS_XCD_MAP) return (int)blockIdx.x;
     const int per_xcd = (num_groups + 7) >> 3;
     return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 }

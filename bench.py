@@ -232,7 +232,8 @@ def main():
     for _ in range(max(1, args.profile_steps)):
         step()
     per_entry = ops.kernel_timer.stop()
-    binning = ops._bin_cache.get(dev.index)[1]
+    from tinysplat_amd import frame as _frame
+    binning = _frame.last_binning[dev.index] if dev.index in _frame.last_binning else ops._bin_cache.get(dev.index)[1]
     isects = int(binning.num_intersects)
     tiles = int(binning.num_tiles)
     bins = binning.tile_bins

@@ -232,7 +232,9 @@ def test_raster_bwd_deterministic():
 
 @pytest.mark.parametrize("n,sh,w,h,mult,fused", [(10000, 0, 256, 256, 2.0, False),
                                                   (30000, 3, 480, 270, 2.0, False),
-                                                  (30000, 3, 480, 270, 2.0, True)])
+                                                  (30000, 3, 480, 270, 2.0, True),
+                                                  (30000, 3, 480, 270, 2.0, "one-node"),
+                                                  (5000, 1, 200, 120, 4.0, "one-node")])
 def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
     """The whole adapter (project -> SH -> rasterize RGB -> rasterize depth) fwd + bwd to the six
     parameter tensors, HIP vs the same recipe run with the oracle ops (float32, CPU autograd)."""
@@ -249,7 +251,8 @@ def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
     ((f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()).backward()
 
     md = model.to(DEV).requires_grad_(True)
-    r = GaussianRasterizer(md, None, device=torch.device(DEV), fused_colors=fused)
+    r = GaussianRasterizer(md, None, device=torch.device(DEV), fused_colors=bool(fused))
+    r.single_node = fused == "one-node"          # frame.py: the fused recipe as one autograd node
     rgb, extras = r(cam, (w, h), sh)
     ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
@@ -394,6 +397,27 @@ def test_fused_prep_flags_equal_op_by_op_recipe():
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4      # rare 1-ulp threshold flips
     ga, gb = outs[0][1], outs[1][1]
     assert ((ga - gb).abs() > 1e-4 * max(1.0, ga.abs().max().item())).float().mean().item() < 1e-3
+
+
+def test_one_node_frame_is_bitwise_the_fused_op_recipe():
+    """frame.render_frame enqueues the same kernels as the fused three-op recipe: identical bits in
+    the image, the depth map and every parameter gradient (incl. extras['xys'].grad)."""
+    n, w, h = 40000, 400, 300
+    model, cam = scene_args(n, 2, w, h, seed=77, scale_mult=3.0)
+    g = torch.Generator().manual_seed(9)
+    w_rgb, w_d = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    res = []
+    for one in (False, True):
+        md = model.to(DEV).requires_grad_(True)
+        r = GaussianRasterizer(md, None, device=torch.device(DEV))
+        r.single_node = one
+        rgb, ex = r(cam, (w, h), 2)
+        ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
+        res.append([rgb.detach(), ex["depth"].detach(), ex["radii"], ex["xys"].detach(), ex["xys"].grad]
+                   + [p.grad for p in md.parameters()])
+    assert len(res[0]) == len(res[1]) == 11
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 def _raster_parity(args, h, w, atol_img=1e-5, use_alpha=True, seed=5):

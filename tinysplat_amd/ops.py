@@ -335,6 +335,37 @@ def _same(t: Tensor, kept: Tensor, version: int) -> bool:
     return (t.data_ptr() == kept.data_ptr() and t._version == version and t.shape == kept.shape)
 
 
+_pinned_counts = {}
+
+
+class _IntersectionCount:
+    """The path's one host read - cum_tiles_hit[n-1], which sizes the intersection buffers - as an
+    asynchronous copy into pinned memory plus an event: the caller keeps enqueueing the kernels
+    that do not depend on the count and waits only when it must allocate."""
+
+    def __init__(self, cum: Tensor, dev: torch.device):
+        self.n = cum.shape[0]
+        if self.n == 0:
+            return
+        slot = _pinned_counts.get(dev.index)
+        if slot is None:
+            slot = (torch.empty((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            _pinned_counts[dev.index] = slot
+        self.host, self.event = slot
+        self.host.copy_(cum[-1:], non_blocking=True)
+        self.event.record(torch.cuda.current_stream(dev))
+
+    def wait(self) -> int:
+        if self.n == 0:
+            return 0
+        self.event.synchronize()
+        total = int(self.host[0])
+        if total < 0:
+            raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
+                                "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
+        return total
+
+
 def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tensor,
                   img_height: int, img_width: int,
                   tile_rows: Optional[Tuple[int, int]] = None, use_cache: bool = True) -> TileBinning:
@@ -369,16 +400,14 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
         cum = torch.empty((n,), **i32)
         ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
         _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth_c), _ptr(cum), _ptr(ws), s)
-        total = int(cum[-1].item()) if n > 0 else 0          # the one host sync of the path
-        if total < 0:
-            raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
-                                "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
+        pending = _IntersectionCount(cum, dev)       # D2H copy of cum[n-1] starts now ...
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-        bucket_ids = torch.empty((max(total, 1),), **i32)
-        ids = torch.empty((max(total, 1),), **i32)
         _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys_c), _ptr(radii_c), cam, _ptr(bin_ws), s)
         _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
+        total = pending.wait()                       # ... and is awaited behind the two launches above
+        bucket_ids = torch.empty((max(total, 1),), **i32)
+        ids = torch.empty((max(total, 1),), **i32)
         if total > 0:
             _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys_c), _ptr(radii_c), cam,
                   _ptr(bin_ws), _ptr(bucket_ids), s)

@@ -21,6 +21,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
+from . import frame as _hip_frame
 from . import ops as _hip_ops
 
 TILE = 16  # rasterize.py:19-20
@@ -94,15 +95,17 @@ class GaussianRasterizer:
         # sigmoid(opacities) (rasterize.py:86) into the projection / packing kernels.
         # fused_depth: composite RGB and depth in ONE 4-channel pass (the kernels are templated on
         # the channel count) instead of two 3-channel passes over the same lists.
+        # single_node: run all of it as one autograd function (frame.py) to cut host overhead.
         self.fused_colors = fused_colors
         self.fused_prep = fused_colors
         self.fused_depth = fused_colors
+        self.single_node = fused_colors
         # the three callables of the boundary; the product default is the HIP library
         self.ops = SimpleNamespace(project_gaussians=_hip_ops.project_gaussians,
                                    spherical_harmonics=_hip_ops.spherical_harmonics,
                                    rasterize_gaussians=_hip_ops.rasterize_gaussians,
                                    sh_colors=_hip_ops.sh_colors, fused_prep=True,
-                                   four_channels=True)
+                                   four_channels=True, render_frame=_hip_frame.render_frame)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
@@ -110,6 +113,17 @@ class GaussianRasterizer:
         ops = self.ops
 
         prep = self.fused_prep and getattr(ops, "fused_prep", False)
+        if (prep and self.fused_colors and self.fused_depth and self.single_node
+                and getattr(ops, "render_frame", None) is not None):
+            # everything above in one autograd node (frame.py): same kernels, a fraction of the
+            # host-side cost per frame
+            view, projview, origin = camera_on_device(camera, self.device)
+            w, h = dims
+            out, xys, radii = ops.render_frame(self.model, view[:3, :], projview, origin, camera.f_x,
+                                               camera.f_y, w, h, True)
+            extras = {"depth": out[:, :, 3], "radii": radii, "xys": xys,
+                      "camera": {"height": camera.height, "width": camera.width}}
+            return torch.clamp(out[:, :, :3], max=1.0), extras
         if prep:
             w, h = dims
             _, projview, _ = camera_on_device(camera, self.device)

@@ -86,7 +86,8 @@ def _colors(model, camera, ops, device, fused_colors):
 
 def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_size: int = 1,
                       group=None, tile_rows: Optional[Tuple[int, int]] = None,
-                      fused_colors: bool = True, collective: Optional[bool] = None):
+                      fused_colors: bool = True, collective: Optional[bool] = None,
+                      single_node: bool = True):
     """Steps 1-3 of the reference frame (rasterize.py:30-45: project, SH, clamp, rasterize RGB,
     clamp) for this rank's stripe.  Returns (rgb_stripe[rows,W,3], (row_begin_px, row_end_px), xys).
 
@@ -99,6 +100,15 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
     sharded = (world_size > 1) if collective is None else collective   # run the grad all-reduce?
     kw = {"tile_rows": tile_rows} if (sharded or tile_rows != (0, tby)) else {}
     prep = fused_colors and getattr(ops, "fused_prep", False)
+    if prep and single_node and getattr(ops, "render_frame", None) is not None:
+        # the recipe below as one autograd node (frame.py); its backward all-reduces the same flat
+        # 2-D gradient buffer between the compositing and the projection backward
+        view, projview, origin = camera_on_device(camera, device)
+        grp = (group if group is not None else dist.group.WORLD) if sharded else None
+        out, xys, _ = ops.render_frame(model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
+                                       w, h, False, tile_rows, grp)
+        y0 = 16 * tile_rows[0]
+        return torch.clamp(out, max=1.0), (y0, y0 + out.shape[0]), xys
     if prep:      # exp / normalise / sigmoid folded into the kernels (see GaussianRasterizer)
         view, projview, _ = camera_on_device(camera, device)
         pa = [model.means, model.scales, 1., model.quats, view[:3, :], projview, camera.f_x,

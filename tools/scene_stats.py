@@ -20,7 +20,8 @@ ra = raster_args(model, xys, depths, radii, conics, nth, col, (w, h))
 ra[5] = ra[5].requires_grad_(True)
 img, alpha = ops.rasterize_gaussians(*ra)
 _, _, fT, fI = img.grad_fn.saved_tensors
-b = ops._bin_cache[0][1]
+from tinysplat_amd import frame as _frame
+b = _frame.last_binning.get(0) or ops._bin_cache[0][1]
 bins, ids = b.tile_bins.long(), b.gaussian_ids_sorted.long()
 op = torch.sigmoid(model.opacities)[:, 0]
 tbx = 120

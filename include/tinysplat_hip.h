@@ -202,6 +202,54 @@ int ts_adam_step(int32_t num_tensors, float* const* params_host, const float* co
                  const float* lr_host, const int32_t* steps_host, float beta1, float beta2, float eps,
                  void* stream);
 
+/* ================== densification hooks (model_gaussian.py:130-242) ========= */
+/* Call order of one densify_and_prune (model_gaussian.py:138-195):
+ *   ts_densify_classify -> ts_densify_plan -> (host reads counts[4]) -> ts_gather_rows x 3 tables
+ *   (parameters: copy_rows = N'; exp_avg, exp_avg_sq: copy_rows = K, the new rows are zero)
+ *   -> ts_split_fixup on rows [K + C, N').  update_state(optim, mask) alone (train.py:103-105) is
+ *   flags = mask ? TS_DENSIFY_PRUNE : 0 -> ts_densify_plan -> ts_gather_rows x 3.               */
+#define TS_DENSIFY_CLONE 1   /* small scale, large mean 2-D gradient (:152-153): row is duplicated       */
+#define TS_DENSIFY_SPLIT 2   /* large scale, large gradient (:164-165): two samples replace the row      */
+#define TS_DENSIFY_PRUNE 4   /* row is dropped (:181-183; every split row is also pruned)                 */
+
+typedef struct ts_densify_policy {
+    float interval_densify;  /* model.interval_densify (:148)                                   */
+    float max_dim;           /* max(width, height) of the last rendered camera (:146-148)       */
+    float tau_means;         /* --tau-means, train.py:212                                       */
+    float scale_thresh;      /* --densify-scale-thresh, train.py:213                            */
+} ts_densify_policy;
+
+/* update_grad_accum (:132): accum[i] += ||v_xy[i]||_2.  v_xy [n,2] is extras['xys'].grad. */
+int ts_grad_accum(int32_t n, const float* v_xy, float* accum, void* stream);
+
+/* Per-Gaussian policy bits (:148-183).  scales are log-scales [n,3], opacities logits [n]. */
+int ts_densify_classify(int32_t n, const float* accum, const float* scales, const float* opacities,
+                        const ts_densify_policy* policy, uint8_t* flags, void* stream);
+
+/* Row map of the rebuilt tensors.  counts (device, 4 int32) <- {K kept, C cloned, S split, N' = K + C + 2S};
+ * src_of (device, capacity >= 2 n int32; N' <= 2 n always) <- source row of every new row, laid out
+ * [kept | cloned | split sample 0 | split sample 1], source order within each part - the order of
+ * torch.cat((param[~mask], cat(cloned, split.repeat(2)))) at :187-192, :213-226.
+ * ws: >= ts_densify_ws_ints(n) int32. */
+int64_t ts_densify_ws_ints(int32_t n);
+int ts_densify_plan(int32_t n, const uint8_t* flags, int32_t* ws, int32_t* counts, int32_t* src_of,
+                    void* stream);
+
+/* dst_i[r, :] = r < copy_rows ? src_i[src_of[r], :] : 0  for up to TS_GATHER_MAX_TENSORS row-major
+ * float32 tensors (row_floats_host[i] floats per row) in one launch.  Pointer tables are HOST arrays. */
+#define TS_GATHER_MAX_TENSORS 8
+int ts_gather_rows(int32_t num_tensors, const float* const* src_host, float* const* dst_host,
+                   const int32_t* row_floats_host, int32_t dst_rows, int32_t copy_rows,
+                   const int32_t* src_of, void* stream);
+
+/* GaussianDistribution.sample (:547-557) for the 2S sampled rows: with i = src_of_split[j],
+ * means_out[j] = R(quats[i] / |quats[i]|) (z[j] * exp(scales[i])) + means[i],
+ * scales_out[j] = log(exp(scales[i]) / 1.6).  z [rows,3] are unit normal draws (the reference's
+ * torch.normal(0, std) is z * std).  src_of_split = src_of + K + C; *_out point at row K + C. */
+int ts_split_fixup(int32_t rows, const int32_t* src_of_split, const float* means, const float* scales,
+                   const float* quats, const float* z, float* means_out, float* scales_out,
+                   void* stream);
+
 /* ======================================= measurement utility ================================== */
 /* Streaming read of n_floats float32 (16-byte loads, grid-stride): the read-bandwidth microbenchmark
  * that SURVEY.md 8(d) D1 asks the roofline to be quoted against as well.  sink: >= 1 float. */

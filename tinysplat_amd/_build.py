@@ -19,6 +19,7 @@ SOURCES = [
     # (measured: raster_bwd 0.87 -> 0.67 ms with it off)
     ("raster.hip", ["-fno-slp-vectorize"]),
     ("train.hip", []),
+    ("densify.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

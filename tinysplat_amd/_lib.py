@@ -27,6 +27,13 @@ class TsCamera(ctypes.Structure):
 _P = c_void_p  # every device pointer travels as an integer address
 _CAM = POINTER(TsCamera)
 
+
+class TsDensifyPolicy(ctypes.Structure):
+    """ts_densify_policy of include/tinysplat_hip.h."""
+    _fields_ = [("interval_densify", c_float), ("max_dim", c_float), ("tau_means", c_float),
+                ("scale_thresh", c_float)]
+
+
 # name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
 SIGNATURES = {
     "ts_abi_version": (c_int32, []),
@@ -50,6 +57,12 @@ SIGNATURES = {
     "ts_photometric_ws_floats": (c_int64, [c_int32, c_int32]),
     "ts_photometric_loss": (c_int32, [c_int32, c_int32, _P, _P, c_float, c_float, _P, _P, _P]),
     "ts_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
+    "ts_grad_accum": (c_int32, [c_int32, _P, _P, _P]),
+    "ts_densify_classify": (c_int32, [c_int32, _P, _P, _P, POINTER(TsDensifyPolicy), _P, _P]),
+    "ts_densify_ws_ints": (c_int64, [c_int32]),
+    "ts_densify_plan": (c_int32, [c_int32, _P, _P, _P, _P, _P]),
+    "ts_gather_rows": (c_int32, [c_int32, _P, _P, _P, c_int32, c_int32, _P, _P]),
+    "ts_split_fixup": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -1,0 +1,191 @@
+"""Densification hooks of tinysplat's GaussianModel on the HIP library.
+
+Host-side mirror of /root/reference/tinysplat/splatting/model_gaussian.py:130-242 - same method
+names, argument meaning and gating - over the C-ABI entries of csrc/densify.hip:
+
+    update_grad_accum(step, extras)          :130-132
+    reset_opacities(step)                    :134-136
+    densify_and_prune(step, optim, extras)   :138-195  (+ GaussianDistribution.sample :533-572)
+    update_state(optim, mask, tensors)       :197-242
+
+The model is any holder of the six parameter tensors (synthetic.SplatModel); ``optim`` is
+training.Adam (exp_avg / exp_avg_sq dictionaries keyed by parameter name, per-tensor step counts
+that densification leaves untouched, as the reference does by carrying the state dict over).
+Nothing here falls back to PyTorch indexing: the rebuilt tensors come from ts_gather_rows.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import TsDensifyPolicy
+from .ops import _call, _f32c, _need_hip, _ptr, _stream
+
+FIELDS = ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities")
+MAX_GAUSSIANS = 1000000          # model_gaussian.py:146
+
+
+@dataclass
+class DensifyConfig:
+    """scripts/train.py:206-214 defaults."""
+    warmup_densify: int = 600
+    warmup_grad: int = 500
+    interval_densify: int = 100
+    interval_opacity_reset: int = 3000
+    densify_end: int = 30000
+    epsilon_alpha: float = 0.005
+    tau_means: float = 0.0002
+    densify_scale_thresh: float = 0.01
+
+
+def _row_floats(t: Tensor) -> int:
+    w = 1
+    for d in t.shape[1:]:
+        w *= int(d)
+    return w
+
+
+def _gather(src: Dict[str, Tensor], dst: Dict[str, Tensor], names, dst_rows: int, copy_rows: int,
+            src_of: Tensor, dev) -> None:
+    k = len(names)
+    PtrArr, IArr = ctypes.c_void_p * k, ctypes.c_int32 * k
+    lib = _lib.load()
+    _call("ts_gather_rows", lib.ts_gather_rows, k, PtrArr(*[src[n].data_ptr() for n in names]),
+          PtrArr(*[dst[n].data_ptr() for n in names]), IArr(*[_row_floats(src[n]) for n in names]),
+          int(dst_rows), int(copy_rows), _ptr(src_of), _stream(dev))
+
+
+class Densifier:
+    def __init__(self, model, config: Optional[DensifyConfig] = None):
+        self.model = model
+        self.cfg = config or DensifyConfig()
+        self.means_grad_accum = torch.zeros(model.means.shape[0], dtype=torch.float32,
+                                            device=model.means.device)      # :62
+        self.last_counts = None      # (kept, cloned, split, new total) of the last rebuild
+
+    # ------------------------------------------------------------------ :130-132
+    @torch.no_grad()
+    def update_grad_accum(self, step: int, extras) -> None:
+        if step < self.cfg.warmup_grad:
+            return
+        g = extras["xys"].grad
+        if g is None:
+            raise RuntimeError("extras['xys'].grad is missing: run backward before update_grad_accum")
+        dev = _need_hip(g, self.means_grad_accum)
+        g = _f32c(g)
+        n = self.means_grad_accum.shape[0]
+        if g.shape != (n, 2):
+            raise ValueError(f"xys.grad must be [{n}, 2]")
+        with torch.cuda.device(dev):
+            _call("ts_grad_accum", _lib.load().ts_grad_accum, n, _ptr(g), _ptr(self.means_grad_accum),
+                  _stream(dev))
+
+    # ------------------------------------------------------------------ :134-136
+    @torch.no_grad()
+    def reset_opacities(self, step: int) -> None:
+        if step % self.cfg.interval_opacity_reset != 0:
+            return
+        self.model.opacities.data.fill_(self.cfg.epsilon_alpha / 2)
+
+    # ------------------------------------------------------------------ :138-195
+    @torch.no_grad()
+    def classify(self, width: int, height: int) -> Tensor:
+        """Policy bits per Gaussian (TS_DENSIFY_CLONE | SPLIT | PRUNE), uint8 [N]."""
+        m = self.model
+        dev = _need_hip(m.scales, m.opacities, self.means_grad_accum)
+        n = m.means.shape[0]
+        flags = torch.empty((n,), dtype=torch.uint8, device=dev)
+        pol = TsDensifyPolicy(float(self.cfg.interval_densify), float(max(width, height)),
+                              float(self.cfg.tau_means), float(self.cfg.densify_scale_thresh))
+        with torch.cuda.device(dev):
+            _call("ts_densify_classify", _lib.load().ts_densify_classify, n, _ptr(self.means_grad_accum),
+                  _ptr(_f32c(m.scales.detach())), _ptr(_f32c(m.opacities.detach())), ctypes.byref(pol),
+                  _ptr(flags), _stream(dev))
+        return flags
+
+    @torch.no_grad()
+    def densify_and_prune(self, step: int, optim, extras, z: Optional[Tensor] = None) -> bool:
+        """Returns True when the tensors were rebuilt.  ``z``: optional unit normal draws [2S, 3]
+        for the split samples (tests pass them to compare with the oracle); drawn on the device
+        with torch's generator otherwise."""
+        c = self.cfg
+        if step < c.warmup_densify or step % c.interval_densify != 0:
+            return False
+        if step > c.densify_end:
+            return False
+        if self.model.means.shape[0] > MAX_GAUSSIANS:
+            return False
+        cam = extras["camera"]
+        flags = self.classify(cam["width"], cam["height"])
+        self._rebuild(optim, flags, z)
+        self.means_grad_accum = torch.zeros(self.model.means.shape[0], dtype=torch.float32,
+                                            device=self.model.means.device)        # :195
+        return True
+
+    # ------------------------------------------------------------------ :197-242
+    @torch.no_grad()
+    def update_state(self, optim, mask: Tensor, _tensors=None) -> None:
+        """Drop the rows where ``mask`` is True (the prune-only use, train.py:103-105)."""
+        if _tensors:
+            raise NotImplementedError("appending caller-made rows goes through densify_and_prune")
+        dev = _need_hip(self.model.means)
+        if mask.dtype != torch.bool or mask.shape != (self.model.means.shape[0],):
+            raise ValueError("mask must be bool [N]")
+        flags = mask.to(device=dev, dtype=torch.uint8) * 4          # TS_DENSIFY_PRUNE
+        self._rebuild(optim, flags, None)
+
+    # ------------------------------------------------------------------
+    def _rebuild(self, optim, flags: Tensor, z: Optional[Tensor]) -> None:
+        m = self.model
+        dev = _need_hip(*[getattr(m, f) for f in FIELDS], flags)
+        n = m.means.shape[0]
+        lib = _lib.load()
+        s = _stream(dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        old = {f: getattr(m, f) for f in FIELDS}
+        for f, t in old.items():
+            if not t.is_contiguous() or t.dtype != torch.float32 or t.shape[0] != n:
+                raise ValueError(f"{f} must be contiguous float32 with {n} rows")
+        with torch.cuda.device(dev):
+            ws = torch.empty((int(lib.ts_densify_ws_ints(n)),), **i32)
+            counts = torch.empty((4,), **i32)
+            src_of = torch.empty((max(2 * n, 1),), **i32)
+            _call("ts_densify_plan", lib.ts_densify_plan, n, _ptr(flags), _ptr(ws), _ptr(counts),
+                  _ptr(src_of), s)
+            K, C, S, n2 = (int(v) for v in counts.tolist())        # the one host read: sizes the tensors
+            self.last_counts = (K, C, S, n2)
+            if K == n and C == 0 and S == 0:
+                return
+            new = {f: torch.empty((n2,) + tuple(old[f].shape[1:]), **f32) for f in FIELDS}
+            live = [f for f in FIELDS if _row_floats(old[f]) > 0]
+            src = {f: old[f].detach() for f in FIELDS}
+            _gather(src, new, live, n2, n2, src_of, dev)
+            if S > 0:
+                if z is None:
+                    z = torch.randn((2 * S, 3), **f32)
+                z = _f32c(z)
+                if z.shape != (2 * S, 3) or z.device != dev:
+                    raise ValueError(f"z must be [{2 * S}, 3] on {dev}")
+                first = K + C
+                _call("ts_split_fixup", lib.ts_split_fixup, 2 * S, src_of[first:].data_ptr(),
+                      _ptr(src["means"]), _ptr(src["scales"]), _ptr(src["quats"]), _ptr(z),
+                      new["means"][first:].data_ptr(), new["scales"][first:].data_ptr(), s)
+            new_m = {f: torch.empty_like(new[f]) for f in FIELDS}
+            new_v = {f: torch.empty_like(new[f]) for f in FIELDS}
+            _gather(optim.exp_avg, new_m, live, n2, K, src_of, dev)
+            _gather(optim.exp_avg_sq, new_v, live, n2, K, src_of, dev)
+            accum = torch.empty((K,), **f32)                        # :242
+            _gather({"a": self.means_grad_accum}, {"a": accum}, ["a"], K, K, src_of, dev)
+        self.means_grad_accum = accum
+        for f in FIELDS:
+            p = new[f].requires_grad_(old[f].requires_grad)
+            setattr(m, f, p)
+            optim.params[f] = p
+            optim.exp_avg[f] = new_m[f]
+            optim.exp_avg_sq[f] = new_v[f]

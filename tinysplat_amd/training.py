@@ -123,7 +123,10 @@ class TrainStep:
         model.requires_grad_(True)
         self.optimizer = Adam({n: getattr(model, n) for n in PARAM_ORDER}, lrs)
 
-    def __call__(self, camera, target_rgb: Tensor, target_depth: Optional[Tensor] = None):
+    def __call__(self, camera, target_rgb: Tensor, target_depth: Optional[Tensor] = None,
+                 densifier=None, step: Optional[int] = None):
+        """``densifier`` (densify.Densifier) + ``step`` add train.py:99-102 after the Adam update:
+        gradient accumulation and, on the policy's steps, clone / split / prune."""
         rgb, extras = self.rasterizer(camera, None, self.model.active_sh_degree)
         loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
         if target_depth is not None:                          # train.py:65-69
@@ -131,6 +134,11 @@ class TrainStep:
         loss.backward()
         self.optimizer.step()
         xys_grad = extras["xys"].grad                          # consumed by densification (F2)
+        if densifier is not None:
+            if step is None:
+                raise ValueError("densification needs the 1-based step number")
+            densifier.update_grad_accum(step, extras)         # train.py:101
+            densifier.densify_and_prune(step, self.optimizer, extras)   # train.py:102
         self.optimizer.zero_grad()
         return {"loss": loss.detach(), "l1": l1, "ssim": ssim, "radii": extras["radii"],
                 "xys_grad": xys_grad}

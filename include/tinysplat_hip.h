@@ -250,6 +250,19 @@ int ts_split_fixup(int32_t rows, const int32_t* src_of_split, const float* means
                    const float* quats, const float* z, float* means_out, float* scales_out,
                    void* stream);
 
+/* ======================== PLY record layout (model_gaussian.py:330-361) ===== */
+/* export_ply's per-Gaussian float32 record: x y z | nx ny nz (zeros) | f_dc_0..2 |
+ * f_rest_0..3*k_rest-1 (channel-major: f_rest[c * k_rest + k] = colors_rest[i, k, c], :351) | opacity |
+ * scale_0..2 | rot_0..3  ->  ts_ply_row_floats(k_rest) = 17 + 3 k_rest floats (62 at SH degree 3).
+ * pack: six tensors -> rows [n, W]; unpack: the inverse (the normals are ignored).  Device pointers. */
+int32_t ts_ply_row_floats(int32_t k_rest);
+int ts_ply_pack_rows(int32_t n, int32_t k_rest, const float* means, const float* colors_dc,
+                     const float* colors_rest, const float* opacities, const float* scales,
+                     const float* quats, float* rows, void* stream);
+int ts_ply_unpack_rows(int32_t n, int32_t k_rest, const float* rows, float* means, float* colors_dc,
+                       float* colors_rest, float* opacities, float* scales, float* quats,
+                       void* stream);
+
 /* ======================================= measurement utility ================================== */
 /* Streaming read of n_floats float32 (16-byte loads, grid-stride): the read-bandwidth microbenchmark
  * that SURVEY.md 8(d) D1 asks the roofline to be quoted against as well.  sink: >= 1 float. */

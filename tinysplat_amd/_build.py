@@ -20,6 +20,7 @@ SOURCES = [
     ("raster.hip", ["-fno-slp-vectorize"]),
     ("train.hip", []),
     ("densify.hip", ["-ffp-contract=off"]),
+    ("formats.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ts_densify_plan": (c_int32, [c_int32, _P, _P, _P, _P, _P]),
     "ts_gather_rows": (c_int32, [c_int32, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "ts_split_fixup": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_ply_row_floats": (c_int32, [c_int32]),
+    "ts_ply_pack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_ply_unpack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Times one densify_and_prune at config-3 size and prices it against HBM.
+
+usage: python tools/time_densify.py [N] [K_rest] [--cpu]    (developer / evidence tool)
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from tinysplat_amd import ops
+from tinysplat_amd.densify import Densifier, DensifyConfig
+from tinysplat_amd.synthetic import SplatModel
+
+FIELDS = ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities")
+
+
+def state(n, k_rest, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.empty(n, 1).uniform_(-7.5, -2.0, generator=g)
+    p = {"means": torch.randn(n, 3, generator=g) * 2, "colors_dc": torch.randn(n, 3, generator=g),
+         "colors_rest": torch.randn(n, k_rest, 3, generator=g) * 0.1,
+         "scales": base + torch.empty(n, 3).uniform_(-0.3, 0.3, generator=g),
+         "quats": torch.randn(n, 4, generator=g), "opacities": torch.randn(n, 1, generator=g) * 2.5}
+    accum = torch.rand(n, generator=g) * 4e-5
+    return p, accum
+
+
+class Optim:
+    def __init__(self, p):
+        self.params = p
+        self.exp_avg = {k: torch.zeros_like(t) for k, t in p.items()}
+        self.exp_avg_sq = {k: torch.zeros_like(t) for k, t in p.items()}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 1_000_000
+    k_rest = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 15
+    dev = torch.device("cuda:0")
+    p, accum = state(n, k_rest)
+    row = sum(t[0].numel() for t in p.values()) * 4            # bytes per Gaussian (236 at K=16)
+    reps, times, per = 5, [], None
+    for r in range(reps + 1):
+        pd = {k: t.to(dev).requires_grad_(True) for k, t in p.items()}
+        model = SplatModel(*[pd[k] for k in FIELDS], active_sh_degree=0)
+        optim = Optim(pd)
+        dens = Densifier(model, DensifyConfig())
+        dens.means_grad_accum = accum.to(dev)
+        torch.cuda.synchronize()
+        if r == reps:
+            ops.kernel_timer.start()
+        t0 = time.perf_counter()
+        dens.densify_and_prune(700, optim, {"camera": {"width": 1920, "height": 1080}})
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        if r == reps:
+            per = ops.kernel_timer.stop()
+    K, C, S, n2 = dens.last_counts
+    # every parameter / moment row read once and written once, plus flags / map traffic
+    alg = 20 * n + n + 2 * n + 4 * n2 + row * (n2 + n2) + 2 * row * (K + n2) + 3 * 4 * n2 + 8 * K
+    ms = sorted(times[1:reps])[len(times[1:reps]) // 2] * 1e3
+    kern = sum(c * m for c, m in per.values())
+    out = {"n": n, "row_bytes": row, "kept": K, "cloned": C, "split": S, "n_after": n2,
+           "wall_ms": round(ms, 3), "kernel_ms": round(kern, 3), "alg_GB": round(alg / 1e9, 3),
+           "GBps_kernels": round(alg / kern / 1e6, 1), "frac_of_8TBps": round(alg / kern / 1e6 / 8000, 3),
+           "entries_ms": {k.replace("ts_", ""): round(c * m, 4) for k, (c, m) in per.items()}}
+    if "--cpu" in sys.argv:
+        from oracle import densify_oracle as D       # baseline leg only
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        m0 = {k: torch.zeros_like(t) for k, t in p.items()}
+        z = torch.randn(2 * S, 3)
+        t0 = time.perf_counter()
+        D.densify_and_prune(p, m0, m0, accum, z, interval_densify=100, width=1920, height=1080,
+                            tau_means=2e-4, scale_thresh=0.01)
+        out["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        out["cpu_threads"] = torch.get_num_threads()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -66,7 +66,8 @@ typedef struct ts_camera {
 
 /* Forward.  viewmat: 12 floats (rows of the 3x4 view matrix, rasterize.py:73 passes
  * view_matrix[:3,:]); projmat: 16 floats (P @ V).  Outputs are fully written for every Gaussian;
- * culled ones (z <= clip, singular cov2d, no tile hit) get zeros. */
+ * culled ones (z <= clip, singular cov2d, no tile hit) get zeros.  cov3d may be NULL (the adapter
+ * discards it, rasterize.py:32; the forward-only viewer path, viewer.py:89-93, passes NULL). */
 int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam_host,
                    int32_t flags, float* xys, float* depths, int32_t* radii, float* conics,
@@ -95,7 +96,8 @@ int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
  * normalize(means - origin), origin = view_matrix[:3,3]; coefficients given as the two parameter
  * tensors colors_dc[n,3] and colors_rest[n,K-1,3] instead of their torch.cat) + rasterize.py:38-39
  * (SH evaluation, clamp(rgb + 0.5, min=0)).  clamp_mask[n]: bit c set where channel c passes
- * gradient.  origin: 3 device floats.  colors_rest may be NULL when num_bases == 1. */
+ * gradient (NULL in forward-only use).  origin: 3 device floats.  colors_rest may be NULL when
+ * num_bases == 1. */
 int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
                      const float* origin, const float* colors_dc, const float* colors_rest,
                      float* colors, uint8_t* clamp_mask, void* stream);
@@ -153,7 +155,8 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
                    void* stream);
 
 /* Front-to-back compositing.  out_img[rows,W,channels], final_Ts[rows,W], final_index[rows,W]
- * where rows = min(16*tile_rows, H - 16*tile_row0).  background: `channels` floats. */
+ * where rows = min(16*tile_rows, H - 16*tile_row0).  background: `channels` floats.  final_Ts and
+ * final_index exist for the backward pass; both may be NULL together (forward-only rendering). */
 int ts_raster_fwd(int32_t channels, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, void* stream);

@@ -84,6 +84,29 @@ def main():
     mg = importlib.import_module("tinysplat.splatting.model_gaussian")
     make(mg, "n40_k15", 40, 15, 11)
     make(mg, "n7_k0", 7, 0, 12)
+    viewer_poses()
+
+
+def viewer_poses():
+    """The viewer's pose handling (viewer.py:82-87): position arrives as a float32 torch tensor, the
+    quaternion as a float32 numpy array, and Camera.update_view_matrix (scene.py:96-110) is run on
+    them - i.e. the rotation is evaluated in float32.  Stored: inputs and the resulting matrices."""
+    import math
+    scene = sys.modules["tinysplat.scene"]
+    cam = scene.Camera(position=np.zeros(3), f_x=300.0, f_y=300.0, fov_x=2 * math.atan(128 / 300.0),
+                       fov_y=2 * math.atan(128 / 300.0), quat=np.array([1.0, 0, 0, 0]), near=0.001,
+                       far=1000.0, image=torch.zeros(256, 256, 3), device="cpu")
+    g = torch.Generator().manual_seed(3)
+    pos = torch.randn(6, 3, generator=g)
+    quat = torch.nn.functional.normalize(torch.randn(6, 4, generator=g), dim=-1).numpy()
+    views = []
+    for i in range(6):
+        position = torch.as_tensor(pos[i].tolist(), dtype=torch.float32)       # viewer.py:84
+        q = np.asarray(quat[i].tolist(), dtype=np.float32)                     # viewer.py:85
+        cam.update_view_matrix(position, q)
+        views.append(cam.view_matrix.numpy().copy())
+    np.savez(HERE / "viewer_poses.npz", positions=pos.numpy(), quats=quat, view_matrices=np.stack(views))
+    print("viewer_poses: 6 poses")
 
 
 if __name__ == "__main__":

@@ -151,3 +151,15 @@ def test_build_adapter_with_oracle_ops_matches_reference_adapter_frame(name):
     assert torch.allclose(extras["depth"], torch.from_numpy(z["depth"]), atol=2e-4)
     same = (extras["radii"] == torch.from_numpy(z["radii"])).double().mean()
     assert same > 0.995        # exp(scales) is computed on this host; ceil() can flip on a last-bit change
+
+
+def test_viewer_pose_handling_matches_reference():
+    """viewer.py:82-87 -> scene.py:96-110 with float32 position / quaternion (the rotation is then
+    evaluated in float32 by numpy): PinholeCamera.update_view_matrix reproduces the reference's
+    view matrices bit for bit (tests/golden/make_format_fixtures.py: viewer_poses)."""
+    from tinysplat_amd.synthetic import PinholeCamera
+    z = np.load(GOLD / "viewer_poses.npz")
+    cam = PinholeCamera.look_at_origin_plus_z(256, 256)
+    for p, q, v in zip(z["positions"], z["quats"], z["view_matrices"]):
+        cam.update_view_matrix(np.asarray(p, dtype=np.float32), np.asarray(q, dtype=np.float32))
+        assert np.array_equal(cam.view_matrix.numpy(), v)

@@ -64,10 +64,12 @@ __global__ __launch_bounds__(kThreads) void project_fwd_kernel(
     radii[i] = o.radius;
     conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
     num_tiles_hit[i] = o.tiles;
-    float2* c3 = reinterpret_cast<float2*>(cov3d) + 3 * (size_t)i;
-    c3[0] = make_float2(o.cov3d[0], o.cov3d[1]);
-    c3[1] = make_float2(o.cov3d[2], o.cov3d[3]);
-    c3[2] = make_float2(o.cov3d[4], o.cov3d[5]);
+    if (cov3d) {
+        float2* c3 = reinterpret_cast<float2*>(cov3d) + 3 * (size_t)i;
+        c3[0] = make_float2(o.cov3d[0], o.cov3d[1]);
+        c3[1] = make_float2(o.cov3d[2], o.cov3d[3]);
+        c3[2] = make_float2(o.cov3d[4], o.cov3d[5]);
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
         c2 = c2 + Y[k] * r[3 * (k - 1) + 2];
     }
     c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
-    mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
+    if (mask) mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
     colors[3 * i] = fmaxf(c0, 0.0f); colors[3 * i + 1] = fmaxf(c1, 0.0f);
     colors[3 * i + 2] = fmaxf(c2, 0.0f);
 }
@@ -372,7 +374,7 @@ int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const f
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!means3d || !scales || !quats || !viewmat || !projmat || !xys || !depths || !radii ||
-        !conics || !num_tiles_hit || !cov3d)
+        !conics || !num_tiles_hit)
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
@@ -468,7 +470,7 @@ int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     const int chk = sh_check(n, degrees_to_use, num_bases);
     if (chk) return chk;
     if (n == 0) return 0;
-    if (!means3d || !origin || !colors_dc || !colors || !clamp_mask || (num_bases > 1 && !colors_rest))
+    if (!means3d || !origin || !colors_dc || !colors || (num_bases > 1 && !colors_rest))
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
     const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);

@@ -377,8 +377,10 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         if (!inside[k]) continue;
         const size_t pix = (size_t)(py0 + 8 * (k >> 1) - row_off) * W + (px0 + 8 * (k & 1));
         const float Tf = __builtin_fabsf(T[k]);
-        final_Ts[pix] = Tf;
-        final_index[pix] = fidx[k];
+        if (final_Ts) {             // null in the forward-only (viewer) mode: nothing is kept for backward
+            final_Ts[pix] = Tf;
+            final_index[pix] = fidx[k];
+        }
         float* o = out_img + pix * CH;
 #pragma unroll
         for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + Tf * bg[c];
@@ -694,7 +696,7 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam, const int32_t* tile_bi
     if (!cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0) return 0;
-    if (!tile_bins || !background || !out_img || !final_Ts || !final_index) return TS_E_BADARG;
+    if (!tile_bins || !background || !out_img || (!final_Ts != !final_index)) return TS_E_BADARG;
     const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);

@@ -148,6 +148,74 @@ class _RenderFrame(torch.autograd.Function):
         return (v_means, v_scales, v_quats, v_opac.view(ctx.opacity_shape), v_dc, v_rest) + (None,) * 12
 
 
+@torch.no_grad()
+def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,
+                width: int, height: int, with_depth: bool = True,
+                tile_rows: Optional[Tuple[int, int]] = None):
+    """Forward-only frame (the viewer's ``with torch.no_grad(): scene.render(camera)``,
+    viewer.py:89-93): the kernels of ``render_frame`` without anything kept for a backward pass -
+    no cov3d, clamp mask, final_Ts / final_index outputs, no autograd node.
+    -> (image[rows, W, 3 or 4] unclamped, xys[N,2], radii[N])."""
+    ps = [model.means, model.scales, model.quats, model.opacities, model.colors_dc, model.colors_rest,
+          view34, projview, origin, model.background]
+    dev = _need_hip(*ps)
+    means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background = (
+        _f32c(t.detach()) for t in ps)
+    n, nb = means.shape[0], colors_rest.shape[1] + 1
+    sh_degree = int(model.active_sh_degree)
+    if sh_degree < 0 or sh_degree > deg_from_sh(nb):
+        raise ValueError("sh_degree exceeds the stored coefficients")
+    w, h = int(width), int(height)
+    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
+    ch = 4 if with_depth else 3
+    bg = _f32c(torch.cat([background, background[:1]]) if with_depth else background)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    s = _stream(dev)
+    with torch.cuda.device(dev):
+        xys = torch.empty((n, 2), **f32); depths = torch.empty((n,), **f32)
+        radii = torch.empty((n,), **i32); conics = torch.empty((n, 3), **f32)
+        nth = torch.empty((n,), **i32)
+        _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means), _ptr(scales), _ptr(quats),
+              _ptr(view34), _ptr(projview), cam, 3, _ptr(xys), _ptr(depths), _ptr(radii),
+              _ptr(conics), _ptr(nth), None, s)
+        num_tiles = cam.tile_rows * cam.tile_bounds_x
+        cum = torch.empty((n,), **i32)
+        ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
+        _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth), _ptr(cum), _ptr(ws), s)
+        pending = _IntersectionCount(cum, dev)
+        cols = torch.empty((n, ch), **f32)
+        colors = cols if ch == 3 else torch.empty((n, 3), **f32)
+        _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, n, sh_degree, nb, _ptr(means), _ptr(origin),
+              _ptr(colors_dc), _ptr(colors_rest) if nb > 1 else None, _ptr(colors), None, s)
+        if ch == 4:
+            torch.cat([colors, depths[:, None]], dim=1, out=cols)
+        bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
+        tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
+        _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), cam, _ptr(bin_ws), s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
+        splats = torch.empty((max(n, 1), 12), **f32)
+        _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1, _ptr(xys), _ptr(radii), _ptr(conics),
+              _ptr(cols), _ptr(opacities), _ptr(cum), cam, _ptr(splats), s)
+        total = pending.wait()
+        bucket_ids = torch.empty((max(total, 1),), **i32)
+        ids = torch.empty((max(total, 1),), **i32)
+        if total > 0:
+            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), cam, _ptr(bin_ws),
+                  _ptr(bucket_ids), s)
+            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
+                  _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
+        out_img = torch.empty((_stripe_rows(cam), w, ch), **f32)
+        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
+              _ptr(bg), _ptr(out_img), None, None, s)
+    b = TileBinning()
+    b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
+    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
+    last_binning[dev.index] = b
+    return out_img, xys, radii
+
+
 def render_frame(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,
                  width: int, height: int, with_depth: bool = True,
                  tile_rows: Optional[Tuple[int, int]] = None, group=None):

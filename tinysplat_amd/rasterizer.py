@@ -105,7 +105,8 @@ class GaussianRasterizer:
                                    spherical_harmonics=_hip_ops.spherical_harmonics,
                                    rasterize_gaussians=_hip_ops.rasterize_gaussians,
                                    sh_colors=_hip_ops.sh_colors, fused_prep=True,
-                                   four_channels=True, render_frame=_hip_frame.render_frame)
+                                   four_channels=True, render_frame=_hip_frame.render_frame,
+                                   render_view=_hip_frame.render_view)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
@@ -119,8 +120,10 @@ class GaussianRasterizer:
             # host-side cost per frame
             view, projview, origin = camera_on_device(camera, self.device)
             w, h = dims
-            out, xys, radii = ops.render_frame(self.model, view[:3, :], projview, origin, camera.f_x,
-                                               camera.f_y, w, h, True)
+            # under torch.no_grad() (the viewer, viewer.py:89-93) nothing is kept for backward
+            fn = ops.render_frame if torch.is_grad_enabled() else getattr(ops, "render_view", ops.render_frame)
+            out, xys, radii = fn(self.model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
+                                 w, h, True)
             extras = {"depth": out[:, :, 3], "radii": radii, "xys": xys,
                       "camera": {"height": camera.height, "width": camera.width}}
             return torch.clamp(out[:, :, :3], max=1.0), extras

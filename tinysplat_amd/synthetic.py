@@ -25,7 +25,9 @@ def num_sh_bases(degree: int) -> int:
 
 def quat_to_rot_matrix(quat) -> np.ndarray:
     """(w,x,y,z) -> 3x3, the numpy formula of tinysplat/utils.py:29-39."""
-    q0, q1, q2, q3 = (float(quat[0]), float(quat[1]), float(quat[2]), float(quat[3]))
+    # element dtype is kept: a float32 quaternion (what the viewer passes, viewer.py:85) is evaluated
+    # in float32 exactly as numpy does for the reference; lists / float64 arrays in float64
+    q0, q1, q2, q3 = quat[0], quat[1], quat[2], quat[3]
     return np.asarray([
         [1 - 2 * q2 ** 2 - 2 * q3 ** 2, 2 * q1 * q2 - 2 * q3 * q0, 2 * q1 * q3 + 2 * q2 * q0],
         [2 * q1 * q2 + 2 * q3 * q0, 1 - 2 * q1 ** 2 - 2 * q3 ** 2, 2 * q2 * q3 - 2 * q1 * q0],
@@ -65,6 +67,20 @@ class PinholeCamera:
         proj[3, 2] = 1
         return cls(torch.as_tensor(view, dtype=torch.float32),
                    torch.as_tensor(proj, dtype=torch.float32), f_x, f_y, width, height)
+
+
+def _update_view_matrix(self, position, quat) -> None:
+    """scene.py:96-110: V = [R | -R p] from a (w, x, y, z) quaternion; R and R p are evaluated in the
+    dtype of the inputs (float32 from the viewer), the matrix is stored float32."""
+    rot = quat_to_rot_matrix(quat)
+    view = np.zeros((4, 4))
+    view[:3, :3] = rot
+    view[:3, 3] = -rot.dot(np.asarray(position))
+    view[3, 3] = 1
+    self.view_matrix = torch.as_tensor(view, dtype=torch.float32)
+
+
+PinholeCamera.update_view_matrix = _update_view_matrix
 
 
 class SplatModel:

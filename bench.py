@@ -238,6 +238,7 @@ def main():
     tiles = int(binning.num_tiles)
     bins = binning.tile_bins
     max_per_tile = int((bins[:, 1] - bins[:, 0]).max().item()) if tiles else 0
+    isects_listed = int(bins[:, 1].max().item()) if tiles else 0    # after tight binning (<= isects)
     if world > 1:
         tt = torch.tensor([isects], device=dev, dtype=torch.int64)
         dist.all_reduce(tt)
@@ -277,7 +278,8 @@ def main():
                                    f"({'RGB+depth' if args.depth else 'RGB'}), BASELINE configs[2]"
                                    if (n, sh, w, h) == (1_000_000, 3, 1920, 1080) else
                                    f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd",
-                       "intersections": isects_total, "max_per_tile": max_per_tile,
+                       "intersections": isects_total, "intersections_listed_rank0": isects_listed,
+                       "max_per_tile": max_per_tile,
                        "parallelism": f"tile-row stripes x{world}" if world > 1 else "single GPU",
                        "scale_mult": args.scale_mult},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,

@@ -121,9 +121,15 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
  * t = (ty - tile_row0) * tile_bounds_x + tx. */
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles);
 
-/* bin_ws[b][t] = number of Gaussians of chunk b whose tile rectangle covers tile t (LDS histograms). */
-int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
-                 int32_t* bin_ws, void* stream);
+/* bin_ws[b][t] = number of Gaussians of chunk b whose tile rectangle covers tile t (LDS histograms).
+ * splats: NULL -> gsplat's bounding-box lists (what the bit-exact binning checks compare).
+ * Non-NULL (the packed records of ts_pack_splats) -> TIGHT lists: a (Gaussian, tile) pair is dropped
+ * when the record proves that no pixel of the tile can reach alpha >= 1/255; such pairs contribute
+ * exactly nothing, so image and gradients are bit-identical while ~1/3 of the pairs never reach the
+ * scatter, the sort and the compositing kernels.  ts_bin_scatter must be given the same pointer.
+ * Buffers stay sized by the bounding-box total I = cum_tiles_hit[n-1]. */
+int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float* splats,
+                 const ts_camera* cam_host, int32_t* bin_ws, void* stream);
 
 /* Turns the counts into bases in place (exclusive scan down the chunk axis, then over tiles) and
  * writes tile_bins[t] = {start, end} (both 0 for an empty tile). */
@@ -131,8 +137,8 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
 
 /* Writes the id of every Gaussian into the bucket of each tile its rectangle covers (bucket_ids[I];
  * order inside a bucket is arbitrary until ts_sort_tiles). */
-int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
-                   const int32_t* bin_ws, int32_t* bucket_ids, void* stream);
+int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const float* splats,
+                   const ts_camera* cam_host, const int32_t* bin_ws, int32_t* bucket_ids, void* stream);
 
 /* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort
  * of (tile<<32 | depth-bits) keys emitted Gaussian-major - reading bucket_ids[I] and depths[n] and

@@ -420,6 +420,42 @@ def test_one_node_frame_is_bitwise_the_fused_op_recipe():
         assert torch.equal(a, b)
 
 
+def test_tight_binning_drops_only_pairs_that_contribute_nothing():
+    """frame.TIGHT_BINNING: (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255 in the
+    tile never enter the lists.  Every output and every gradient is bitwise what gsplat's
+    bounding-box lists give, and each tight tile list is the bounding-box list with entries
+    removed (same order)."""
+    from tinysplat_amd import frame
+    n, w, h = 50000, 480, 270
+    g = torch.Generator().manual_seed(4)
+    w_rgb, w_d = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    for mult, seed in ((2.0, 5), (6.0, 6)):
+        model, cam = scene_args(n, 1, w, h, seed=seed, scale_mult=mult)
+        res, lists = [], []
+        try:
+            for tight in (False, True):
+                frame.TIGHT_BINNING = tight
+                md = model.to(DEV).requires_grad_(True)
+                r = GaussianRasterizer(md, None, device=torch.device(DEV))
+                rgb, ex = r(cam, (w, h), 1)
+                ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
+                b = frame.last_binning[0]
+                lists.append((b.tile_bins.cpu(), b.gaussian_ids_sorted.cpu()))
+                res.append([rgb.detach(), ex["depth"].detach(), ex["xys"].grad] + [p.grad for p in md.parameters()])
+        finally:
+            frame.TIGHT_BINNING = True
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        (bins0, ids0), (bins1, ids1) = lists
+        i0, i1 = int(bins0[:, 1].max()), int(bins1[:, 1].max())
+        assert i1 < 0.85 * i0, (i0, i1)                       # a third of the pairs goes away
+        for t in range(0, bins0.shape[0], 7):
+            a = ids0[bins0[t, 0]:bins0[t, 1]].tolist()
+            b = ids1[bins1[t, 0]:bins1[t, 1]].tolist()
+            it = iter(a)
+            assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
+
+
 def _raster_parity(args, h, w, atol_img=1e-5, use_alpha=True, seed=5):
     """fwd + bwd of rasterize_gaussians through the C ABI vs autograd of the float64 oracle."""
     a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in args]

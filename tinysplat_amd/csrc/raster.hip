@@ -56,8 +56,8 @@ namespace {
 #endif
 constexpr int kWaves = TS_RASTER_WAVES;   // tiles (= waves) per workgroup; waves never synchronise
 constexpr int kThreads = 64 * kWaves;
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLog2_255 = 7.994353436858858f;
+using ts::kLog2e;
+using ts::kLog2_255;
 
 #define TS_WAVE_SYNC()                                            \
     do {                                                          \
@@ -96,25 +96,6 @@ __device__ __forceinline__ int wave_max_int(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
     return v;
-}
-
-// Minimum over the rectangle dx in [xlo,xhi], dy in [ylo,yhi] of hA dx^2 + B dx dy + hC dy^2
-// (hA, hC > 0 assumed by the caller).
-__device__ __forceinline__ float min_form_on_rect(float hA, float B, float hC, float xlo, float xhi,
-                                                  float ylo, float yhi) {
-    if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return 0.0f;
-    float best = 3.0e38f;
-    const float inv2C = 0.5f / hC, inv2A = 0.5f / hA;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float dx = e ? xhi : xlo;
-        const float dy = fminf(fmaxf(-B * dx * inv2C, ylo), yhi);
-        best = fminf(best, hA * dx * dx + dy * (B * dx + hC * dy));
-        const float ey = e ? yhi : ylo;
-        const float ex = fminf(fmaxf(-B * ey * inv2A, xlo), xhi);
-        best = fminf(best, hC * ey * ey + ex * (B * ey + hA * ex));
-    }
-    return best;
 }
 
 // sigma * log2(e) for one pixel; explicit fmas so that forward and backward (which must replay the
@@ -181,17 +162,14 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
         const float tau = s.lo + kLog2_255;            // sigma' <= tau  <=>  alpha >= 1/255
         if (tau >= -0.02f) {
             if (s.hA > 0.0f && s.hC > 0.0f) {
+                const float inv2A = 0.5f / s.hA, inv2C = 0.5f / s.hC;
 #pragma unroll 1
                 for (int k = 0; k < 4; ++k) {           // rolled: runs once per 64 entries, keeps VGPRs low
                     if (!(blocks & (1 << k))) continue;
                     const float4 r = rects[k];          // {x0, x1, y0, y1}, wave-uniform
-                    const float xlo = s.gx - r.y, xhi = s.gx - r.x;
-                    const float ylo = s.gy - r.w, yhi = s.gy - r.z;
-                    const float m = min_form_on_rect(s.hA, s.B, s.hC, xlo, xhi, ylo, yhi);
-                    const float dxm = fmaxf(fabsf(xlo), fabsf(xhi));
-                    const float dym = fmaxf(fabsf(ylo), fabsf(yhi));
-                    const float mag = s.hA * dxm * dxm + s.hC * dym * dym + fabsf(s.B) * dxm * dym;
-                    if (m <= tau + 0.02f + 4.0e-6f * mag) s.mask |= (1 << k);
+                    if (ts::rect_may_contribute(s.hA, s.B, s.hC, inv2A, inv2C, tau, s.gx, s.gy, r.x, r.y, r.z,
+                                                r.w))
+                        s.mask |= (1 << k);
                 }
             } else {
                 s.mask = blocks;                        // not a PSD conic: no geometric cull
@@ -238,6 +216,7 @@ template <int CH, bool GENERAL>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
                                           float fpy0, float (&T)[4], int (&fidx)[4],
                                           float (&acc)[4][CH]) {
+#pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
@@ -459,6 +438,10 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
                                           float (&acc)[6 + CH], long long num_isects,
                                           float* __restrict__ partials,
                                           unsigned char* __restrict__ row_flags, int lane) {
+    // Every fused multiply-add below is written out; implicit contraction is switched off so that the
+    // GENERAL and the lean instantiation round identically (otherwise `acc[0] += -am * v_a` fuses
+    // in one and not in the other, and a gradient would depend on which chunk an entry lands in).
+#pragma clang fp contract(off)
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));

@@ -344,4 +344,45 @@ TS_HD void sh_basis(int degree, float dx, float dy, float dz, float* Y) {
     Y[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
 }
 
+// ---- conservative "can this Gaussian reach that pixel rectangle" test ---------------------------
+// Used by the compositing kernels (per 8x8 block, raster.hip: stage_splat) and by the tight tile
+// binning (per 16x16 tile, binning.hip).  Works in the log2 domain: with hA = log2e/2 * conic.x,
+// B = log2e * conic.y, hC = log2e/2 * conic.z the exponent is sigma' = hA dx^2 + B dx dy + hC dy^2 and
+// alpha >= 1/255  <=>  sigma' <= log2(opacity) + log2(255).
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLog2_255 = 7.994353436858858f;
+
+// Minimum over the rectangle dx in [xlo,xhi], dy in [ylo,yhi] of hA dx^2 + B dx dy + hC dy^2
+// (hA, hC > 0 assumed by the caller; inv2A = 0.5 / hA, inv2C = 0.5 / hC).
+TS_HD float min_form_on_rect(float hA, float B, float hC, float inv2A, float inv2C, float xlo,
+                             float xhi, float ylo, float yhi) {
+    if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return 0.0f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e ? xhi : xlo;
+        const float dy = fminf(fmaxf(-B * dx * inv2C, ylo), yhi);
+        best = fminf(best, hA * dx * dx + dy * (B * dx + hC * dy));
+        const float ey = e ? yhi : ylo;
+        const float ex = fminf(fmaxf(-B * ey * inv2A, xlo), xhi);
+        best = fminf(best, hC * ey * ey + ex * (B * ey + hA * ex));
+    }
+    return best;
+}
+
+// True unless NO sample position of the rectangle [x0,x1] x [y0,y1] can have alpha >= 1/255 for the
+// Gaussian centred at (gx, gy).  tau = log2(opacity) + log2(255).  The slack (0.02 in the exponent,
+// i.e. 1.4 % in alpha, plus a relative term for large offsets) covers the rounding of this bound and
+// of the per-pixel evaluation, so a false return is a proof that every pixel's alpha test fails.
+TS_HD bool rect_may_contribute(float hA, float B, float hC, float inv2A, float inv2C, float tau,
+                               float gx, float gy, float x0, float x1, float y0, float y1) {
+    const float xlo = gx - x1, xhi = gx - x0;
+    const float ylo = gy - y1, yhi = gy - y0;
+    const float m = min_form_on_rect(hA, B, hC, inv2A, inv2C, xlo, xhi, ylo, yhi);
+    const float dxm = fmaxf(fabsf(xlo), fabsf(xhi));
+    const float dym = fmaxf(fabsf(ylo), fabsf(yhi));
+    const float mag = hA * dxm * dxm + hC * dym * dym + fabsf(B) * dxm * dym;
+    return m <= tau + 0.02f + 4.0e-6f * mag;
+}
+
 }  // namespace ts

@@ -12,6 +12,7 @@ RGB + depth, and a single autograd node.  Results are those of the op-by-op path
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -21,6 +22,11 @@ from torch import Tensor
 from . import _lib
 from .ops import (TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
                   _tile_bounds, deg_from_sh)
+
+# Tight tile lists (see ts_bin_count): (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255
+# anywhere in the tile are dropped at binning time.  Results are bit-identical either way
+# (tests/test_gpu_parity.py); TS_TIGHT_BINNING=0 restores gsplat's bounding-box lists for A/B timing.
+TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
@@ -70,16 +76,17 @@ class _RenderFrame(torch.autograd.Function):
             cols = torch.cat([colors, depths[:, None]], dim=1) if with_depth else colors
             bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
             tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-            _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), cam, _ptr(bin_ws), s)
-            _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
             splats = torch.empty((max(n, 1), 12), **f32)
             _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1, _ptr(xys), _ptr(radii), _ptr(conics),
                   _ptr(cols), _ptr(opacities), _ptr(cum), cam, _ptr(splats), s)
+            tight = _ptr(splats) if TIGHT_BINNING else None      # drop pairs that cannot contribute
+            _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), tight, cam, _ptr(bin_ws), s)
+            _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
             total = pending.wait()                                # the one host sync of the path
             bucket_ids = torch.empty((max(total, 1),), **i32)
             ids = torch.empty((max(total, 1),), **i32)
             if total > 0:
-                _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), cam,
+                _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), tight, cam,
                       _ptr(bin_ws), _ptr(bucket_ids), s)
                 _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
                       _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
@@ -193,17 +200,18 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
             torch.cat([colors, depths[:, None]], dim=1, out=cols)
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-        _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), cam, _ptr(bin_ws), s)
-        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
         splats = torch.empty((max(n, 1), 12), **f32)
         _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1, _ptr(xys), _ptr(radii), _ptr(conics),
               _ptr(cols), _ptr(opacities), _ptr(cum), cam, _ptr(splats), s)
+        tight = _ptr(splats) if TIGHT_BINNING else None
+        _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), tight, cam, _ptr(bin_ws), s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
         total = pending.wait()
         bucket_ids = torch.empty((max(total, 1),), **i32)
         ids = torch.empty((max(total, 1),), **i32)
         if total > 0:
-            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), cam, _ptr(bin_ws),
-                  _ptr(bucket_ids), s)
+            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), tight, cam,
+                  _ptr(bin_ws), _ptr(bucket_ids), s)
             _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
                   _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
         out_img = torch.empty((_stripe_rows(cam), w, ch), **f32)

@@ -145,34 +145,67 @@ inline int bin_window_tiles(int n, int num_tiles) {
 }
 
 // Tight binning (splats != nullptr): a (Gaussian, tile) pair of the bounding box is dropped when the
-// packed record proves that no pixel of the 16x16 tile can reach alpha >= 1/255
-// (ts::rect_may_contribute - the same conservative bound the compositing kernels apply per 8x8
-// block).  Dropped pairs contribute exactly nothing to the image or to any gradient, so the frame is
-// bit-identical; on the random scenes ~36 % of the bounding-box pairs go away before the scatter,
-// the sort and the compositing kernels ever see them.  Count and scatter make the same decisions
-// (same code, same inputs).  With splats == nullptr the lists are gsplat's bounding-box lists.
+// packed record proves that no pixel of the 16x16 tile can reach alpha >= 1/255.  Dropped pairs
+// contribute exactly nothing to the image or to any gradient, so the frame is bit-identical; on the
+// random scenes ~36 % of the bounding-box pairs go away before the scatter, the sort and the
+// compositing kernels ever see them.  Count and scatter make the same decisions (same code, same
+// inputs).  With splats == nullptr the lists are gsplat's bounding-box lists.
+//
+// The level set {alpha >= 1/255} is the ellipse  hA dx^2 + B dx dy + hC dy^2 <= tau  (log2 domain,
+// d = pixel - centre).  Instead of testing every tile of the box, each tile ROW gets the x-interval
+// of the ellipse over the row's y-band in closed form: for a fixed dy the ellipse is the interval
+// (-B dy -+ sqrt(disc(dy))) / (2 hA) with disc = 4 hA tau - D4 dy^2, D4 = 4 hA hC - B^2; its left
+// end is convex and its right end concave in dy, so over a band the union is spanned by the band's
+// two ends and, when they lie in the band, the ellipse's leftmost / rightmost points.  tau carries
+// the same slack as ts::rect_may_contribute (evaluated for the farthest pixel of the box) and the
+// interval is widened by kTightEps pixels, which makes the kept set a superset of every pixel whose
+// alpha test can pass in the compositing kernels.
 constexpr int kTilePix = 16;              // tile edge in pixels (rasterize.py:19-20)
+constexpr float kTightEps = 0.02f;
 struct TightTest {
     bool cull_all, geometric;
-    float gx, gy, hA, B, hC, tau, inv2A, inv2C;
-    __device__ __forceinline__ TightTest(const float4* __restrict__ splats, int i) {
+    float gx, gy, hA, B, tau4A, D4, inv2A, dymax, dxext, dy_left;
+    __device__ __forceinline__ TightTest(const float4* __restrict__ splats, int i, float radius) {
         cull_all = false; geometric = false;
-        gx = gy = hA = B = hC = tau = inv2A = inv2C = 0.0f;
+        gx = gy = hA = B = tau4A = D4 = inv2A = dymax = dxext = dy_left = 0.0f;
         if (!splats) return;
         const float4 q0 = splats[3 * (size_t)i], q1 = splats[3 * (size_t)i + 1];
         gx = q0.x; gy = q0.y;
-        hA = 0.5f * ts::kLog2e * q0.w; B = ts::kLog2e * q1.x; hC = 0.5f * ts::kLog2e * q1.y;
+        hA = 0.5f * ts::kLog2e * q0.w; B = ts::kLog2e * q1.x;
+        const float hC = 0.5f * ts::kLog2e * q1.y;
         const float op = q0.z;
-        tau = __log2f(op) + ts::kLog2_255;
+        float tau = __log2f(op) + ts::kLog2_255;
         if (!(op > 0.0f) || !(tau >= -0.02f)) { cull_all = true; return; }
-        geometric = hA > 0.0f && hC > 0.0f;
-        if (geometric) { inv2A = 0.5f / hA; inv2C = 0.5f / hC; }
+        D4 = 4.0f * hA * hC - B * B;
+        if (!(hA > 0.0f && hC > 0.0f && D4 > 1e-12f * (hA * hC))) return;     // not safely PSD: keep the box
+        const float far = radius + (float)kTilePix;                            // farthest pixel offset
+        tau += 0.02f + 4.0e-6f * (hA + hC + fabsf(B)) * far * far;
+        geometric = true;
+        inv2A = 0.5f / hA;
+        tau4A = 4.0f * hA * tau;
+        dymax = sqrtf(tau4A / D4) + kTightEps;
+        dxext = sqrtf(4.0f * hC * tau / D4);
+        dy_left = B * dxext / (2.0f * hC);           // dy of the leftmost point (rightmost: -dy_left)
     }
-    __device__ __forceinline__ bool keep(int tx, int ty) const {
-        if (!geometric) return true;
-        const float x0 = (float)(tx * kTilePix), y0 = (float)(ty * kTilePix);
-        return ts::rect_may_contribute(hA, B, hC, inv2A, inv2C, tau, gx, gy, x0, x0 + (float)(kTilePix - 1), y0,
-                                       y0 + (float)(kTilePix - 1));
+    // tiles [lo, hi) of tile row ty (clipped to [minx, maxx)) the ellipse can reach
+    __device__ __forceinline__ void row_range(int ty, int minx, int maxx, int& lo, int& hi) const {
+        lo = minx; hi = maxx;
+        if (!geometric) return;
+        const float a = fmaxf((float)(ty * kTilePix) - gy - kTightEps, -dymax);
+        const float b = fminf((float)(ty * kTilePix + kTilePix - 1) - gy + kTightEps, dymax);
+        if (a > b) { hi = lo; return; }
+        const float sa = sqrtf(fmaxf(tau4A - D4 * a * a, 0.0f)), sb = sqrtf(fmaxf(tau4A - D4 * b * b, 0.0f));
+        float left = fminf((-B * a - sa) * inv2A, (-B * b - sb) * inv2A);
+        float right = fmaxf((-B * a + sa) * inv2A, (-B * b + sb) * inv2A);
+        if (dy_left >= a && dy_left <= b) left = -dxext;
+        if (-dy_left >= a && -dy_left <= b) right = dxext;
+        left = fminf(left, right);                                   // rounding near a tangent band
+        const float xl = gx + left - kTightEps, xr = gx + right + kTightEps;
+        // tile tx holds sample positions 16 tx .. 16 tx + 15
+        const int tlo = (int)ceilf((xl - (float)(kTilePix - 1)) * (1.0f / kTilePix));
+        const int thi = (int)floorf(xr * (1.0f / kTilePix)) + 1;
+        lo = max(lo, tlo); hi = min(hi, thi);
+        if (hi < lo) hi = lo;
     }
 };
 
@@ -193,13 +226,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        const TightTest tight(splats, i);
+        const TightTest tight(splats, i, (float)r);
         if (tight.cull_all) continue;
-        for (int ty = b.miny; ty < b.maxy; ++ty)
-            for (int tx = b.minx; tx < b.maxx; ++tx) {
+        for (int ty = b.miny; ty < b.maxy; ++ty) {
+            int lo, hi;
+            tight.row_range(ty, b.minx, b.maxx, lo, hi);
+            for (int tx = lo; tx < hi; ++tx) {
                 const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
-                if ((unsigned)t < (unsigned)tw && tight.keep(tx, ty)) atomicAdd(&hist[t], 1);
+                if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
             }
+        }
     }
     __syncthreads();
     int* dst = counts + (size_t)blockIdx.x * num_tiles + t0;
@@ -314,14 +350,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        const TightTest tight(splats, i);
+        const TightTest tight(splats, i, (float)r);
         if (tight.cull_all) continue;
-        for (int ty = b.miny; ty < b.maxy; ++ty)
-            for (int tx = b.minx; tx < b.maxx; ++tx) {
+        for (int ty = b.miny; ty < b.maxy; ++ty) {
+            int lo, hi;
+            tight.row_range(ty, b.minx, b.maxx, lo, hi);
+            for (int tx = lo; tx < hi; ++tx) {
                 const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
-                if ((unsigned)t < (unsigned)tw && tight.keep(tx, ty))
-                    bucket_ids[atomicAdd(&cursor[t], 1)] = i;
+                if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
             }
+        }
     }
 }
 

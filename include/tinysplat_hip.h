@@ -163,20 +163,27 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
 /* Front-to-back compositing.  out_img[rows,W,channels], final_Ts[rows,W], final_index[rows,W]
  * where rows = min(16*tile_rows, H - 16*tile_row0).  background: `channels` floats.  final_Ts and
  * final_index exist for the backward pass; both may be NULL together (forward-only rendering). */
-int ts_raster_fwd(int32_t channels, const ts_camera* cam_host, const int32_t* tile_bins,
+/* flags: TS_RASTER_CLAMP_RGB folds the adapter's clamp(rgb, max=1) (rasterize.py:45) into the store of
+ * channels 0..2; clamp_mask[rows,W] (bytes, may be NULL when no backward follows) then receives bit c
+ * where channel c passes gradient (value <= 1, torch's rule) for ts_raster_bwd. */
+#define TS_RASTER_CLAMP_RGB 2
+int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
-                  float* out_img, float* final_Ts, int32_t* final_index, void* stream);
+                  float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
+                  void* stream);
 
 /* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
  * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
  *   {S v_s, S v_s dx, S v_s dy, S v_s dx^2, S v_s dx dy, S v_s dy^2, v_c0, v_c1, v_c2, v_c3, -, -}
  * row_flags[I] (bytes) is zeroed by this call and set to 1 for every row written; rows whose flag
- * stays 0 keep stale contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL. */
+ * stays 0 keep stale contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL.
+ * clamp_mask: NULL, or the mask ts_raster_fwd wrote under TS_RASTER_CLAMP_RGB (v_out_img is then the
+ * gradient w.r.t. the clamped image and is zeroed where the clamp was active). */
 int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam_host,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
-                  const float* v_out_img, const float* v_out_alpha, float* partials,
-                  uint8_t* row_flags, void* stream);
+                  const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
+                  float* partials, uint8_t* row_flags, void* stream);
 
 /* Sums each Gaussian's flagged rows (a contiguous range of `partials`, fixed order => run-to-run
  * bit-reproducible gradients), applies the conic / opacity factors read from `splats`, and writes

@@ -52,7 +52,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_project_fwd(-3, *([None] * 5), None, 0, *([None] * 7)) == -1
     cam = _lib.TsCamera(1, 1, 0, 0, 16, 16, 1, 1, 0, 1, 1.0, 0.01)
     assert lib.ts_pack_splats(4, 5, 0, *([None] * 6), cam, None, None) == -1
-    assert lib.ts_raster_fwd(2, cam, *([None] * 8)) == -1
+    assert lib.ts_raster_fwd(2, 0, cam, *([None] * 9)) == -1
 
 
 def test_ops_refuse_cpu_tensors_and_product_never_imports_the_oracle():

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
     const float* __restrict__ background, float* __restrict__ out_img,
-    float* __restrict__ final_Ts, int* __restrict__ final_index) {
+    float* __restrict__ final_Ts, int* __restrict__ final_index, const int clamp_rgb,
+    unsigned char* __restrict__ clamp_mask) {
     __shared__ float4 lds_all[kWaves][64 * 3];
     __shared__ float4 rect_all[kWaves][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -361,8 +362,17 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             final_index[pix] = fidx[k];
         }
         float* o = out_img + pix * CH;
+        int pass = 0;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) o[c] = acc[k][c] + Tf * bg[c];
+        for (int c = 0; c < CH; ++c) {
+            float val = acc[k][c] + Tf * bg[c];
+            if (clamp_rgb && c < 3) {          // the adapter's clamp(rgb, max=1), rasterize.py:45
+                pass |= (val <= 1.0f) ? (1 << c) : 0;          // torch's rule: gradient passes at x <= max
+                val = fminf(val, 1.0f);
+            }
+            o[c] = val;
+        }
+        if (clamp_mask) clamp_mask[pix] = (unsigned char)pass;
     }
 }
 
@@ -513,6 +523,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float4* __restrict__ splats, const float* __restrict__ background,
     const float* __restrict__ final_Ts, const int* __restrict__ final_index,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
+    const unsigned char* __restrict__ clamp_mask,
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     __shared__ float4 lds_all[kWaves][64 * 4];
     __shared__ float4 rect_all[kWaves][4];
@@ -554,9 +565,10 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             fidx[k] = final_index[pix];
             T[k] = final_Ts[pix];
             float dotbg = 0.0f;
+            const int pass = clamp_mask ? clamp_mask[pix] : 7;   // backward of the fused clamp(max=1)
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                vo[k][c] = v_out_img[pix * CH + c];
+                vo[k][c] = (c >= 3 || (pass & (1 << c))) ? v_out_img[pix * CH + c] : 0.0f;
                 dotbg += bg[c] * vo[k][c];
             }
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
@@ -673,9 +685,10 @@ inline int launch_status() { return (int)hipGetLastError(); }
 
 extern "C" {
 
-int ts_raster_fwd(int32_t channels, const ts_camera* cam, const int32_t* tile_bins,
+int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
-                  float* out_img, float* final_Ts, int32_t* final_index, void* stream) {
+                  float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
+                  void* stream) {
     if (!cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0) return 0;
@@ -683,22 +696,23 @@ int ts_raster_fwd(int32_t channels, const ts_camera* cam, const int32_t* tile_bi
     const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
+    const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
     if (channels == 3)
         hipLaunchKernelGGL(raster_fwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,
-                           final_index);
+                           final_index, clamp, clamp ? clamp_mask : nullptr);
     else
         hipLaunchKernelGGL(raster_fwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,
-                           final_index);
+                           final_index, clamp, clamp ? clamp_mask : nullptr);
     return launch_status();
 }
 
 int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
-                  const float* v_out_img, const float* v_out_alpha, float* partials,
-                  uint8_t* row_flags, void* stream) {
+                  const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
+                  float* partials, uint8_t* row_flags, void* stream) {
     if (!cam || (channels != 3 && channels != 4) || num_intersects < 0) return TS_E_BADARG;
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0 || num_intersects == 0) return 0;
@@ -713,12 +727,12 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
     if (channels == 3)
         hipLaunchKernelGGL(raster_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials,
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials,
                            row_flags);
     else
         hipLaunchKernelGGL(raster_bwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
                            (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, partials,
+                           background, final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials,
                            row_flags);
     return launch_status();
 }

@@ -95,8 +95,9 @@ class _RenderFrame(torch.autograd.Function):
             out_img = torch.empty((rows, w, ch), **f32)
             final_Ts = torch.empty((rows, w), **f32)
             final_idx = torch.empty((rows, w), **i32)
-            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
-                  _ptr(bg), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx), s)
+            clamp_mask = torch.empty((rows, w), dtype=torch.uint8, device=dev)
+            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
+                  _ptr(bg), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx), _ptr(clamp_mask), s)
         b = TileBinning()
         b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
         b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
@@ -106,14 +107,14 @@ class _RenderFrame(torch.autograd.Function):
         ctx.opacity_shape = opacities.shape
         ctx.xys_out = xys
         ctx.save_for_backward(means, scales, quats, view34, projview, origin, radii, nth, cum,
-                              tile_bins, ids, splats, bg, final_Ts, final_idx, mask)
+                              tile_bins, ids, splats, bg, final_Ts, final_idx, mask, clamp_mask)
         ctx.mark_non_differentiable(xys, radii)
         return out_img, xys, radii
 
     @staticmethod
     def backward(ctx, v_img, _v_xys, _v_radii):
         (means, scales, quats, view34, projview, origin, radii, nth, cum, tile_bins, ids, splats, bg,
-         final_Ts, final_idx, mask) = ctx.saved_tensors
+         final_Ts, final_idx, mask, clamp_mask) = ctx.saved_tensors
         dev, n, ch, cam, total = means.device, ctx.n, ctx.ch, ctx.cam, ctx.total
         f32 = dict(dtype=torch.float32, device=dev)
         lib = _lib.load()
@@ -129,7 +130,7 @@ class _RenderFrame(torch.autograd.Function):
             row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
             _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, cam, _ptr(tile_bins), _ptr(ids),
                   _ptr(splats), _ptr(bg), _ptr(final_Ts), _ptr(final_idx), _ptr(v_img), None,
-                  _ptr(partials), _ptr(row_flags), s)
+                  _ptr(clamp_mask), _ptr(partials), _ptr(row_flags), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, 1, _ptr(nth), _ptr(cum),
                   _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                   _ptr(v_cols), _ptr(v_opac), s)
@@ -162,7 +163,7 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
     """Forward-only frame (the viewer's ``with torch.no_grad(): scene.render(camera)``,
     viewer.py:89-93): the kernels of ``render_frame`` without anything kept for a backward pass -
     no cov3d, clamp mask, final_Ts / final_index outputs, no autograd node.
-    -> (image[rows, W, 3 or 4] unclamped, xys[N,2], radii[N])."""
+    -> (image[rows, W, 3 or 4] with RGB clamped to <= 1, xys[N,2], radii[N])."""
     ps = [model.means, model.scales, model.quats, model.opacities, model.colors_dc, model.colors_rest,
           view34, projview, origin, model.background]
     dev = _need_hip(*ps)
@@ -215,8 +216,8 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
             _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
                   _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
         out_img = torch.empty((_stripe_rows(cam), w, ch), **f32)
-        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
-              _ptr(bg), _ptr(out_img), None, None, s)
+        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
+              _ptr(bg), _ptr(out_img), None, None, None, s)
     b = TileBinning()
     b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
     b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
@@ -227,7 +228,9 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
 def render_frame(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,
                  width: int, height: int, with_depth: bool = True,
                  tile_rows: Optional[Tuple[int, int]] = None, group=None):
-    """-> (image[rows, W, 3 or 4] (unclamped; channel 3 = depth), xys[N,2], radii[N]).
+    """-> (image[rows, W, 3 or 4], xys[N,2], radii[N]).  Channels 0..2 are the RGB image already
+    clamped to <= 1 (the adapter's rasterize.py:45, folded into the compositing kernels together with
+    its backward); channel 3, when asked for, is the unclamped depth map.
 
     ``group`` (a process group, or ``dist.group.WORLD``) makes backward sum the 2-D gradients over
     the ranks rendering the other stripes; ``None`` = single GPU, no collective.

@@ -462,9 +462,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1 if logit_opacity else 0, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
                                           _ptr(colors_c), _ptr(opac_c), _ptr(b.cum_tiles_hit), cam,
                                           _ptr(splats), s)
-            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
+            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 0, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
                                          _ptr(splats), _ptr(bg_c), _ptr(out_img), _ptr(final_Ts),
-                                         _ptr(final_idx), s)
+                                         _ptr(final_idx), None, s)
         out_alpha = 1.0 - final_Ts
         ctx.binning, ctx.ch, ctx.n = b, ch, n
         ctx.logit = 1 if logit_opacity else 0
@@ -499,7 +499,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, b.cam, _ptr(b.tile_bins),
                                          _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
-                                         _ptr(v_out_alpha), _ptr(partials), _ptr(row_flags), s)
+                                         _ptr(v_out_alpha), None, _ptr(partials), _ptr(row_flags), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, ctx.logit, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
                                               _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                                               _ptr(v_colors), _ptr(v_opacity), s)

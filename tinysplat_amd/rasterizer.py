@@ -126,7 +126,7 @@ class GaussianRasterizer:
                                  w, h, True)
             extras = {"depth": out[:, :, 3], "radii": radii, "xys": xys,
                       "camera": {"height": camera.height, "width": camera.width}}
-            return torch.clamp(out[:, :, :3], max=1.0), extras
+            return out[:, :, :3], extras           # clamp(max=1) is applied inside the kernels
         if prep:
             w, h = dims
             _, projview, _ = camera_on_device(camera, self.device)

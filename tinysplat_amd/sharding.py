@@ -108,7 +108,7 @@ def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_siz
         out, xys, _ = ops.render_frame(model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
                                        w, h, False, tile_rows, grp)
         y0 = 16 * tile_rows[0]
-        return torch.clamp(out, max=1.0), (y0, y0 + out.shape[0]), xys
+        return out, (y0, y0 + out.shape[0]), xys        # already clamped to <= 1 by the kernels
     if prep:      # exp / normalise / sigmoid folded into the kernels (see GaussianRasterizer)
         view, projview, _ = camera_on_device(camera, device)
         pa = [model.means, model.scales, 1., model.quats, view[:3, :], projview, camera.f_x,

@@ -203,8 +203,17 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
  * (2 floats per 32x32 tile: SSIM-map sum, |X-Y| sum) and, if v_image != NULL,
  *   v_image = w_l1 * sign(X - Y) + w_ssim * dSSIMsum/dX      (caller passes w_l1 = c_l1 / (3 H W),
  *                                                             w_ssim = -c_ssim / (3 (H-10)(W-10))).
- * ws: >= ts_photometric_ws_floats(H, W) floats; the partial sums start at ws + 9 (H-10)(W-10). */
+ * ws: >= ts_photometric_ws_floats(H, W) floats; the partial sums ({ssim, l1, -} per 32x32 tile)
+ * start at ws + 9 (H-10)(W-10). */
 int64_t ts_photometric_ws_floats(int32_t height, int32_t width);
+/* Same loss on the compositing kernels' own output: `image` has pixel_floats (3 or 4) floats per
+ * pixel; with 4, channel 3 is the rendered depth and, when depth_target[H,W] != NULL, the depth L1 of
+ * train.py:65-69 is evaluated too: per-tile sums {ssim, l1, depth l1} at ws + 9 (H-10)(W-10) (3 per
+ * tile) and v_image[..., 3] = w_depth * sign(depth - target) (0 without a target).  v_image has the
+ * layout of `image`.  Saves slicing / re-packing a 33 MB image and its gradient per training step. */
+int ts_photometric_loss_rgbd(int32_t height, int32_t width, int32_t pixel_floats, const float* image,
+                             const float* target, const float* depth_target, float w_l1,
+                             float w_ssim, float w_depth, float* ws, float* v_image, void* stream);
 int ts_photometric_loss(int32_t height, int32_t width, const float* image, const float* target,
                         float w_l1, float w_ssim, float* ws, float* v_image, void* stream);
 

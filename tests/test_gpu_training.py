@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import train_oracle as TO
-from tinysplat_amd.training import Adam, TrainStep, photometric_loss
+from tinysplat_amd.training import Adam, TrainStep, frame_loss, photometric_loss
 from tinysplat_amd.synthetic import make_scene
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +28,33 @@ def test_photometric_loss_and_gradient(h, w, lam):
     err = (xd.grad.cpu().double() / 3.0 - x64.grad).abs().max().item()
     assert err < 1e-5 * max(1.0, x64.grad.abs().max().item() * 1e3), err
     assert err < 2e-8 + 1e-4 * x64.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("h,w,with_depth", [(64, 96, True), (77, 131, False), (120, 50, True)])
+def test_frame_loss_on_rgbd_output_equals_the_separate_losses(h, w, with_depth):
+    """The fused loss on the adapter's [H, W, 4] output (train.py:58-69) vs autograd of the oracle's
+    photometric loss + a float64 depth L1."""
+    g = torch.Generator().manual_seed(h + w)
+    frame = torch.rand(h, w, 4, generator=g)
+    frame[:, :, 3] = 2.0 + 8.0 * frame[:, :, 3]
+    tgt = (frame[:, :, :3] + 0.2 * torch.randn(h, w, 3, generator=g)).clamp(0, 1)
+    dtgt = 2.0 + 8.0 * torch.rand(h, w, generator=g)
+    lam, lamd = 0.2, 0.3
+    x64 = frame.double().requires_grad_(True)
+    ref, ref_l1, ref_s = TO.photometric_loss(x64[:, :, :3], tgt.double(), lam)
+    ref_d = (x64[:, :, 3] - dtgt.double()).abs().mean()
+    total = ref + lamd * ref_d if with_depth else ref
+    total.backward()
+    xd = frame.to(DEV).requires_grad_(True)
+    loss, l1, s, ld = frame_loss(xd * 1.0, tgt.to(DEV), dtgt.to(DEV) if with_depth else None, lam, lamd)
+    (2.0 * loss).backward()
+    assert abs(loss.item() - total.item()) < 3e-6 and abs(l1.item() - ref_l1.item()) < 2e-6
+    assert abs(s.item() - ref_s.item()) < 2e-6
+    assert abs(ld.item() - (ref_d.item() if with_depth else 0.0)) < 2e-6
+    err = (xd.grad.cpu().double() / 2.0 - x64.grad).abs().max().item()
+    assert err < 2e-8 + 1e-4 * x64.grad.abs().max().item(), err
+    if not with_depth:
+        assert torch.all(xd.grad[:, :, 3] == 0)
 
 
 def test_ssim_of_identical_images_is_one():

@@ -44,7 +44,7 @@ class _PhotometricLoss(torch.autograd.Function):
             _call("ts_photometric_loss", lib.ts_photometric_loss, h, w, _ptr(image), _ptr(target),
                   (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo), _ptr(ws), _ptr(v_image),
                   _stream(dev))
-        sums = ws[9 * ho * wo:].view(-1, 2).sum(dim=0, dtype=torch.float64)
+        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
         ssim = sums[0] / (3.0 * ho * wo)
         l1 = sums[1] / (3.0 * h * w)
         loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim)).to(torch.float32)
@@ -56,6 +56,54 @@ class _PhotometricLoss(torch.autograd.Function):
     def backward(ctx, v_loss, _v_l1, _v_ssim):
         (v_image,) = ctx.saved_tensors
         return (None if v_image is None else v_image * v_loss), None, None
+
+
+class _FrameLoss(torch.autograd.Function):
+    """train.py:58-69 on the adapter's 4-channel output (RGB + depth) in one pair of launches."""
+
+    @staticmethod
+    def forward(ctx, frame, target, depth_target, lambda_dssim, lambda_depth):
+        dev = _need_hip(frame, target)
+        if frame.dim() != 3 or frame.shape[2] != 4 or not frame.is_contiguous():
+            raise ValueError("frame must be a contiguous [H, W, 4] tensor (RGB + depth)")
+        h, w = frame.shape[0], frame.shape[1]
+        if target.shape != (h, w, 3) or (depth_target is not None and depth_target.shape != (h, w)):
+            raise ValueError("target must be [H, W, 3] and depth_target [H, W]")
+        if h <= 10 or w <= 10:
+            raise ValueError("SSIM with an 11-tap window needs H, W > 10")
+        frame, target = _f32c(frame), _f32c(target)
+        dt = None if depth_target is None else _f32c(depth_target)
+        lib = _lib.load()
+        ws = torch.empty((int(lib.ts_photometric_ws_floats(h, w)),), dtype=torch.float32, device=dev)
+        v_frame = torch.empty_like(frame) if ctx.needs_input_grad[0] else None
+        ho, wo = h - 10, w - 10
+        lam, lamd = float(lambda_dssim), float(lambda_depth) if dt is not None else 0.0
+        with torch.cuda.device(dev):
+            _call("ts_photometric_loss_rgbd", lib.ts_photometric_loss_rgbd, h, w, 4, _ptr(frame),
+                  _ptr(target), _ptr(dt), (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo),
+                  lamd / (h * w), _ptr(ws), _ptr(v_frame), _stream(dev))
+        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
+        ssim = sums[0] / (3.0 * ho * wo)
+        l1 = sums[1] / (3.0 * h * w)
+        ldepth = sums[2] / (h * w)
+        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim) + lamd * ldepth).to(torch.float32)
+        ctx.save_for_backward(v_frame)
+        outs = (l1.to(torch.float32), ssim.to(torch.float32), ldepth.to(torch.float32))
+        ctx.mark_non_differentiable(*outs)
+        return (loss,) + outs
+
+    @staticmethod
+    def backward(ctx, v_loss, *_):
+        (v_frame,) = ctx.saved_tensors
+        return (None if v_frame is None else v_frame.mul_(v_loss)), None, None, None, None
+
+
+def frame_loss(frame: Tensor, target: Tensor, depth_target: Optional[Tensor] = None,
+               lambda_dssim: float = 0.2, lambda_depth: float = 0.2):
+    """Total training loss of train.py:58-69 on the adapter's [H, W, 4] output (RGB already clamped,
+    channel 3 = depth): ``(1-l) L1 + l (1 - SSIM) [+ l_depth * mean|depth - depth_target|]``.
+    Returns ``(loss, l1, ssim, depth_l1)``; differentiable w.r.t. ``frame``."""
+    return _FrameLoss.apply(frame, target, depth_target, lambda_dssim, lambda_depth)
 
 
 def photometric_loss(image: Tensor, target: Tensor, lambda_dssim: float = 0.2):
@@ -128,9 +176,17 @@ class TrainStep:
         """``densifier`` (densify.Densifier) + ``step`` add train.py:99-102 after the Adam update:
         gradient accumulation and, on the policy's steps, clone / split / prune."""
         rgb, extras = self.rasterizer(camera, None, self.model.active_sh_degree)
-        loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
-        if target_depth is not None:                          # train.py:65-69
-            loss = loss + self.lambda_depth * (extras["depth"] - target_depth).abs().mean()
+        frame = getattr(rgb, "_base", None)
+        if (frame is not None and frame.dim() == 3 and frame.shape[2] == 4 and frame.is_contiguous()
+                and extras["depth"]._base is frame):
+            # the adapter's one-node path hands out views of ONE [H, W, 4] tensor: evaluate the
+            # whole loss (train.py:58-69) on it in place, no slicing / re-packing of image or gradient
+            loss, l1, ssim, _ = frame_loss(frame, target_rgb, target_depth, self.lambda_dssim,
+                                           self.lambda_depth)
+        else:
+            loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
+            if target_depth is not None:                          # train.py:65-69
+                loss = loss + self.lambda_depth * (extras["depth"] - target_depth).abs().mean()
         loss.backward()
         self.optimizer.step()
         xys_grad = extras["xys"].grad                          # consumed by densification (F2)

@@ -378,6 +378,8 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
 
 // Butterfly merge of two per-lane partial vectors: lanes whose `bit` is clear keep a, the others
 // keep b, and each adds the kept quantity of its partner lane (partner given by the DPP control).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int CTRL>
 __device__ __forceinline__ float merge2(float a, float b, bool bit) {
     const float keep = bit ? b : a, send = bit ? a : b;
@@ -389,49 +391,50 @@ __device__ __forceinline__ float dpp_add_t(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
 }
 
-// Reduces eight per-lane values over the wave: on return every lane l holds the wave sum of
-// v[l & 7].  8 DPP adds + 14 selects + 2 ds_bpermute adds instead of 8 x 6 DPP adds.
-__device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+// Reduces ten per-lane values over the wave in one merged butterfly.  On return lane l holds the wave
+// sum of value (l & 7) if bit 3 of l is clear, of value 8 + (l & 1) otherwise.
+//   level 1  partner l ^ 1 (quad_perm):  5 merges, lanes with bit 0 keep the odd value of each pair
+//   level 2  partner l ^ 2 (quad_perm):  2 merges (bit 1) + 1 plain add for the {8,9} pair
+//   level 3  row_ror:4:                  1 merge (bit 2) + 1 plain add
+//   level 4  row_ror:8:                  1 merge (bit 3): values 0..7 | values 8,9  -> row-of-16 totals
+//   rows are combined lane-wise through the LDS crossbar (ds_bpermute; the single-lane row_bcast forms
+//   cannot be used because lanes of a row hold different values).
+// 31 VALU issues + 2 ds_bpermute for 10 values (a plain DPP reduction is 6-8 per value).
+__device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
     const float u0 = merge2<0xB1>(v[0], v[1], b0), u1 = merge2<0xB1>(v[2], v[3], b0);
     const float u2 = merge2<0xB1>(v[4], v[5], b0), u3 = merge2<0xB1>(v[6], v[7], b0);
+    float t = merge2<0xB1>(v[8], v[9], b0);
     const float w0 = merge2<0x4E>(u0, u1, b1), w1 = merge2<0x4E>(u2, u3, b1);
+    t = dpp_add_t<0x4E, 0xF>(t);
     float x = merge2<0x124>(w0, w1, b2);     // row_ror:4  (source lane differs in bit 2, same bits 1:0)
-    x = dpp_add_t<0x128, 0xF>(x);            // row_ror:8  -> row-of-16 totals, value (lane & 7)
-    // rows hold different values per lane, so the single-lane row_bcast forms cannot be used here:
-    // combine the four rows lane-wise through the LDS crossbar (ds_bpermute, no memory access)
+    t = dpp_add_t<0x124, 0xF>(t);
+    x = merge2<0x128>(x, t, b3);             // row_ror:8
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
     return x;
 }
 
 // Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
-// (lanes 48.. each store one float of the 40/48-byte row).
+// (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag).
 template <int CH>
 __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
                                           unsigned char* __restrict__ row_flags, int lane) {
-    float r8, rc[2] = {0.f, 0.f};
+    float r;
     if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
-        r8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        rc[0] = v[8];
+        r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + v[8];
     } else {
-        const float v8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-        r8 = wave_sum8(v8, lane);
+        float v10[10];
 #pragma unroll
-        for (int c = 8; c < 6 + CH; ++c) rc[c - 8] = wave_sum_hi(v[c]);
+        for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
+        r = wave_sum10(v10, lane);
     }
-    const int w = lane - 48;                                   // writer lanes 48 .. 48+5+CH
+    const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
     const long long slot = (long long)slot_i;
     if (w >= 0 && slot < num_isects) {
-        if (w < 6 + CH) {
-            float val = r8;
-            if (w == 8) val = rc[0];
-            if (CH == 4 && w == 9) val = rc[1];
-            partials[slot * TS_PARTIAL_ROW_FLOATS + w] = val;
-        } else if (w == 6 + CH) {
-            row_flags[slot] = 1;                               // this row now holds data
-        }
+        if (w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
+        else if (w == 10) row_flags[slot] = 1;                 // this row now holds data
     }
 }
 
@@ -470,7 +473,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
 
-        bool any = false;
+        int any = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
@@ -484,7 +487,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
                 validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
             }
             if (validm == 0ull) continue;                              // wave-uniform
-            any = true;
+            any = 1;
             const float am = TS_LANE(validm) ? a : 0.0f;
             const float ra = __builtin_amdgcn_rcpf(1.0f - am);
             const float Tk = T[k] * ra;                 // transmittance in front of the Gaussian
@@ -507,11 +510,22 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
             acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
         }
-        if (any) {                                                     // `any` is wave-uniform
+        // `any` is wave-uniform.  It is passed through an empty asm so that the compiler cannot prove
+        // "block 3 ran => a flush follows": with that knowledge it specialises the last block body
+        // (results in fresh registers) and pays for it with 10-17 register copies per entry on the
+        // joining paths; kept opaque, all four bodies accumulate in place and the flush reads acc.
+        asm volatile("" : "+s"(any));
+        if (any) {
             flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
                           partials, row_flags, lane);
+            // zero the accumulators two at a time (v_mov_b64 on a register pair)
 #pragma unroll
-            for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
+            for (int c = 0; c + 1 < 6 + CH; c += 2) {
+                f2 z = (f2)(0.0f);
+                asm volatile("" : "+v"(z));
+                acc[c] = z.x; acc[c + 1] = z.y;
+            }
+            if ((6 + CH) & 1) acc[5 + CH] = 0.0f;
         }
     }
 }

@@ -66,32 +66,6 @@ using ts::kLog2_255;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
 
-__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
-    // v + (v moved by the DPP control); lanes of disabled rows / without a source add 0
-    int moved;
-    switch (ctrl) {  // the builtin needs literal immediates
-        case 0xB1: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true); break;
-        case 0x4E: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true); break;
-        case 0x141: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); break;
-        case 0x140: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); break;
-        case 0x142: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true); break;
-        default: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true); break;
-    }
-    (void)row_mask;
-    return v + __int_as_float(moved);
-}
-
-// sum over the 64 lanes; the total is valid in lanes 48..63 (read it from lane 63)
-__device__ __forceinline__ float wave_sum_hi(float v) {
-    v = dpp_add(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-    v = dpp_add(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-    v = dpp_add(v, 0x141, 0xF);   // row_half_mirror
-    v = dpp_add(v, 0x140, 0xF);   // row_mirror      -> every lane holds its row-of-16 sum
-    v = dpp_add(v, 0x142, 0xA);   // row_bcast15     -> rows 1,3 += previous row
-    v = dpp_add(v, 0x143, 0xC);   // row_bcast31     -> rows 2,3 += rows 0+1
-    return v;
-}
-
 __device__ __forceinline__ int wave_max_int(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));

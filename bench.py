@@ -126,8 +126,8 @@ def cpu_baseline(seconds_budget: float = 20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
@@ -297,9 +297,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out now
+        # so that the JSON line is the last line of output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -374,11 +374,13 @@ __device__ __forceinline__ float dpp_add_t(float v) {
 //   rows are combined lane-wise through the LDS crossbar (ds_bpermute; the single-lane row_bcast forms
 //   cannot be used because lanes of a row hold different values).
 // 31 VALU issues + 2 ds_bpermute for 10 values (a plain DPP reduction is 6-8 per value).
+template <bool HAVE9>
 __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
     const float u0 = merge2<0xB1>(v[0], v[1], b0), u1 = merge2<0xB1>(v[2], v[3], b0);
     const float u2 = merge2<0xB1>(v[4], v[5], b0), u3 = merge2<0xB1>(v[6], v[7], b0);
-    float t = merge2<0xB1>(v[8], v[9], b0);
+    // without a tenth value the {8,9} "pair" is a plain add (both lanes of a pair then hold value 8)
+    float t = HAVE9 ? merge2<0xB1>(v[8], v[9], b0) : dpp_add_t<0xB1, 0xF>(v[8]);
     const float w0 = merge2<0x4E>(u0, u1, b1), w1 = merge2<0x4E>(u2, u3, b1);
     t = dpp_add_t<0x4E, 0xF>(t);
     float x = merge2<0x124>(w0, w1, b2);     // row_ror:4  (source lane differs in bit 2, same bits 1:0)
@@ -402,7 +404,7 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         float v10[10];
 #pragma unroll
         for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
-        r = wave_sum10(v10, lane);
+        r = wave_sum10<(CH == 4)>(v10, lane);
     }
     const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
     const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)

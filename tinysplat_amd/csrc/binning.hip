@@ -513,7 +513,7 @@ __device__ __forceinline__ void sort_bucket_block(const int* g, const float* __r
 //   4. each wave sorts whole sub-buckets (<= 256 keys) on its own, in place; the rare larger ones are
 //      sorted afterwards by the whole workgroup.
 // LDS (u64 units): scratch[4096] sample[1024] tables[1024] = 48 KiB.
-constexpr int kSampleMin = kSortCap;      // tiles up to this size use the plain network
+// tiles up to kSortCap keys use the plain network (one wave up to kWaveSortMax, the workgroup beyond)
 constexpr int kMaxSub = 512;              // sub-buckets per tile
 constexpr int kSubTarget = 96;            // mean keys per sub-bucket aimed at
 constexpr int kLargeLdsU64 = kSortCap + 2048;
@@ -616,20 +616,64 @@ __device__ __forceinline__ void sort_tile_sample(const int* __restrict__ g,
     }
 }
 
-// Two launches so that the common small tiles keep a small LDS footprint (occupancy): the first
-// kernel sorts every tile the network can hold and appends the others to a list; the second one is
-// a small persistent grid that walks that (normally empty) list.
+// One WAVE sorts one tile (n <= 64 E keys, E = 1..16 per lane): the whole bitonic network runs on
+// registers and lane exchanges, no LDS storage, no barrier, and the E independent keys of a lane
+// keep E exchanges in flight per stage.  Which key starts in which position is irrelevant to a sort,
+// so the ids are loaded coalesced (position e*64 + lane); the result is stored by position.
+constexpr int kWaveSortMax = 1024;
+template <int E>
+__device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
+                                               const float* __restrict__ depths,
+                                               int* __restrict__ out, int n, int lane) {
+    unsigned long long k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        k[e] = i < n ? make_key(depths, g[i]) : ~0ull;
+    }
+    bitonic_regs<E, 64>(k, lane, min(pow2_at_least(n), 64 * E), nullptr);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        if (i < n) out[i] = (int)(unsigned int)k[e];
+    }
+}
+
+// Three launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles
+// per workgroup) and lists the tiles beyond kSortCap; the second sorts the tiles in between with one
+// workgroup each; the third is a small persistent grid that walks the (normally empty) list with the
+// sample sort.
 __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
-    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    int num_tiles, const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_list) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
+    const int n = range.y - range.x;
+    if (n <= 0) return;
+    if (n > kWaveSortMax) {                      // (kWaveSortMax, kSortCap]: sort_tiles_mid_kernel
+        if (n > kSortCap && lane == 0) large_list[1 + atomicAdd(&large_list[0], 1)] = tile;
+        return;
+    }
+    const int* g = bucket_ids + range.x;
+    int* out = ids_sorted + range.x;
+    if (n <= 64) sort_tile_wave<1>(g, depths, out, n, lane);
+    else if (n <= 128) sort_tile_wave<2>(g, depths, out, n, lane);
+    else if (n <= 256) sort_tile_wave<4>(g, depths, out, n, lane);
+    else if (n <= 512) sort_tile_wave<8>(g, depths, out, n, lane);
+    else sort_tile_wave<16>(g, depths, out, n, lane);
+}
+
+// Tiles of kWaveSortMax < n <= kSortCap keys: one workgroup per tile, register network with LDS for the
+// cross-wave stages.  Launched over all tiles; the others leave at once.
+__global__ __launch_bounds__(kThreads) void sort_tiles_mid_kernel(
+    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
     __shared__ unsigned long long lk[kSortCap];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
     const int n = range.y - range.x;
-    if (n <= 0) return;
-    if (n > kSampleMin) {
-        if (threadIdx.x == 0) large_list[1 + atomicAdd(&large_list[0], 1)] = blockIdx.x;
-        return;
-    }
+    if (n <= kWaveSortMax || n > kSortCap) return;
     sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lk);
 }
 
@@ -790,8 +834,11 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins,
-                       depths, bucket_ids, gaussian_ids_sorted, sort_ws);
+    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3((num_tiles + kThreads / 64 - 1) / (kThreads / 64)),
+                       dim3(kThreads), 0, s, (int)num_tiles, tile_bins, depths, bucket_ids,
+                       gaussian_ids_sorted, sort_ws);
+    hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
+                       bucket_ids, gaussian_ids_sorted);
     const int grid = num_tiles < 768 ? num_tiles : 768;
     hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
                        bucket_ids, gaussian_ids_sorted, sort_ws);

@@ -214,15 +214,17 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
             const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dyv[k >> 1]);
             float a = __builtin_amdgcn_exp2f(-sgl);
-            bool ok = (a >= ts::kAlphaMin) & (T[k] > 0.0f);
+            bool ok = a >= ts::kAlphaMin;
             if (GENERAL) {
                 a = fminf(ts::kAlphaMax, a);
                 ok = ok & (sgl >= neg_lo);                            // sigma >= 0
             }
+            // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, so
+            // either `stop` fires and -|T| puts T back, or ae = 0 and nT = T; vis is 0 both ways.
             const float ae = ok ? a : 0.0f;
             const float nT = __builtin_fmaf(-ae, T[k], T[k]);
             const bool stop = (nT <= ts::kTEps) & ok;
-            const float Tn = stop ? -T[k] : nT;       // the stopping Gaussian is not composited
+            const float Tn = stop ? -__builtin_fabsf(T[k]) : nT;   // the stopping Gaussian is not composited
             const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);

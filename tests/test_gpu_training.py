@@ -101,3 +101,37 @@ def test_train_step_reduces_the_loss():
     losses = [step(cam, tgt, extras["depth"])["loss"].item() for _ in range(30)]
     assert losses[-1] < 0.7 * losses[0], losses[::5]
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_fit_loop_follows_the_reference_schedule():
+    """training.fit = scripts/train.py:45-106: SH degree schedule, random background, camera pick,
+    step, densification, on a two-camera toy problem."""
+    import numpy as np
+    from tinysplat_amd.densify import DensifyConfig, Densifier
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    from tinysplat_amd.synthetic import PinholeCamera
+    from tinysplat_amd.training import CameraSampler, Scheduler, fit
+    w, h = 160, 120
+    truth, cam0 = make_scene(3000, 1, w, h, seed=11, scale_mult=4.0)
+    cam1 = PinholeCamera.look_at_origin_plus_z(w, h, position=(0.3, 0.0, 0.0))
+    truth = truth.to(DEV)
+    truth.background = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        r = GaussianRasterizer(truth, None, device=torch.device(DEV))
+        tg = [r(c, None, 1)[0].clone() for c in (cam0, cam1)]
+    model, _ = make_scene(3000, 1, w, h, seed=12, scale_mult=4.0)
+    model = model.to(DEV)
+    model.active_sh_degree = 0
+    losses, degrees = [], []
+    dens = Densifier(model, DensifyConfig(warmup_densify=10, warmup_grad=5, interval_densify=10, tau_means=1e-7))
+    fit(model, [cam0, cam1], tg, DEV, 30, sh_increment_interval=8, max_sh_degree=1, densifier=dens,
+        rng=np.random.default_rng(0), generator=torch.Generator().manual_seed(0),
+        on_step=lambda s, o: (losses.append(float(o["loss"])), degrees.append(model.active_sh_degree)))
+    assert degrees[6] == 0 and degrees[7] == 1 and degrees[-1] == 1          # step 8 raises the degree, capped at 1
+    assert model.means.shape[0] != 3000                                         # densification fired (steps 10, 20, 30)
+    assert len(losses) == 30 and all(np.isfinite(losses))    # (that the loss falls is test_train_step_reduces_the_loss's job:
+                                                             #  here the background is random per step, train.py:51)
+    assert Scheduler(True, 3, 5)(3) and not Scheduler(True, 3, 5)(5) and not Scheduler(False, 0, 9)(1)
+    pick = CameraSampler(4, np.random.default_rng(1))
+    seq = [pick(s) for s in range(1, 10)]
+    assert all(0 <= i < 4 for i in seq)

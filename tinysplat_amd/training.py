@@ -198,3 +198,61 @@ class TrainStep:
         self.optimizer.zero_grad()
         return {"loss": loss.detach(), "l1": l1, "ssim": ssim, "radii": extras["radii"],
                 "xys_grad": xys_grad}
+
+
+class Scheduler:
+    """scripts/train.py:152-159."""
+
+    def __init__(self, active: bool, start: int, stop: int):
+        self.active, self.start, self.stop = active, start, stop
+
+    def __call__(self, step: int) -> bool:
+        return bool(self.active) and self.start <= step < self.stop
+
+
+class CameraSampler:
+    """Scene.get_random_camera (scene.py:207-216), condition for condition: a fresh permutation is
+    drawn whenever ``step % len(cameras) - 1`` is non-zero (i.e. on every step except those with
+    ``step % n == 1``), otherwise the cursor advances.  ``rng``: a numpy Generator (the reference
+    uses an unseeded one)."""
+
+    def __init__(self, num_cameras: int, rng=None):
+        import numpy as np
+        self.n = int(num_cameras)
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.order, self.cursor = None, 0
+
+    def __call__(self, step: int) -> int:
+        if step % self.n - 1 or self.order is None:
+            self.order, self.cursor = self.rng.permutation(self.n), 0
+        else:
+            self.cursor += 1
+        return int(self.order[self.cursor % self.n])
+
+
+def fit(model, cameras, targets, device, max_iter: int, depth_targets=None,
+        sh_increment_interval: int = 500, max_sh_degree: int = 3, lambda_dssim: float = 0.2,
+        lambda_depth: float = 0.2, depth_schedule: Optional[Scheduler] = None, densifier=None,
+        lrs: Optional[Dict[str, float]] = None, rng=None, generator: Optional[torch.Generator] = None,
+        on_step=None):
+    """The training loop of scripts/train.py:45-106 (steps 1-7) on in-memory cameras / targets:
+    SH degree schedule (:49-50, model_gaussian.py:126-128), random background (:51), camera pick
+    (:54), render + loss (:55-69), backward + Adam (:93-97), gradient accumulation and
+    densification (:99-102).  Dataset loading, the opacity / density regularisers of the surface
+    extension (:71-90), metrics and checkpoints stay with the caller (``on_step(step, out)``)."""
+    dev = torch.device(device)
+    step_fn = TrainStep(model, dev, lambda_dssim, lambda_depth, lrs)
+    pick = CameraSampler(len(cameras), rng)
+    out = None
+    for step in range(1, int(max_iter) + 1):
+        if step % sh_increment_interval == 0 and model.active_sh_degree < max_sh_degree:
+            model.active_sh_degree += 1
+        model.background = torch.rand(3, generator=generator).to(dev) if generator is not None \
+            else torch.rand(3, device=dev)
+        i = pick(step)
+        use_depth = depth_targets is not None and (depth_schedule is None or depth_schedule(step))
+        out = step_fn(cameras[i], targets[i], depth_targets[i] if use_depth else None,
+                      densifier=densifier, step=step)
+        if on_step is not None:
+            on_step(step, out)
+    return out

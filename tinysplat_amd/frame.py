@@ -4,11 +4,12 @@
 The three drop-in ops of ``ops.py`` each cost an autograd node, a dozen Python-level tensor
 allocations and a binning-cache lookup per frame; on small scenes and on multi-GPU stripes that
 host time (~0.5 ms) exceeds the GPU time.  This function enqueues the same kernels in the same order
-(project -> colour stage -> binning -> pack -> composite; backward: composite -> reduce ->
+(project -> scan -> colour stage -> pack -> binning -> composite; backward: composite -> reduce ->
 [all-reduce across stripes] -> colour stage -> project) with the adapter's exp / normalise / sigmoid
 folded in (``TS_PROJECT_*`` / ``TS_RASTER_LOGIT_OPACITY`` flags), one 4-channel compositing pass for
-RGB + depth, and a single autograd node.  Results are those of the op-by-op path
-(tests/test_gpu_frame.py).
+RGB + depth, tight tile lists, the adapter's clamp(max=1) inside the compositing kernels, and a single
+autograd node.  Results are bitwise those of the op-by-op path
+(tests/test_gpu_parity.py: test_one_node_frame_is_bitwise_the_fused_op_recipe).
 """
 from __future__ import annotations
 
@@ -57,10 +58,10 @@ class _RenderFrame(torch.autograd.Function):
         with torch.cuda.device(dev):
             xys = torch.empty((n, 2), **f32); depths = torch.empty((n,), **f32)
             radii = torch.empty((n,), **i32); conics = torch.empty((n, 3), **f32)
-            nth = torch.empty((n,), **i32); cov3d = torch.empty((n, 6), **f32)
+            nth = torch.empty((n,), **i32)
             _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means), _ptr(scales), _ptr(quats),
                   _ptr(view34), _ptr(projview), cam, 3, _ptr(xys), _ptr(depths), _ptr(radii),
-                  _ptr(conics), _ptr(nth), _ptr(cov3d), s)
+                  _ptr(conics), _ptr(nth), None, s)          # cov3d: the adapter discards it (rasterize.py:32)
             # binning, first half; the intersection count travels to the host while the kernels
             # that do not need it (colour stage, per-tile counts, offsets) run
             num_tiles = cam.tile_rows * cam.tile_bounds_x

@@ -69,3 +69,25 @@ def test_bad_files_raise(tmp_path):
         formats.load_checkpoint(tmp_path / "z.pth", DEV)
     with pytest.raises(RuntimeError):
         formats.ply_records(make_scene(10, 0, 64, 64)[0])       # CPU tensors: no fallback
+
+
+def test_empty_model_round_trips(tmp_path):
+    """N = 0: header-only PLY, empty tensors back; the frame path renders the background."""
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    from tinysplat_amd.synthetic import PinholeCamera, SplatModel
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    m = SplatModel(z(0, 3), z(0, 3), z(0, 3, 3), z(0, 3), z(0, 4), z(0, 1), active_sh_degree=1,
+                   background=torch.tensor([0.1, 0.2, 0.3], device=DEV))
+    formats.export_ply(m, tmp_path / "e.ply")
+    assert (tmp_path / "e.ply").read_bytes() == F.ply_header(0, 3)
+    back = formats.load_ply(tmp_path / "e.ply", DEV)
+    assert back.means.shape == (0, 3) and back.colors_rest.shape == (0, 3, 3) and back.active_sh_degree == 1
+    cam = PinholeCamera.look_at_origin_plus_z(64, 48)
+    m.requires_grad_(True)
+    rgb, extras = GaussianRasterizer(m, None, device=torch.device(DEV))(cam, None, 1)
+    assert rgb.shape == (48, 64, 3) and torch.allclose(rgb, m.background.expand(48, 64, 3))
+    (rgb.sum() + extras["depth"].sum()).backward()
+    assert m.means.grad.shape == (0, 3)
+    with torch.no_grad():
+        rgb2, _ = GaussianRasterizer(m, None, device=torch.device(DEV))(cam, None, 1)
+    assert torch.equal(rgb2, rgb.detach())

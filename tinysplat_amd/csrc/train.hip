@@ -81,7 +81,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 
 // Pass 1: per 32x32 tile of the SSIM map: the five filtered maps, the SSIM value (summed per block
 // into sums[block*2+0]) and the three partial-derivative maps dS/d filt(X), dS/d filt(X^2),
-// dS/d filt(XY) written to dmaps[3][Ho][Wo][3].  Also the L1 sum of the tile's own 32x32 pixels
+// dS/d filt(XY) written to dmaps[3][3 channels][Ho][Wo] (planar).  Also the L1 sum of the tile's own 32x32 pixels
 // (image tiles of the same grid cover the whole image; sums[block*2+1]).
 // X has `xs` floats per pixel (3: an RGB image; 4: the compositing kernels' RGB+depth output, whose
 // channel 3 is compared with the depth target D when D != nullptr, train.py:65-69).
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
             const float inv = 1.0f / (B1 * B2);
             const float S = A1 * A2 * inv;
             ssim_sum += S;
-            const size_t o = ((size_t)y * Wo + x) * 3 + c;
+            const size_t o = ((size_t)c * Ho + y) * Wo + x;      // planar per channel: coalesced in x
             const size_t plane = (size_t)Ho * Wo * 3;
             dmaps[o] = 2.0f * m2 * (A2 - A1) * inv - 2.0f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/d filt(X)
             dmaps[plane + o] = -S / B2;                                                        // d/d filt(X^2)
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, int xs
             const int y = y0 - kHalo + r, x = x0 - kHalo + q;
             float a = 0.f, b = 0.f, d = 0.f;
             if (y >= 0 && y < Ho && x >= 0 && x < Wo) {
-                const size_t o = ((size_t)y * Wo + x) * 3 + c;
+                const size_t o = ((size_t)c * Ho + y) * Wo + x;
                 a = dmaps[o]; b = dmaps[plane + o]; d = dmaps[2 * plane + o];
             }
             p0[r][q] = a; p1[r][q] = b; p2[r][q] = d;

@@ -100,20 +100,44 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
     const int Ho = H - kHalo, Wo = W - kHalo;
     const int ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
     float ssim_sum = 0.0f, l1_sum = 0.0f, depth_sum = 0.0f;
-    for (int c = 0; c < 3; ++c) {
-        for (int i = threadIdx.x; i < kPatch * kPatch; i += kThreads) {
-            const int r = i / kPatch, q = i % kPatch;
-            const int y = oy0 + r, x = ox0 + q;
-            float a = 0.0f, b = 0.0f;
-            if (y < H && x < W) {
-                a = X[((size_t)y * W + x) * xs + c];
-                b = Y[((size_t)y * W + x) * 3 + c];
-                if (r < kTile && q < kTile) {
-                    l1_sum += fabsf(a - b);
-                    if (c == 0 && D) depth_sum += fabsf(X[((size_t)y * W + x) * xs + 3] - D[(size_t)y * W + x]);
-                }
+    // every thread's share of the 42 x 42 pixel patch is fetched ONCE for the three channels (one
+    // 16-byte load per pixel of a 4-float image) instead of one strided 4-byte load per channel pass
+    constexpr int kShare = (kPatch * kPatch + kThreads - 1) / kThreads;
+    float xa[kShare][3], ya[kShare][3];
+#pragma unroll
+    for (int u = 0; u < kShare; ++u) {
+        const int i = threadIdx.x + u * kThreads;
+        const int r = i / kPatch, q = i % kPatch;
+        const int y = oy0 + r, x = ox0 + q;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xa[u][c] = ya[u][c] = 0.0f;
+        if (i < kPatch * kPatch && y < H && x < W) {
+            const size_t pix = (size_t)y * W + x;
+            float x3 = 0.0f;
+            if (xs == 4) {
+                const float4 v = reinterpret_cast<const float4*>(X)[pix];
+                xa[u][0] = v.x; xa[u][1] = v.y; xa[u][2] = v.z; x3 = v.w;
+            } else {
+                xa[u][0] = X[pix * 3]; xa[u][1] = X[pix * 3 + 1]; xa[u][2] = X[pix * 3 + 2];
             }
-            px[r][q] = a; py[r][q] = b;
+            ya[u][0] = Y[pix * 3]; ya[u][1] = Y[pix * 3 + 1]; ya[u][2] = Y[pix * 3 + 2];
+            if (r < kTile && q < kTile) {
+                l1_sum += fabsf(xa[u][0] - ya[u][0]);
+                l1_sum += fabsf(xa[u][1] - ya[u][1]);
+                l1_sum += fabsf(xa[u][2] - ya[u][2]);
+                if (D) depth_sum += fabsf(x3 - D[pix]);
+            }
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            if (i < kPatch * kPatch) {
+                const int r = i / kPatch, q = i % kPatch;
+                px[r][q] = c == 0 ? xa[u][0] : (c == 1 ? xa[u][1] : xa[u][2]);
+                py[r][q] = c == 0 ? ya[u][0] : (c == 1 ? ya[u][1] : ya[u][2]);
+            }
         }
         __syncthreads();
         // horizontal pass: 42 rows x 32 columns, five quantities.  One item = kStrip adjacent
@@ -194,6 +218,11 @@ __global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, int xs
     const int Ho = H - kHalo, Wo = W - kHalo;
     const size_t plane = (size_t)Ho * Wo * 3;
     const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;     // image tile
+    // each thread owns kStrip vertically adjacent pixels of the 32 x 32 tile: their gradients are
+    // collected over the three channel passes and stored once (one 16-byte store per pixel of a
+    // 4-float image) instead of three strided 4-byte stores
+    static_assert(kTile * (kTile / kStrip) == kThreads, "one strip per thread");
+    float gacc[kStrip][3];
     for (int c = 0; c < 3; ++c) {
         // map patch needed: rows y0-10 .. y0+31, cols x0-10 .. x0+31
         for (int i = threadIdx.x; i < kPatch * kPatch; i += kThreads) {
@@ -228,18 +257,30 @@ __global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, int xs
             const float xv = X[pix * xs + c], yv = Y[pix * 3 + c];
             const float diff = xv - yv;
             const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-            gX[pix * xs + c] = w_l1 * sgn + w_ssim * (a + 2.0f * xv * b + yv * d);
-            if (c == 0 && xs == 4) {                 // gradient of the depth channel (zero without a target)
-                float gd = 0.0f;
+            const float gv = w_l1 * sgn + w_ssim * (a + 2.0f * xv * b + yv * d);
+            if (c == 0) gacc[j][0] = gv; else if (c == 1) gacc[j][1] = gv; else gacc[j][2] = gv;
+          }
+        }
+        __syncthreads();
+    }
+    {
+        const int q = threadIdx.x % kTile, r0 = (threadIdx.x / kTile) * kStrip;
+#pragma unroll
+        for (int j = 0; j < kStrip; ++j) {
+            const int y = y0 + r0 + j, x = x0 + q;
+            if (y >= H || x >= W) continue;
+            const size_t pix = (size_t)y * W + x;
+            if (xs == 4) {
+                float gd = 0.0f;                     // gradient of the depth channel (zero without a target)
                 if (D) {
                     const float dd = X[pix * 4 + 3] - D[pix];
                     gd = w_depth * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f));
                 }
-                gX[pix * 4 + 3] = gd;
+                reinterpret_cast<float4*>(gX)[pix] = make_float4(gacc[j][0], gacc[j][1], gacc[j][2], gd);
+            } else {
+                gX[pix * 3] = gacc[j][0]; gX[pix * 3 + 1] = gacc[j][1]; gX[pix * 3 + 2] = gacc[j][2];
             }
-          }
         }
-        __syncthreads();
     }
 }
 

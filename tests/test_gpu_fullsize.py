@@ -124,3 +124,45 @@ def test_gradient_of_colours_is_the_weight_image(frame):
     assert (wgt >= 0).all() and torch.all(ra[5].grad[:, 1:] == 0)
     tot, ref = wgt.double().sum().item(), alpha.double().sum().item()
     assert abs(tot - ref) / ref < 1e-5
+
+
+def test_frame_path_at_full_size_tight_lists_stripes_and_forward_only():
+    """Config 3 through the adapter's one-node path: (i) tight tile lists vs gsplat's bounding-box
+    lists - bitwise the same image, depth and parameter gradients, with a third fewer listed pairs;
+    (ii) the tile-row stripes of two 'ranks' tile the full frame bitwise; (iii) the no-grad
+    (viewer) frame equals the training-mode forward bitwise."""
+    from tinysplat_amd import frame
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    from tinysplat_amd.sharding import render_rgb_stripe, stripe_rows
+    model, cam = scene_args(N, 3, W, H, seed=0)
+    g = torch.Generator().manual_seed(5)
+    w_rgb = torch.rand(H, W, 3, generator=g).to(DEV)
+    w_d = torch.rand(H, W, generator=g).to(DEV)
+    res, listed = [], []
+    try:
+        for tight in (False, True):
+            frame.TIGHT_BINNING = tight
+            md = model.to(DEV).requires_grad_(True)
+            r = GaussianRasterizer(md, None, device=torch.device(DEV))
+            rgb, ex = r(cam, (W, H), 3)
+            ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
+            listed.append(int(frame.last_binning[0].tile_bins[:, 1].max()))
+            res.append([rgb.detach(), ex["depth"].detach(), ex["xys"].grad] + [p.grad for p in md.parameters()])
+    finally:
+        frame.TIGHT_BINNING = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert listed[1] < 0.75 * listed[0]
+    rgb_full = res[1][0]
+    with torch.no_grad():
+        rgb_view, ex_view = r(cam, (W, H), 3)
+    assert torch.equal(rgb_view, rgb_full) and torch.equal(ex_view["depth"], res[1][1])
+    tby = (H + 15) // 16
+    parts = []
+    for rank in range(2):
+        with torch.no_grad():
+            part, (y0, y1), _ = render_rgb_stripe(md, cam, (W, H), r.ops, torch.device(DEV), rank, 2,
+                                                  tile_rows=stripe_rows(tby, 2, rank), collective=False)
+        assert part.shape[0] == y1 - y0
+        parts.append(part)
+    assert torch.equal(torch.cat(parts, dim=0), rgb_full)

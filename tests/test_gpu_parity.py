@@ -7,6 +7,8 @@ the reference tensor where that exceeds 1).  Compositing has two discrete per-pi
 threshold are excluded from value checks - there a 1-ulp difference in exp() legitimately flips a
 whole contribution - and their fraction is asserted to be tiny.
 """
+import math
+
 import pytest
 import torch
 
@@ -462,6 +464,37 @@ def test_tight_binning_drops_only_pairs_that_contribute_nothing():
             b = ids1[bins1[t, 0]:bins1[t, 1]].tolist()
             it = iter(a)
             assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
+
+
+def test_tight_binning_stress_anisotropic_faint_and_opaque():
+    """Needle-like and huge Gaussians, opacities from just above 1/255 to > 0.999, centres on and off
+    the image: the tight lists must still give bitwise the bounding-box result."""
+    from tinysplat_amd import frame
+    n, w, h = 60000, 416, 240
+    model, cam = scene_args(n, 0, w, h, seed=33, scale_mult=1.0)
+    g = torch.Generator().manual_seed(34)
+    z = model.means[:, 2:3]
+    model.scales = torch.log(z) + torch.empty(n, 3).uniform_(math.log(2e-4), math.log(0.25), generator=g)
+    logit = torch.empty(n, 1).uniform_(-5.6, 9.0, generator=g)          # sigmoid: 0.0037 .. 0.9999
+    logit[: n // 10] = -5.53 + 0.02 * torch.rand(n // 10, 1, generator=g)   # right at alpha = 1/255
+    model.opacities = logit
+    wr = torch.rand(h, w, 3, generator=g).to(DEV)
+    wd = torch.rand(h, w, generator=g).to(DEV)
+    res, listed = [], []
+    try:
+        for tight in (False, True):
+            frame.TIGHT_BINNING = tight
+            md = model.to(DEV).requires_grad_(True)
+            rgb, ex = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), 0)
+            ((rgb * wr).sum() + (ex["depth"] * wd).sum()).backward()
+            listed.append(int(frame.last_binning[0].tile_bins[:, 1].max()))
+            res.append([rgb.detach(), ex["depth"].detach(), ex["xys"].grad] + [p.grad for p in md.parameters()])
+    finally:
+        frame.TIGHT_BINNING = True
+    assert listed[1] < listed[0]
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[1][0]).all() and all(torch.isfinite(t).all() for t in res[1][3:])
 
 
 def _raster_parity(args, h, w, atol_img=1e-5, use_alpha=True, seed=5):

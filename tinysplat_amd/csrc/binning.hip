@@ -119,7 +119,10 @@ __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restri
 // fastest split - larger chunks with several tile windows make the runs written into a bucket
 // longer but re-read every Gaussian once per window and lost 10-30 %.
 constexpr int kBinThreads = 512;
-constexpr int kBinChunkMin = 4096;        // Gaussians per chunk (at least)
+#ifndef TS_BIN_CHUNK
+#define TS_BIN_CHUNK 4096
+#endif
+constexpr int kBinChunkMin = TS_BIN_CHUNK;  // Gaussians per chunk (at least)
 constexpr int kBinMaxChunks = 512;
 constexpr int kBinWindowMax = 36864;      // tiles per LDS window (144 KiB of the 160 KiB LDS)
 constexpr int kBinTargetBlocks = 1;       // chunks x windows aimed at (1 = no extra windows)

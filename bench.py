@@ -143,6 +143,11 @@ def main():
                     help="time the no_grad forward frame only (the viewer path, SURVEY 8(f) F4)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="single-GPU estimate of the per-rank step at this many tile-row stripes: renders "
+                         "only stripe --emulate-rank of that many (with --force-dist the 1-rank all-reduce "
+                         "runs too); the printed value is NOT a multi-GPU measurement")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--config", type=int, default=None,
                     help="BASELINE.json config shortcut: 2 = 100k/1080p, 3 = 1M/1080p (default), "
                          "5 = 5M/4K with depth")
@@ -204,8 +209,13 @@ def main():
             rgb, extras = adapter(cam, (w, h), sh)
             loss = (rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()
         else:
-            rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev, rank, world,
-                                                 collective=True if args.force_dist else None)
+            if args.emulate_ranks > 1 and world == 1:
+                rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev,
+                                                     args.emulate_rank, args.emulate_ranks,
+                                                     collective=bool(args.force_dist))
+            else:
+                rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev, rank, world,
+                                                     collective=True if args.force_dist else None)
             loss = (rgb * w_rgb[y0:y1]).sum()
         loss.backward()
 

@@ -167,6 +167,11 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
  * channels 0..2; clamp_mask[rows,W] (bytes, may be NULL when no backward follows) then receives bit c
  * where channel c passes gradient (value <= 1, torch's rule) for ts_raster_bwd. */
 #define TS_RASTER_CLAMP_RGB 2
+/* TS_RASTER_SPLIT_BLOCKS: four waves per tile, one per 8x8 block (same results per pixel).  For launches
+ * with fewer tiles than the GPU has SIMDs (a tile-row stripe of a multi-GPU frame, a small image).  In
+ * ts_raster_bwd / ts_reduce_partials the flag makes every (tile, Gaussian) own FOUR partial rows (slot
+ * 4 s + block): partials must hold 4 * num_intersects rows and row_flags 4 * num_intersects bytes. */
+#define TS_RASTER_SPLIT_BLOCKS 4
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
@@ -179,7 +184,7 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, co
  * stays 0 keep stale contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL.
  * clamp_mask: NULL, or the mask ts_raster_fwd wrote under TS_RASTER_CLAMP_RGB (v_out_img is then the
  * gradient w.r.t. the clamped image and is zeroed where the clamp was active). */
-int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam_host,
+int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const ts_camera* cam_host,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
                   const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,

@@ -466,6 +466,36 @@ def test_tight_binning_drops_only_pairs_that_contribute_nothing():
             assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
 
 
+def test_split_blocks_mapping_matches_one_wave_per_tile():
+    """TS_RASTER_SPLIT_BLOCKS (four waves per tile, one per 8x8 block; used for launches with few
+    tiles): the image, depth and transmittance decisions are bitwise those of the one-wave-per-tile
+    mapping; gradients agree to rounding (four partial rows per pair are summed instead of one)."""
+    from tinysplat_amd import frame
+    n, w, h = 40000, 336, 208          # 21 x 13 = 273 tiles, image not a multiple of 16
+    model, cam = scene_args(n, 1, w, h, seed=41, scale_mult=4.0)
+    g = torch.Generator().manual_seed(42)
+    wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    res = []
+    keep = frame.SPLIT_BLOCKS_BELOW
+    try:
+        for below in (0, 1 << 30):
+            frame.SPLIT_BLOCKS_BELOW = below
+            md = model.to(DEV).requires_grad_(True)
+            r = GaussianRasterizer(md, None, device=torch.device(DEV))
+            rgb, ex = r(cam, (w, h), 1)
+            ((rgb * wr).sum() + (ex["depth"] * wd).sum()).backward()
+            with torch.no_grad():
+                rgb_v, _ = r(cam, (w, h), 1)
+            assert torch.equal(rgb_v, rgb.detach())
+            res.append([rgb.detach(), ex["depth"].detach(), ex["xys"].grad] + [p.grad for p in md.parameters()])
+    finally:
+        frame.SPLIT_BLOCKS_BELOW = keep
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2:], res[1][2:]):
+        tol = 2e-6 * max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
+
+
 def test_tight_binning_stress_anisotropic_faint_and_opaque():
     """Needle-like and huge Gaussians, opacities from just above 1/255 to > 0.999, centres on and off
     the image: the tight lists must still give bitwise the bounding-box result."""

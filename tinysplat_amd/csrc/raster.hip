@@ -236,7 +236,11 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
 // that position in each of the four blocks k of the 16x16 tile.
-template <int CH>
+// SPLIT: four waves per tile, each owning ONE 8x8 block (the other three count as outside the image).
+// Same list, same arithmetic per pixel; used when a launch has fewer tiles than the GPU has SIMDs (a
+// tile-row stripe of a multi-GPU frame, a small image), where one wave per tile leaves the vector ALUs
+// without a second wave to switch to and the launch takes as long as the longest tile list.
+template <int CH, bool SPLIT>
 __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
@@ -246,8 +250,11 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     __shared__ float4 lds_all[kWaves][64 * 3];
     __shared__ float4 rect_all[kWaves][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
-    if (tile >= num_tiles) return;
+    const int units = SPLIT ? 4 * num_tiles : num_tiles;
+    const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
+    if (unit >= units) return;
+    const int tile = SPLIT ? unit >> 2 : unit;
+    const int only = SPLIT ? unit & 3 : -1;
     float4* lds = lds_all[wave];
     float4* rects = rect_all[wave];
     const int tbx = cam.tile_bounds_x;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     int live = 0;                                   // blocks that still have unfinished pixels
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H);
+        inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H) && (!SPLIT || k == only);
         T[k] = inside[k] ? 1.0f : -1.0f;
         fidx[k] = 0;
 #pragma unroll
@@ -509,7 +516,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
     }
 }
 
-template <int CH>
+template <int CH, bool SPLIT>
 __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
@@ -521,8 +528,11 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     __shared__ float4 lds_all[kWaves][64 * 4];
     __shared__ float4 rect_all[kWaves][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = xcd_tile_group((num_tiles + kWaves - 1) / kWaves) * kWaves + wave;
-    if (tile >= num_tiles) return;
+    const int units = SPLIT ? 4 * num_tiles : num_tiles;
+    const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
+    if (unit >= units) return;
+    const int tile = SPLIT ? unit >> 2 : unit;
+    const int only = SPLIT ? unit & 3 : -1;       // SPLIT: this wave owns block `only`, row slot*4 + only
     float4* rects = rect_all[wave];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     if (range.y <= range.x) return;
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
-        const bool inside = (px < W) && (py < H);
+        const bool inside = (px < W) && (py < H) && (!SPLIT || k == only);
         fidx[k] = -1;
         T[k] = 1.0f;
         R[k] = 0.0f;
@@ -615,7 +625,8 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
         const int cnt = __popcll(mask);
         if (keep) {
             const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            const int slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
+            int slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
+            if (SPLIT) slot = 4 * slot + only;       // one partial row per (tile, Gaussian, block)
             lds[4 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
             lds[4 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
             lds[4 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(slot));
@@ -646,12 +657,26 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     const int cnt = num_tiles_hit[i];
     const long long end = cum_tiles_hit[i];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    for (long long s = end - cnt; s < end; ++s) {
-        if (!row_flags[s]) continue;          // never written this pass (stale contents)
+    auto add_row = [&](long long s) {
         const float4 p0 = partials[3 * s], p1 = partials[3 * s + 1], p2 = partials[3 * s + 2];
         a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
         a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
         a2.x += p2.x; a2.y += p2.y;
+    };
+    if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
+        const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
+        for (long long s = end - cnt; s < end; ++s) {
+            const unsigned int f = flags4[s];
+            if (f == 0u) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (f & (0xffu << (8 * k))) add_row(4 * s + k);
+        }
+    } else {
+        for (long long s = end - cnt; s < end; ++s) {
+            if (!row_flags[s]) continue;          // never written this pass (stale contents)
+            add_row(s);
+        }
     }
     float vx = 0.f, vy = 0.f, vop = 0.f;
     if (cnt > 0) {
@@ -686,22 +711,23 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const i
     const int nt = cam->tile_rows * cam->tile_bounds_x;
     if (nt <= 0) return 0;
     if (!tile_bins || !background || !out_img || (!final_Ts != !final_index)) return TS_E_BADARG;
-    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
+    const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    const int units = split ? 4 * nt : nt;
+    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-    if (channels == 3)
-        hipLaunchKernelGGL(raster_fwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,
-                           final_index, clamp, clamp ? clamp_mask : nullptr);
-    else
-        hipLaunchKernelGGL(raster_fwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,
-                           final_index, clamp, clamp ? clamp_mask : nullptr);
+#define TS_LAUNCH_FWD(C, S)                                                                        \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,       \
+                       tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,           \
+                       final_index, clamp, clamp ? clamp_mask : nullptr)
+    if (channels == 3) { if (split) TS_LAUNCH_FWD(3, true); else TS_LAUNCH_FWD(3, false); }
+    else { if (split) TS_LAUNCH_FWD(4, true); else TS_LAUNCH_FWD(4, false); }
+#undef TS_LAUNCH_FWD
     return launch_status();
 }
 
-int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam,
+int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const ts_camera* cam,
                   const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
                   const float* background, const float* final_Ts, const int32_t* final_index,
                   const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
@@ -713,20 +739,19 @@ int ts_raster_bwd(int32_t channels, int64_t num_intersects, const ts_camera* cam
         !v_out_img || !partials || !row_flags)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects, s);
+    const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * (split ? 4 : 1), s);
     if (e != hipSuccess) return (int)e;
-    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
+    const int units = split ? 4 * nt : nt;
+    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
-    if (channels == 3)
-        hipLaunchKernelGGL(raster_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials,
-                           row_flags);
-    else
-        hipLaunchKernelGGL(raster_bwd_kernel<4>, dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp,
-                           background, final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials,
-                           row_flags);
+#define TS_LAUNCH_BWD(C, S)                                                                        \
+    hipLaunchKernelGGL((raster_bwd_kernel<C, S>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,       \
+                       (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp, background,  \
+                       final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials, row_flags)
+    if (channels == 3) { if (split) TS_LAUNCH_BWD(3, true); else TS_LAUNCH_BWD(3, false); }
+    else { if (split) TS_LAUNCH_BWD(4, true); else TS_LAUNCH_BWD(4, false); }
+#undef TS_LAUNCH_BWD
     return launch_status();
 }
 

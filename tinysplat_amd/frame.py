@@ -29,6 +29,11 @@ from .ops import (TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_
 # (tests/test_gpu_parity.py); TS_TIGHT_BINNING=0 restores gsplat's bounding-box lists for A/B timing.
 TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 
+# Launches with at most this many tiles (a stripe of a multi-GPU frame, a small image) composite with
+# four waves per tile, one per 8x8 block (TS_RASTER_SPLIT_BLOCKS): an MI355X has 1024 SIMDs, and with
+# one wave per tile such launches cannot hide any latency.  0 disables.
+SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
+
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
 
@@ -97,13 +102,14 @@ class _RenderFrame(torch.autograd.Function):
             final_Ts = torch.empty((rows, w), **f32)
             final_idx = torch.empty((rows, w), **i32)
             clamp_mask = torch.empty((rows, w), dtype=torch.uint8, device=dev)
-            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
+            split = 4 if 0 < num_tiles <= SPLIT_BLOCKS_BELOW else 0      # TS_RASTER_SPLIT_BLOCKS
+            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2 | split, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
                   _ptr(bg), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx), _ptr(clamp_mask), s)
         b = TileBinning()
         b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
         b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
         last_binning[dev.index] = b
-        ctx.cam, ctx.ch, ctx.n, ctx.nb, ctx.total = cam, ch, n, nb, total
+        ctx.cam, ctx.ch, ctx.n, ctx.nb, ctx.total, ctx.split = cam, ch, n, nb, total, split
         ctx.sh_degree, ctx.group = int(sh_degree), group
         ctx.opacity_shape = opacities.shape
         ctx.xys_out = xys
@@ -127,12 +133,13 @@ class _RenderFrame(torch.autograd.Function):
             v_conic = flat[2 * n:5 * n].view(n, 3)
             v_cols = flat[5 * n:(5 + ch) * n].view(n, ch)
             v_opac = flat[(5 + ch) * n:]
-            partials = torch.empty((max(total, 1), 12), **f32)
-            row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
-            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, cam, _ptr(tile_bins), _ptr(ids),
+            rows = max(total, 1) * (4 if ctx.split else 1)
+            partials = torch.empty((rows, 12), **f32)
+            row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
+            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, ctx.split, total, cam, _ptr(tile_bins), _ptr(ids),
                   _ptr(splats), _ptr(bg), _ptr(final_Ts), _ptr(final_idx), _ptr(v_img), None,
                   _ptr(clamp_mask), _ptr(partials), _ptr(row_flags), s)
-            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, 1, _ptr(nth), _ptr(cum),
+            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, 1 | ctx.split, _ptr(nth), _ptr(cum),
                   _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
                   _ptr(v_cols), _ptr(v_opac), s)
             if ctx.group is not None:                          # tile-stripe sharding: sum over ranks
@@ -217,7 +224,8 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
             _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
                   _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
         out_img = torch.empty((_stripe_rows(cam), w, ch), **f32)
-        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
+        split = 4 if 0 < num_tiles <= SPLIT_BLOCKS_BELOW else 0
+        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2 | split, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
               _ptr(bg), _ptr(out_img), None, None, None, s)
     b = TileBinning()
     b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total

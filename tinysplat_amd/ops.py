@@ -496,7 +496,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):
-            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, total, b.cam, _ptr(b.tile_bins),
+            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, 0, total, b.cam, _ptr(b.tile_bins),
                                          _ptr(b.gaussian_ids_sorted), _ptr(splats), _ptr(bg_c),
                                          _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img),
                                          _ptr(v_out_alpha), None, _ptr(partials), _ptr(row_flags), s)

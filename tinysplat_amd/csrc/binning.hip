@@ -229,6 +229,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+        if (b.maxy <= b.miny || b.maxx <= b.minx) continue;      // not in this stripe: skip the record load
         const TightTest tight(splats, i, (float)r);
         if (tight.cull_all) continue;
         for (int ty = b.miny; ty < b.maxy; ++ty) {
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+        if (b.maxy <= b.miny || b.maxx <= b.minx) continue;
         const TightTest tight(splats, i, (float)r);
         if (tight.cull_all) continue;
         for (int ty = b.miny; ty < b.maxy; ++ty) {
@@ -709,6 +711,7 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
         const int w = b.maxx - b.minx, h = b.maxy - b.miny;
         const int cnt = h > 0 ? w * h : 0;
+      if (cnt > 0) {       // cnt == 0: visible, but not in this stripe -> never listed, the record stays zero
         const int excl = cum_tiles_hit[i] - cnt;
         const int slot_base = excl - b.miny * w - b.minx;
         float op = opacity[i];
@@ -723,6 +726,7 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
         }
         q1 = make_float4(conics[3 * i + 1], conics[3 * i + 2], c0, c1);
         q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w));
+      }
     }
     splats[3 * (size_t)i] = q0;
     splats[3 * (size_t)i + 1] = q1;

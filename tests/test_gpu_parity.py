@@ -416,15 +416,21 @@ def test_one_node_frame_is_bitwise_the_fused_op_recipe():
     model, cam = scene_args(n, 2, w, h, seed=77, scale_mult=3.0)
     g = torch.Generator().manual_seed(9)
     w_rgb, w_d = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    from tinysplat_amd import frame
     res = []
-    for one in (False, True):
-        md = model.to(DEV).requires_grad_(True)
-        r = GaussianRasterizer(md, None, device=torch.device(DEV))
-        r.single_node = one
-        rgb, ex = r(cam, (w, h), 2)
-        ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
-        res.append([rgb.detach(), ex["depth"].detach(), ex["radii"], ex["xys"].detach(), ex["xys"].grad]
-                   + [p.grad for p in md.parameters()])
+    keep = frame.SPLIT_BLOCKS_BELOW
+    frame.SPLIT_BLOCKS_BELOW = 0        # the drop-in ops use one wave per tile: compare like with like
+    try:
+        for one in (False, True):
+            md = model.to(DEV).requires_grad_(True)
+            r = GaussianRasterizer(md, None, device=torch.device(DEV))
+            r.single_node = one
+            rgb, ex = r(cam, (w, h), 2)
+            ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
+            res.append([rgb.detach(), ex["depth"].detach(), ex["radii"], ex["xys"].detach(), ex["xys"].grad]
+                       + [p.grad for p in md.parameters()])
+    finally:
+        frame.SPLIT_BLOCKS_BELOW = keep
     assert len(res[0]) == len(res[1]) == 11
     for a, b in zip(*res):
         assert torch.equal(a, b)

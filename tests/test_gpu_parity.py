@@ -472,6 +472,38 @@ def test_tight_binning_drops_only_pairs_that_contribute_nothing():
             assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
 
 
+def test_frame_path_with_opaque_and_faint_gaussians_matches_oracle():
+    """The adapter's fast path (one node, tight lists, split mapping at this tile count, general
+    per-pixel code for opacities > 0.99) against the oracle frame incl. parameter gradients."""
+    n, sh, w, h = 6000, 1, 200, 120
+    model, cam = scene_args(n, sh, w, h, seed=51, scale_mult=5.0)
+    g = torch.Generator().manual_seed(52)
+    model.opacities = torch.empty(n, 1).uniform_(-6.0, 9.0, generator=g)      # sigmoid 0.0025 .. 0.9999
+    model.background = torch.tensor([0.3, 0.1, 0.2])
+    m64, _ = scene_args(n, sh, w, h, seed=51, scale_mult=5.0)
+    m64.opacities = model.opacities.clone()
+    m64.background = model.background.clone()
+    m64.requires_grad_(True)
+    f = oracle_frame(m64, cam, (w, h), depth=True)
+    stable = f["aux"]["margin"] > MARGIN
+    w_rgb = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    w_d = torch.rand(h, w, generator=g) * stable
+    ((f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()).backward()
+    md = model.to(DEV).requires_grad_(True)
+    rgb, extras = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), sh)
+    ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
+    assert torch.equal(extras["radii"].cpu(), f["radii"])
+    assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb")
+    assert_close_masked(extras["depth"], f["depth"], 1e-4, stable, what="depth")
+    for a, b, nm in [(md.means, m64.means, "means"), (md.scales, m64.scales, "scales"),
+                     (md.quats, m64.quats, "quats"), (md.opacities, m64.opacities, "opacities"),
+                     (md.colors_dc, m64.colors_dc, "colors_dc"), (md.colors_rest, m64.colors_rest, "rest")]:
+        ref, got = b.grad, a.grad.cpu().double()
+        tol = 2e-5 * max(1.0, ref.abs().max().item())
+        bad = ((got - ref).abs() > tol).double().mean().item()
+        assert bad < 5e-4, f"grad {nm}: {bad:.2e} off by > {tol:.2e}; max {(got - ref).abs().max():.3e}"
+
+
 def test_split_blocks_mapping_matches_one_wave_per_tile():
     """TS_RASTER_SPLIT_BLOCKS (four waves per tile, one per 8x8 block; used for launches with few
     tiles): the image, depth and transmittance decisions are bitwise those of the one-wave-per-tile

@@ -188,11 +188,20 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(GatherTable t, in
     float* __restrict__ dst = t.dst[blockIdx.y];
     const long long total = (long long)dst_rows * w;
     const long long stride = (long long)gridDim.x * kThreads;
-    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride) {
+    auto fetch = [&](long long e) -> float {
         const int r = (int)(e / w);
         const int c = (int)(e - (long long)r * w);
-        dst[e] = r < copy_rows ? src[(long long)src_of[r] * w + c] : 0.0f;
+        return r < copy_rows ? src[(long long)src_of[r] * w + c] : 0.0f;
+    };
+    // four consecutive output floats per lane: one 16-byte store (the tensors are 16-byte aligned and
+    // the unit starts at a multiple of four floats), four 4-byte gathers that mostly share a source row
+    const long long units = total >> 2;
+    for (long long u = (long long)blockIdx.x * kThreads + threadIdx.x; u < units; u += stride) {
+        const long long e = u << 2;
+        reinterpret_cast<float4*>(dst)[u] = make_float4(fetch(e), fetch(e + 1), fetch(e + 2), fetch(e + 3));
     }
+    for (long long e = (units << 2) + (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride)
+        dst[e] = fetch(e);
 }
 
 // means / scales of the 2S sampled rows (GaussianDistribution.sample, :547-557; utils.py:41-73)
@@ -286,8 +295,9 @@ int ts_gather_rows(int32_t num_tensors, const float* const* src, float* const* d
         if (e > most) most = e;
     }
     if (most == 0) return 0;
-    long long blocks = (most + kThreads - 1) / kThreads;
+    long long blocks = (most / 4 + kThreads - 1) / kThreads;
     if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks, num_tensors), dim3(kThreads), 0,
                        (hipStream_t)stream, t, dst_rows, copy_rows, src_of);
     return launch_status();

@@ -291,7 +291,10 @@ def main():
                        "intersections": isects_total, "intersections_listed_rank0": isects_listed,
                        "max_per_tile": max_per_tile,
                        "parallelism": f"tile-row stripes x{world}" if world > 1 else "single GPU",
-                       "scale_mult": args.scale_mult},
+                       "scale_mult": args.scale_mult,
+                       **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "
+                                              "(per-rank estimate, not a multi-GPU measurement)"}
+                          if args.emulate_ranks > 1 and world == 1 else {})},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": a_bytes,

@@ -5,21 +5,28 @@ One "step" = one frame of the hot path over one synthetic scene already resident
 project_gaussians -> spherical_harmonics -> clamp -> rasterize_gaussians (RGB) -> clamp, then the
 backward of L = (rgb * w).sum() down to the six parameter tensors (means, log-scales, quats,
 opacity logits, colors_dc, colors_rest).  Default workload = BASELINE.json configs[2]:
-1 M Gaussians, SH degree 3, 1920x1080.  With --depth the second (depth) rasterize pass of the
-reference adapter is included.
+1 M Gaussians, SH degree 3, 1920x1080.  With --depth the depth output of the reference adapter
+(rasterize.py:47-51) is rendered and differentiated too.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is sharded by tile-row
-stripes, the 40 N-byte 2-D gradient buffers are summed with one RCCL all-reduce (sharding.py);
-the total work is fixed, so scaling is "strong".
+N > 1: one rank per GPU.  ``python bench.py --gpus N`` from a plain shell re-launches itself under
+``torch.distributed.run`` (127.0.0.1 rendezvous); started by ``torch.distributed.run`` it uses the
+ranks it is given.  The frame is sharded by tile-row stripes, the per-Gaussian 2-D gradient buffers
+are summed with one RCCL all-reduce (sharding.py); the total work is fixed, so scaling is "strong".
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 (the last line of stdout).
 """
 from __future__ import annotations
 
 import argparse
+import collections
+import csv
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -29,36 +36,53 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak; 256 CUs x 4 SIMDs x 16 lanes at
+# 2.4 GHz = 39.3 T fp32 lane-operations/s for non-packed VALU instructions (one wave64 instruction
+# occupies a SIMD for 4 cycles), 157.3 TFLOP/s with packed (2-wide) FMAs
+HBM_PEAK_GBS = 8000.0
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
+VALU_FP32_PEAK_TFLOPS = 157.3
+
+# C-ABI entry -> stage of SURVEY.md 8(d) D5.  "raster_bwd" is the compositing backward INCLUDING
+# the reduction of the per-(tile, Gaussian) rows (D5 counts the gradient scatter in that stage), so
+# the two entries are timed together when that stage is priced.
+STAGE_OF = {
+    "ts_project_fwd": "project_fwd", "ts_project_bwd": "project_bwd",
+    "ts_sh_fwd": "sh_fwd", "ts_sh_colors_fwd": "sh_fwd",
+    "ts_sh_bwd": "sh_bwd", "ts_sh_colors_bwd": "sh_bwd",
+    "ts_scan_tiles": "bin_sort", "ts_bin_count": "bin_sort", "ts_tile_offsets": "bin_sort",
+    "ts_bin_scatter": "bin_sort", "ts_sort_tiles": "bin_sort", "ts_pack_splats": "bin_sort",
+    "ts_frame_prep": "bin_sort",
+    "ts_raster_fwd": "raster_fwd",
+    "ts_raster_bwd": "raster_bwd", "ts_reduce_partials": "raster_bwd",
+    "ts_grads_bwd": "param_bwd",
+}
 
 
-def alg_bytes(entry: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3) -> float:
-    """Algorithmic (lower-bound) bytes one launch of a C-ABI entry moves; DESIGN.md section 4, which
-    splits SURVEY.md 8(d) D5's per-stage figures over the entries."""
+def stage_alg_bytes(stage: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3) -> float:
+    """SURVEY.md 8(d) D5, per stage and per pass, with the measured I (bounding-box pairs, the
+    count gsplat's lists hold).  A 4-channel (RGB + depth) pass moves 4 more bytes per pair and
+    pixel than D5's 3-channel figures in each direction."""
+    extra = 4.0 * (ch - 3)
     return {
-        "ts_project_fwd": 96.0 * n,                       # R 40 N + W 56 N
-        "ts_project_bwd": 104.0 * n,                      # R 40+4+24 N, W 40 N  (no v_cov3d)
-        "ts_sh_fwd": (24.0 + 12.0 * k) * n,
-        "ts_sh_bwd": (24.0 + 12.0 * k) * n,
-        "ts_sh_colors_fwd": (24.0 + 12.0 * k) * n,        # same stage, view dirs + clamp fused
-        "ts_sh_colors_bwd": (24.0 + 12.0 * k) * n,
-        "ts_scan_tiles": 8.0 * n,
-        "ts_bin_count": 12.0 * n + 4.0 * t,
-        "ts_tile_offsets": 16.0 * t,
-        "ts_bin_scatter": 12.0 * n + 4.0 * i,
-        "ts_sort_tiles": 8.0 * i + 8.0 * t,
-        "ts_pack_splats": (36.0 + 4.0 + 4.0 + 48.0) * n,
-        "ts_raster_fwd": 40.0 * i + 20.0 * p + 8.0 * t,   # D5 "raster fwd"
-        "ts_raster_bwd": 24.0 * p + 76.0 * i + 36.0 * n,  # D5 "raster bwd" (incl. reduce)
-        "ts_reduce_partials": 48.0 * i + 36.0 * n,
-        "ts_photometric_loss": 36.0 * p,                  # read X, Y, write gX (3 channels)
-        "ts_adam_step": 28.0 * (14.0 + 3.0 * k) * n,      # p, g, m, v read; p, m, v written
-    }[entry]
+        "project_fwd": 96.0 * n,
+        "sh_fwd": (24.0 + 12.0 * k) * n,
+        "bin_sort": 28.0 * n + 44.0 * i + 8.0 * t,
+        "raster_fwd": (40.0 + extra) * i + (20.0 + extra) * p + 8.0 * t,
+        "raster_bwd": (24.0 + extra) * p + (76.0 + 2 * extra) * i + (36.0 + extra) * n,
+        "sh_bwd": (24.0 + 12.0 * k) * n,
+        "project_bwd": 144.0 * n,
+        "param_bwd": (24.0 + 12.0 * k) * n + 144.0 * n,      # SH bwd + project bwd in one launch
+    }[stage]
 
 
 def frame_alg_bytes(n, i, p, t, k, depth):
+    """D5's whole-frame figures.  RGB only: 736 N + 160 I + 44 P (+16 T).  With the depth output the
+    reference composites twice (772 N + 276 I + 88 P); this build composites RGB + depth in ONE
+    4-channel pass, so the bytes it has to move are the one-pass figure below (D5's per-stage terms
+    with 4 channels), which is what is priced - not the two-pass formula."""
     if depth:
-        return 772.0 * n + 276.0 * i + 88.0 * p
+        return 748.0 * n + 172.0 * i + 52.0 * p + 16.0 * t
     return 736.0 * n + 160.0 * i + 44.0 * p + 16.0 * t
 
 
@@ -83,44 +107,182 @@ def measure_read_bandwidth(dev, gib: float = 2.0, reps: int = 10) -> float:
     return best
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
-    """Times the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the
-    same workload: same scene generator / camera / SH degree, fwd+bwd of the RGB frame, scaled down
-    to N = 100k Gaussians at 480x270 so that it finishes in ~10-30 s of CPU work."""
+# --------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores, beside the GPU number
+# --------------------------------------------------------------------------------------------------
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _median(xs):
+    return sorted(xs)[len(xs) // 2]
+
+
+def cpu_baseline(budget_s: float = 120.0):
+    """D6: the pure-PyTorch CPU oracle (kind "port") driven through the adapter's recipe, with
+    ``torch.set_num_threads(<all available cores>)``, 2 warm-ups, median of 5 runs:
+
+      * BASELINE config 1 (10 k Gaussians, SH 0, 256x256, forward RGB) - always;
+      * BASELINE config 2 (100 k, SH 3, 1920x1080, fwd+bwd RGB): first on a bounded sample - the
+        same scene, camera and resolution, compositing only tile rows 30..37 of 68 (11.9 % of the
+        pixels; projection and SH for all N, as one rank of a sharded frame would) - and, when the
+        full frame is predicted to fit the remaining budget, on the whole frame.
+
+    ``value`` is the config-2 figure (full frame when measured, else the sample) in
+    Gaussians*pixels/s = N * pixels composited / median time.
+    """
     from oracle import gsplat_oracle as O
     from tinysplat_amd.rasterizer import project_args, raster_args, sh_args
     from tinysplat_amd.synthetic import loss_weights, make_scene
-    n, w, h, sh = 100_000, 480, 270, 3
+    t_begin = time.perf_counter()
     try:
-        avail = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))      # many tiny per-tile ops: more threads only add sync cost
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    model, cam = make_scene(n, sh, w, h, seed=0)
-    model.requires_grad_(True)
-    w_rgb, _ = loss_weights(w, h)
+    cpu = _cpu_model()
 
-    def step():
-        for p_ in model.parameters():
-            p_.grad = None
-        pa = project_args(model, cam, (w, h), "cpu")
-        xys, depths, radii, conics, nth, _ = O.project_gaussians(*pa)
-        col = torch.clamp(O.spherical_harmonics(*sh_args(model, cam, "cpu")) + 0.5, min=0.0)
-        img, _ = O.rasterize_gaussians(*raster_args(model, xys, depths, radii, conics, nth, col, (w, h)))
-        (torch.clamp(img, max=1.0) * w_rgb).sum().backward()
+    def timed(fn, warm=2, runs=5, deadline=None):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if deadline is not None and time.perf_counter() > deadline and len(ts) >= 3:
+                break
+        return _median(ts), len(ts)
 
-    step()                                  # warm-up
-    times = []
-    t_end = time.perf_counter() + seconds_budget
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 5):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    return {"value": n * w * h / med, "unit": "Gaussians*pixels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch CPU) fwd+bwd RGB frame, N={n} SH{sh} {w}x{h}, "
-                      f"median of {len(times)} runs = {med * 1e3:.0f} ms/frame"}
+    # config 1: forward only
+    n1, w1, h1 = 10_000, 256, 256
+    m1, c1 = make_scene(n1, 0, w1, h1, seed=0)
+
+    def fwd1():
+        with torch.no_grad():
+            xys, depths, radii, conics, nth, _ = O.project_gaussians(*project_args(m1, c1, (w1, h1), "cpu"))
+            col = torch.clamp(O.spherical_harmonics(*sh_args(m1, c1, "cpu")) + 0.5, min=0.0)
+            O.rasterize_gaussians(*raster_args(m1, xys, depths, radii, conics, nth, col, (w1, h1)))
+
+    t1, r1 = timed(fwd1)
+    config1 = {"value": n1 * w1 * h1 / t1, "ms_per_frame": t1 * 1e3, "runs": r1,
+               "workload": "BASELINE configs[0]: 10k Gaussians, SH 0, 256x256, forward RGB"}
+
+    # config 2: fwd+bwd, bounded sample (a stripe of tile rows), then the full frame if affordable
+    n2, w2, h2, sh2 = 100_000, 1920, 1080, 3
+    m2, c2 = make_scene(n2, sh2, w2, h2, seed=0)
+    m2.requires_grad_(True)
+    w_rgb, _ = loss_weights(w2, h2)
+    tby = (h2 + 15) // 16
+
+    def fwd_bwd2(rows):
+        def run():
+            for p_ in m2.parameters():
+                p_.grad = None
+            xys, depths, radii, conics, nth, _ = O.project_gaussians(*project_args(m2, c2, (w2, h2), "cpu"))
+            col = torch.clamp(O.spherical_harmonics(*sh_args(m2, c2, "cpu")) + 0.5, min=0.0)
+            ra = raster_args(m2, xys, depths, radii, conics, nth, col, (w2, h2))
+            img, _ = O.rasterize_gaussians(*ra, tile_rows=None if rows == (0, tby) else rows)
+            y0 = 16 * rows[0]
+            (torch.clamp(img, max=1.0) * w_rgb[y0:y0 + img.shape[0]]).sum().backward()
+        return run
+
+    rows = (30, 38)
+    ts, rs = timed(fwd_bwd2(rows), deadline=t_begin + 0.5 * budget_s)
+    px_s = (min(16 * rows[1], h2) - 16 * rows[0]) * w2
+    sample = {"value": n2 * px_s / ts, "ms": ts * 1e3, "runs": rs, "pixels": px_s,
+              "workload": f"BASELINE configs[1] (100k Gaussians, SH 3, 1920x1080, fwd+bwd RGB), tile rows "
+                          f"{rows[0]}..{rows[1] - 1} of {tby} only ({100.0 * px_s / (w2 * h2):.1f} % of the pixels)"}
+    out = {"value": sample["value"], "unit": "Gaussians*pixels/s", "cores": cores, "kind": "port",
+           "cpu": cpu, "config1_fwd": config1, "config2_sample": sample}
+    est_full = ts * (w2 * h2) / px_s
+    left = budget_s - (time.perf_counter() - t_begin)
+    if 5.0 * est_full <= left:           # 2 warm-ups + >= 3 timed runs fit
+        tf, rf = timed(fwd_bwd2((0, tby)), deadline=t_begin + budget_s)
+        out["config2_full"] = {"value": n2 * w2 * h2 / tf, "ms_per_frame": tf * 1e3, "runs": rf}
+        out["value"] = out["config2_full"]["value"]
+        what = f"whole frame, median of {rf} runs = {tf * 1e3:.0f} ms/frame"
+    else:
+        what = (f"bounded sample: tile rows {rows[0]}..{rows[1] - 1} of {tby}, median of {rs} runs = "
+                f"{ts * 1e3:.0f} ms (whole frame predicted {est_full:.0f} s/frame: over the {budget_s:.0f} s budget)")
+    out["sample"] = (f"oracle (pure PyTorch, CPU) through the adapter recipe on {cores} threads of {cpu}; "
+                     f"BASELINE configs[1] 100k SH3 1920x1080 fwd+bwd RGB, {what}; configs[0] forward "
+                     f"{t1 * 1e3:.0f} ms/frame = {config1['value']:.3g} G*px/s; 2 warm-ups each")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# PMC counters of the same workload (rocprofv3, one counter group per pass, no tracing)
+# --------------------------------------------------------------------------------------------------
+KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel", "ts_raster_fwd"),
+                   ("reduce_partials_kernel", "ts_reduce_partials"), ("sort_tiles", "ts_sort_tiles"),
+                   ("bin_scatter_kernel", "ts_bin_scatter"), ("bin_count_kernel", "ts_bin_count"),
+                   ("sh_colors_fwd_kernel", "ts_sh_colors_fwd"), ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
+                   ("grads_bwd_kernel", "ts_grads_bwd"), ("frame_prep_kernel", "ts_frame_prep"),
+                   ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
+                   ("pack_splats_kernel", "ts_pack_splats")]
+
+
+def collect_pmc(workload_argv, timeout_s: float = 150.0):
+    """Re-runs a few frames of THIS workload under ``rocprofv3 --pmc`` - FETCH_SIZE, WRITE_SIZE and
+    SQ_INSTS_VALU in separate passes, never combined with tracing (MI355X_MICROARCH.md, HBM section)
+    - and returns {entry: {"fetch_kib", "write_kib", "valu_insts"}} as means per dispatch, or None
+    when rocprofv3 is unavailable / a pass fails (the caller then falls back to ``profiles/``)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    res = collections.defaultdict(dict)
+    for counter, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib"),
+                         ("SQ_INSTS_VALU", "valu_insts")):
+        tmp = tempfile.mkdtemp(prefix="ts_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+                   sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1",
+                   "--profile-steps", "1", "--no-cpu-baseline", "--no-pmc", "--no-bandwidth"] + workload_argv
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k_, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s)
+            files = list(Path(tmp).rglob("*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            acc, seen = collections.defaultdict(float), collections.defaultdict(set)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"]
+                entry = next((e for pat, e in KERNEL_TO_ENTRY if pat in name), None)
+                if entry is None:
+                    continue
+                acc[entry] += float(row["Counter_Value"])
+                seen[entry].add(row["Dispatch_Id"])
+            for entry, tot in acc.items():
+                res[entry][key] = tot / max(1, len(seen[entry]))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return dict(res)
+
+
+def _log(msg: str) -> None:
+    """Progress on stderr (stdout carries the one JSON line)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
@@ -133,8 +295,11 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale-mult", type=float, default=1.0)
-    ap.add_argument("--depth", action="store_true", help="also run the depth rasterize pass")
+    ap.add_argument("--depth", action="store_true", help="also render and differentiate the depth output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-run the workload under rocprofv3 --pmc for roofline.traffic / valu_roofline")
+    ap.add_argument("--no-bandwidth", action="store_true", help="skip the read-bandwidth microbenchmark")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--train-step", action="store_true",
                     help="time the whole training step of SURVEY 8(f) F1 instead: render RGB+depth, "
@@ -143,6 +308,10 @@ def main():
                     help="time the no_grad forward frame only (the viewer path, SURVEY 8(f) F4)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with "
+                         "--backend gloo; RCCL refuses two ranks on one GPU).  Not a measurement.")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="single-GPU estimate of the per-rank step at this many tile-row stripes: renders "
                          "only stripe --emulate-rank of that many (with --force-dist the 1-rank all-reduce "
@@ -160,20 +329,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks on this node
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
         if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from tinysplat_amd import ops
     from tinysplat_amd.rasterizer import GaussianRasterizer
-    from tinysplat_amd.sharding import render_rgb_stripe
+    from tinysplat_amd.sharding import render_stripe
     from tinysplat_amd.synthetic import loss_weights, make_scene
 
     n, w, h, sh = args.n, args.width, args.height, args.sh_degree
@@ -182,6 +363,7 @@ def main():
     w_rgb, w_d = loss_weights(w, h)
     w_rgb, w_d = w_rgb.to(dev), w_d.to(dev)
     adapter = GaussianRasterizer(model, None, device=dev)
+    sharded = world > 1 or args.emulate_ranks > 1 or args.force_dist
 
     trainer = None
     if args.train_step:
@@ -203,20 +385,19 @@ def main():
             with torch.no_grad():
                 adapter(cam, (w, h), sh)
             return
-        if args.depth:
-            if world > 1:
-                raise SystemExit("--depth is a single-GPU mode")
+        if not sharded and args.depth:           # the adapter call itself (rasterize.py:26-62)
             rgb, extras = adapter(cam, (w, h), sh)
             loss = (rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()
         else:
             if args.emulate_ranks > 1 and world == 1:
-                rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev,
-                                                     args.emulate_rank, args.emulate_ranks,
-                                                     collective=bool(args.force_dist))
+                r_, ws_ = args.emulate_rank, args.emulate_ranks
             else:
-                rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), adapter.ops, dev, rank, world,
-                                                     collective=True if args.force_dist else None)
-            loss = (rgb * w_rgb[y0:y1]).sum()
+                r_, ws_ = rank, world
+            out, (y0, y1), _ = render_stripe(model, cam, (w, h), dev, r_, ws_, with_depth=args.depth,
+                                             collective=(world > 1 or args.force_dist))
+            loss = (out[:, :, :3] * w_rgb[y0:y1]).sum()
+            if args.depth:
+                loss = loss + (out[:, :, 3] * w_d[y0:y1]).sum()
         loss.backward()
 
     def barrier():
@@ -224,9 +405,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        _log(f"scene ready (N={n}, {w}x{h}); warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
+    if rank == 0:
+        _log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -250,32 +435,110 @@ def main():
     max_per_tile = int((bins[:, 1] - bins[:, 0]).max().item()) if tiles else 0
     isects_listed = int(bins[:, 1].max().item()) if tiles else 0    # after tight binning (<= isects)
     if world > 1:
-        tt = torch.tensor([isects], device=dev, dtype=torch.int64)
+        tt = torch.tensor([isects, isects_listed], device=dev, dtype=torch.int64)
         dist.all_reduce(tt)
-        isects_total = int(tt.item())
+        isects_total, listed_total = int(tt[0].item()), int(tt[1].item())
     else:
-        isects_total = isects
+        isects_total, listed_total = isects, isects_listed
 
     if rank == 0:
         p = w * h
         k = (sh + 1) ** 2
+        ch = 4 if (args.depth or args.forward_only or args.train_step) else 3
         ms = dt / args.steps * 1e3
         value = n * p / (dt / args.steps)
-        # dominant kernel = the C-ABI entry with the largest mean duration on this rank
-        dom = max(per_entry.items(), key=lambda kv: kv[1][1] * kv[1][0])
-        dom_name, (dom_launches, dom_ms) = dom
-        p_local = p if world == 1 else binning.cam.tile_rows * 16 * w
-        a_bytes = alg_bytes(dom_name, n, isects, p_local, tiles, k)
+        per_step = {e: v[1] * v[0] / max(1, args.profile_steps) for e, v in per_entry.items()}   # ms / step
+        stage_ms = collections.defaultdict(float)
+        stage_entries = collections.defaultdict(list)
+        for e, t_ in per_step.items():
+            st = STAGE_OF.get(e)
+            if st is not None:
+                stage_ms[st] += t_
+                stage_entries[st].append(e)
+        # dominant stage = the D5 stage with the largest time on this rank; its dominant kernel is
+        # the entry inside it with the largest time
+        dom_stage = max(stage_ms.items(), key=lambda kv: kv[1])[0]
+        dom_ms = stage_ms[dom_stage]
+        dom_entry = max(stage_entries[dom_stage], key=lambda e: per_step[e])
+        p_local = p if (world == 1 and args.emulate_ranks <= 1) else binning.cam.tile_rows * 16 * w
+        a_bytes = stage_alg_bytes(dom_stage, n, isects, p_local, tiles, k, ch)
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
-        frame_bytes = frame_alg_bytes(n, isects_total, p, (w + 15) // 16 * ((h + 15) // 16), k, args.depth)
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():
-            try:
-                traffic = json.loads(tf.read_text()).get(dom_name)
-            except Exception:
-                traffic = None
-        bw_meas = measure_read_bandwidth(dev)
+        full_tiles = (w + 15) // 16 * ((h + 15) // 16)
+        frame_bytes = frame_alg_bytes(n, isects_total, p, full_tiles, k, args.depth)
+        frame_bytes_listed = frame_alg_bytes(n, listed_total, p, full_tiles, k, args.depth)
+
+        pmc, pmc_src = None, None
+        if world == 1 and not args.no_pmc and not args.train_step:
+            wl = ["--n", str(n), "--sh-degree", str(sh), "--width", str(w), "--height", str(h),
+                  "--scale-mult", str(args.scale_mult)] + (["--depth"] if args.depth else []) \
+                 + (["--forward-only"] if args.forward_only else []) \
+                 + (["--emulate-ranks", str(args.emulate_ranks), "--emulate-rank", str(args.emulate_rank)]
+                    if args.emulate_ranks > 1 else [])
+            _log("PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU)")
+            pmc = collect_pmc(wl)
+            _log("PMC passes done" if pmc else "PMC passes unavailable")
+            pmc_src = "rocprofv3 --pmc passes of this run" if pmc else None
+        if pmc is None:
+            tf = ROOT / "profiles" / "pmc_latest.json"
+            if tf.exists() and (n, sh, w, h, args.depth) == (1_000_000, 3, 1920, 1080, False):
+                try:
+                    pmc = json.loads(tf.read_text())
+                    pmc_src = "profiles/pmc_latest.json (committed; not collected in this run)"
+                except Exception:
+                    pmc = None
+
+        def traffic_of(entries):
+            """HBM bytes per step of the entries: (2 x FETCH_SIZE + WRITE_SIZE) KiB - gfx950 tallies
+            128-B read requests as 64 B (MI355X_MICROARCH.md, HBM section)."""
+            if not pmc:
+                return None
+            tot = 0.0
+            for e in entries:
+                c = pmc.get(e)
+                if not c or "fetch_kib" not in c or "write_kib" not in c:
+                    return None
+                launches = per_entry[e][0] / max(1, args.profile_steps)
+                tot += (2.0 * c["fetch_kib"] + c["write_kib"]) * 1024.0 * launches
+            return tot
+
+        _log(f"timed: {ms:.3f} ms/step")
+        bw_meas = None if args.no_bandwidth else measure_read_bandwidth(dev)
+        roofline = {"bound": "hbm", "stage": dom_stage, "kernel": dom_entry,
+                    "entries": sorted(stage_entries[dom_stage]),
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(stage_entries[dom_stage]),
+                    "traffic_source": pmc_src, "alg_bytes_per_launch": a_bytes, "kernel_ms": dom_ms,
+                    "kernel_ms_dominant_entry": per_step[dom_entry],
+                    "peak_read_measured": bw_meas,
+                    "frac_of_measured": None if bw_meas is None else achieved / bw_meas}
+        frame_gbs = frame_bytes / (ms * 1e-3) / 1e9
+        frame_roofline = {"alg_bytes": frame_bytes, "achieved": frame_gbs, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS,
+                          "alg_bytes_listed": frame_bytes_listed,
+                          "frac_listed": frame_bytes_listed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "peak_read_measured": bw_meas,
+                          "frac_of_measured": None if bw_meas is None else frame_gbs / bw_meas}
+        # D4 secondary figure: the compositing kernels against the vector ALUs
+        valu = {}
+        for e in ("ts_raster_fwd", "ts_raster_bwd"):
+            if e not in per_step:
+                continue
+            t_s = per_step[e] * 1e-3
+            ent = {"kernel_ms": per_step[e],
+                   # D4: 256 pixel x Gaussian evaluations per listed pair (upper bound, before early-out)
+                   "pair_evals_per_s": 256.0 * isects_listed / t_s,
+                   "pair_evals_per_s_gsplat_lists": 256.0 * isects / t_s}
+            c = (pmc or {}).get(e)
+            if c and "valu_insts" in c:
+                lane_ops = c["valu_insts"] * 64.0
+                ent.update({"valu_wave_insts": c["valu_insts"],
+                            "valu_insts_per_listed_pair": c["valu_insts"] / max(1, isects_listed),
+                            "lane_ops_per_s": lane_ops / t_s, "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK,
+                            "frac": lane_ops / t_s / VALU_LANE_OPS_PEAK,
+                            # counting every VALU instruction as one FMA (2 flops): an upper bound
+                            "tflops_if_all_fma": 2.0 * lane_ops / t_s / 1e12,
+                            "peak_tflops_packed": VALU_FP32_PEAK_TFLOPS})
+            valu[e] = ent
         out = {
             "metric": "Gaussians*pixels/s forward only (no_grad, RGB+depth)" if args.forward_only else
                       "Gaussians*pixels/s fwd+bwd" if not args.train_step else
@@ -287,29 +550,28 @@ def main():
             "config": {"workload": f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd "
                                    f"({'RGB+depth' if args.depth else 'RGB'}), BASELINE configs[2]"
                                    if (n, sh, w, h) == (1_000_000, 3, 1920, 1080) else
-                                   f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd",
-                       "intersections": isects_total, "intersections_listed_rank0": isects_listed,
+                                   f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd "
+                                   f"({'RGB+depth' if args.depth else 'RGB'})",
+                       "intersections": isects_total, "intersections_listed": listed_total,
                        "max_per_tile": max_per_tile,
-                       "parallelism": f"tile-row stripes x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"tile-row stripes x{world}" + (" (ALL RANKS ON ONE GPU: functional test, "
+                                       "not a measurement)" if args.single_device else "")) if world > 1 else "single GPU",
                        "scale_mult": args.scale_mult,
                        **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "
                                               "(per-rank estimate, not a multi-GPU measurement)"}
                           if args.emulate_ranks > 1 and world == 1 else {})},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": a_bytes,
-                         "kernel_ms": dom_ms, "launches_per_step": dom_launches / max(1, args.profile_steps),
-                         "peak_read_measured": bw_meas, "frac_of_measured": achieved / bw_meas},
-            "frame_roofline": {"alg_bytes": frame_bytes, "achieved": frame_bytes / (ms * 1e-3) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "peak_read_measured": bw_meas,
-                               "frac_of_measured": frame_bytes / (ms * 1e-3) / 1e9 / bw_meas},
-            "entries_ms": {k_: round(v[1] * v[0] / max(1, args.profile_steps), 4)
-                           for k_, v in sorted(per_entry.items())},
+            "roofline": roofline,
+            "frame_roofline": frame_roofline,
+            "valu_roofline": valu,
+            "stages_ms": {k_: round(v, 4) for k_, v in sorted(stage_ms.items())},
+            "entries_ms": {k_: round(v, 4) for k_, v in sorted(per_step.items())},
         }
+        if pmc:
+            out["pmc_per_dispatch"] = {e: {k_: round(v, 1) for k_, v in c.items()} for e, c in sorted(pmc.items())}
         if world == 1 and not args.no_cpu_baseline:
+            _log("CPU baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()
+            _log("CPU baseline done")
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -348,14 +348,77 @@ def stripe_tiles_hit(xys: Tensor, radii: Tensor, tile_bounds, tile_rows) -> Tens
     return torch.where(radii > 0, cnt, torch.zeros_like(cnt)).to(torch.int32)
 
 
+def _composite_tiles(xys, conics, colors, opacity, gids, starts, ends, tx, ty, return_aux):
+    """Front-to-back compositing of a BATCH of tiles in one set of tensor ops.
+
+    gids [I] sorted Gaussian ids; starts/ends [B] list ranges; tx, ty [B] tile coordinates.  Lists are
+    padded to the longest one of the batch; a padded entry is invalid by construction (alpha 0, never
+    stops a pixel, never counted), so every tile gets exactly the result it would get alone - the
+    per-(pixel, Gaussian) arithmetic below is elementwise, and the products / index reductions run
+    along the list axis of each pixel independently.  All 256 pixels of a tile are evaluated; the
+    caller crops those beyond the image.
+    -> pix [B,256,C] (colour without background), T_fin [B,256], f_idx [B,256] int64, margin [B,256] f64 | None
+    """
+    dt = xys.dtype
+    B = starts.shape[0]
+    L = int((ends - starts).max())
+    idxs = torch.arange(L)[None, None, :]                                     # [1,1,L]
+    pos = starts[:, None] + torch.arange(L)[None, :]                          # [B,L]
+    pad = pos >= ends[:, None]
+    g = gids[torch.where(pad, starts[:, None].expand_as(pos), pos)]           # padded slots repeat entry 0
+    pad = pad[:, None, :]                                                     # [B,1,L]
+    lane = torch.arange(BLOCK * BLOCK)
+    PX = ((tx * BLOCK)[:, None] + (lane % BLOCK)[None, :]).to(dt)[:, :, None] + PIXEL_CENTER_OFFSET   # [B,256,1]
+    PY = ((ty * BLOCK)[:, None] + (lane // BLOCK)[None, :]).to(dt)[:, :, None] + PIXEL_CENTER_OFFSET
+    gx, gy = xys[g, 0][:, None, :], xys[g, 1][:, None, :]                     # [B,1,L]
+    con = conics[g]                                                           # [B,L,3]
+    cA, cB, cC = con[:, None, :, 0], con[:, None, :, 1], con[:, None, :, 2]
+    dx, dy = gx - PX, gy - PY
+    sigma = 0.5 * (cA * dx * dx + cC * dy * dy) + cB * dx * dy
+    # exp on a safe argument: sigma < 0 entries are skipped below, and exp(+large) = inf would turn
+    # their (masked) gradient into 0 * inf = NaN under autograd
+    raw = opacity[g][:, None, :] * torch.exp(-torch.where(sigma >= 0, sigma, torch.zeros_like(sigma)))
+    alpha = torch.clamp(raw, max=ALPHA_MAX)
+    valid = (sigma >= 0) & (alpha >= ALPHA_MIN) & ~pad
+    a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+    next_T = torch.cumprod(1.0 - a_eff, dim=2)                                # T after each Gaussian
+    stop = valid & (next_T <= T_EPS)
+    # first stopping index per pixel (L if none)
+    first_stop = torch.where(stop, idxs, torch.full_like(idxs, L)).min(dim=2, keepdim=True).values
+    live = valid & (idxs < first_stop)
+    T_before = torch.cat([torch.ones_like(next_T[:, :, :1]), next_T[:, :, :-1]], dim=2)
+    wgt = torch.where(live, a_eff * T_before, torch.zeros_like(a_eff))        # alpha * T
+    pix = torch.bmm(wgt, colors[g])                                           # [B,256,C]
+    # final T = T in front of the stopping Gaussian (or after the last one)
+    T_ext = torch.cat([torch.ones_like(next_T[:, :, :1]), next_T], dim=2)     # [B,256,L+1]
+    T_fin = T_ext.gather(2, first_stop)[:, :, 0]
+    last = torch.where(live, idxs, torch.full_like(idxs, -1)).max(dim=2).values
+    f_idx = torch.where(last >= 0, last + starts[:, None], torch.zeros_like(last))
+    margin = None
+    if return_aux:
+        with torch.no_grad():
+            seen = (idxs <= first_stop) & ~pad                    # evaluated before/at termination
+            big = torch.full_like(raw, 1e30).double()
+            m_a = torch.where(seen & (sigma >= 0), (raw.double() * 255.0 - 1.0).abs(), big)
+            m_t = torch.where(seen & valid, (next_T.double() / T_EPS - 1.0).abs(), big)
+            mag = (0.5 * ((cA * dx * dx).abs() + (cC * dy * dy).abs()) + (cB * dx * dy).abs()).double()
+            m_s = torch.where(seen & (mag > 0), sigma.double().abs() / (mag + 1e-300), big)
+            margin = torch.minimum(torch.minimum(m_a, m_t), m_s).min(dim=2).values
+    return pix, T_fin, f_idx, margin
+
+
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
                         num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
                         img_width: int, background: Tensor, return_aux: bool = False,
-                        tile_rows=None):
+                        tile_rows=None, batch_elems: int = 1 << 22):
     """-> (out_img[H,W,C], out_alpha[H,W]); with return_aux also a dict of final_Ts, final_index,
     tile_bins, gaussian_ids_sorted and ``margin`` (per-pixel distance of the closest discrete decision
     - alpha >= 1/255, next_T <= 1e-4 - to its threshold, relative; pixels with a tiny margin are the
     ones where two correct float32 implementations may legitimately differ by a whole contribution).
+
+    ``batch_elems`` bounds pixels x list length of the tiles composited together by one set of tensor
+    ops (tiles of similar list length are grouped and padded); 0 = one tile at a time.  Grouping only
+    changes how much Python / dispatch overhead a frame costs: per pixel the arithmetic is the same.
     """
     if colors.dim() != 2 or xys.shape[0] != colors.shape[0]:
         raise ValueError("colors must be [N, C]")
@@ -373,92 +436,56 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     gids = gids.to(torch.int64)
     bg = background.to(dt)
     row_lo, row_hi = (0, tby) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+    rows = row_hi - row_lo
+    P = BLOCK * BLOCK
 
-    out_img = torch.zeros(H, W, C, dtype=dt) + bg            # empty tiles: T=1 -> background
-    out_alpha = torch.zeros(H, W, dtype=dt)
-    final_T = torch.ones(H, W, dtype=dt)
-    final_idx = torch.zeros(H, W, dtype=torch.int32)
-    margin = torch.full((H, W), float("inf"), dtype=torch.float64)
-    img_parts = {}
+    # tiles of the stripe, longest list first; empty tiles keep T = 1 (background only)
+    t_ids = torch.arange(row_lo * tbx, row_hi * tbx)
+    lens = (tile_bins[t_ids, 1] - tile_bins[t_ids, 0]).to(torch.int64)
+    order = torch.argsort(lens, descending=True, stable=True)
+    order = order[lens[order] > 0]
+    pix_all = torch.zeros(rows * tbx, P, C, dtype=dt)                 # per tile, without background
+    T_all = torch.ones(rows * tbx, P, dtype=dt)
+    idx_all = torch.zeros(rows * tbx, P, dtype=torch.int64)
+    margin_all = torch.full((rows * tbx, P), float("inf"), dtype=torch.float64)
+    parts, where = [], []
+    k = 0
+    while k < order.shape[0]:
+        Lmax = int(lens[order[k]])
+        nb = max(1, int(batch_elems) // (P * Lmax)) if batch_elems > 0 else 1
+        sel = order[k:k + nb]
+        k += nb
+        t = t_ids[sel]
+        pix, T_fin, f_idx, margin = _composite_tiles(
+            xys, conics, colors, opacity, gids, tile_bins[t, 0].to(torch.int64),
+            tile_bins[t, 1].to(torch.int64), t % tbx, t // tbx, return_aux)
+        parts.append(pix)
+        where.append(sel)
+        T_all[sel] = T_fin.detach()
+        parts.append(T_fin[:, :, None])                               # differentiable copy, see below
+        idx_all[sel] = f_idx
+        if margin is not None:
+            margin_all[sel] = margin
+    if where:
+        sel = torch.cat(where)
+        pix_all = pix_all.index_copy(0, sel, torch.cat(parts[0::2], dim=0))           # differentiable
+        T_diff = torch.ones(rows * tbx, P, 1, dtype=dt).index_copy(0, sel, torch.cat(parts[1::2], dim=0))
+    else:
+        T_diff = torch.ones(rows * tbx, P, 1, dtype=dt)
 
-    for t in range(row_lo * tbx, row_hi * tbx):
-        s, e = int(tile_bins[t, 0]), int(tile_bins[t, 1])
-        if e <= s:
-            continue
-        ty, tx = divmod(t, tbx)
-        y0, x0 = ty * BLOCK, tx * BLOCK
-        y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
-        g = gids[s:e]
-        pxs = torch.arange(x0, x1, dtype=dt) + PIXEL_CENTER_OFFSET
-        pys = torch.arange(y0, y1, dtype=dt) + PIXEL_CENTER_OFFSET
-        PY, PX = torch.meshgrid(pys, pxs, indexing="ij")
-        PX, PY = PX.reshape(-1, 1), PY.reshape(-1, 1)           # [p,1]
-        gx, gy = xys[g, 0][None, :], xys[g, 1][None, :]          # [1,n]
-        con = conics[g]
-        dx, dy = gx - PX, gy - PY
-        sigma = 0.5 * (con[:, 0][None] * dx * dx + con[:, 2][None] * dy * dy) + con[:, 1][None] * dx * dy
-        # exp on a safe argument: sigma < 0 entries are skipped below, and exp(+large) = inf would turn
-        # their (masked) gradient into 0 * inf = NaN under autograd
-        raw = opacity[g][None, :] * torch.exp(-torch.where(sigma >= 0, sigma, torch.zeros_like(sigma)))
-        alpha = torch.clamp(raw, max=ALPHA_MAX)
-        valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
-        a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
-        next_T = torch.cumprod(1.0 - a_eff, dim=1)               # T after each Gaussian
-        stop = valid & (next_T <= T_EPS)
-        # first stopping index per pixel (n if none)
-        n = g.shape[0]
-        idxs = torch.arange(n)[None, :]
-        first_stop = torch.where(stop, idxs, torch.full_like(idxs, n)).min(dim=1, keepdim=True).values
-        live = valid & (idxs < first_stop)
-        T_before = torch.cat([torch.ones_like(next_T[:, :1]), next_T[:, :-1]], dim=1)
-        wgt = torch.where(live, a_eff * T_before, torch.zeros_like(a_eff))          # alpha * T
-        pix = wgt @ colors[g]                                                      # [p,C]
-        # final T = T in front of the stopping Gaussian (or after the last one)
-        T_ext = torch.cat([torch.ones_like(next_T[:, :1]), next_T], dim=1)          # [p,n+1]
-        T_fin = T_ext.gather(1, first_stop)[:, 0]
-        last = torch.where(live, idxs, torch.full_like(idxs, -1)).max(dim=1).values
-        f_idx = torch.where(last >= 0, last + s, torch.zeros_like(last))
-        hh, ww = y1 - y0, x1 - x0
-        img_parts[t] = (pix + T_fin[:, None] * bg).reshape(hh, ww, C)
-        out_alpha[y0:y1, x0:x1] = (1.0 - T_fin).reshape(hh, ww)
-        final_T[y0:y1, x0:x1] = T_fin.detach().reshape(hh, ww)
-        final_idx[y0:y1, x0:x1] = f_idx.to(torch.int32).reshape(hh, ww)
-        if return_aux:
-            with torch.no_grad():
-                seen = idxs <= first_stop                         # evaluated before/at termination
-                m_a = torch.where(seen & (sigma >= 0),
-                                  (raw.double() * 255.0 - 1.0).abs(), torch.full_like(raw, 1e30).double())
-                m_t = torch.where(seen & valid, (next_T.double() / T_EPS - 1.0).abs(),
-                                  torch.full_like(raw, 1e30).double())
-                mag = (0.5 * ((con[:, 0][None] * dx * dx).abs() + (con[:, 2][None] * dy * dy).abs())
-                       + (con[:, 1][None] * dx * dy).abs()).double()
-                m_s = torch.where(seen & (mag > 0), sigma.double().abs() / (mag + 1e-300),
-                                  torch.full_like(raw, 1e30).double())
-                m = torch.minimum(torch.minimum(m_a, m_t), m_s).min(dim=1).values
-                margin[y0:y1, x0:x1] = m.reshape(hh, ww)
+    def to_image(x):      # [rows*tbx, 256, c] tile-major -> [rows*16, tbx*16, c] -> crop to the image
+        c = x.shape[-1]
+        x = x.reshape(rows, tbx, BLOCK, BLOCK, c).permute(0, 2, 1, 3, 4).reshape(rows * BLOCK, tbx * BLOCK, c)
+        return x[:min(row_hi * BLOCK, H) - row_lo * BLOCK, :W]
 
-    if img_parts:
-        # assemble with differentiable ops (index_put on a cloned base keeps autograd intact)
-        rows = []
-        for ty in range(tby):
-            cols = []
-            for tx in range(tbx):
-                t = ty * tbx + tx
-                y0, x0 = ty * BLOCK, tx * BLOCK
-                y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
-                if t in img_parts:
-                    cols.append(img_parts[t])
-                else:
-                    cols.append(bg.expand(y1 - y0, x1 - x0, C))
-            rows.append(torch.cat(cols, dim=1))
-        out_img = torch.cat(rows, dim=0)
-    if tile_rows is not None:
-        y0, y1 = row_lo * BLOCK, min(row_hi * BLOCK, H)
-        out_img, out_alpha = out_img[y0:y1], out_alpha[y0:y1]
-        final_T, final_idx, margin = final_T[y0:y1], final_idx[y0:y1], margin[y0:y1]
+    T_img = to_image(T_diff)
+    out_img = to_image(pix_all) + T_img * bg                          # final T * background
+    out_alpha = 1.0 - T_img[:, :, 0]
     if return_aux:
-        aux = {"final_Ts": final_T, "final_index": final_idx, "tile_bins": tile_bins,
-               "gaussian_ids_sorted": gids.to(torch.int32), "margin": margin}
+        aux = {"final_Ts": to_image(T_all[:, :, None])[:, :, 0].contiguous(),
+               "final_index": to_image(idx_all[:, :, None])[:, :, 0].to(torch.int32).contiguous(),
+               "tile_bins": tile_bins, "gaussian_ids_sorted": gids.to(torch.int32),
+               "margin": to_image(margin_all[:, :, None])[:, :, 0].contiguous()}
         return out_img, out_alpha, aux
     return out_img, out_alpha
 

@@ -48,3 +48,25 @@ def hostmath():
 def fptr(t):
     assert t.is_contiguous()
     return ctypes.c_void_p(t.data_ptr())
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst measured error per compared gradient tensor (helpers.check_grad)."""
+    try:
+        from helpers import PARITY_LOG
+    except Exception:
+        return
+    if not PARITY_LOG:
+        return
+    lines = ["test | tensor | max abs err | |ref|_inf | tolerance | err/tol | fraction over"]
+    for test, what, worst, mag, tol, frac in PARITY_LOG:
+        lines.append(f"{test} | {what} | {worst:.3e} | {mag:.3e} | {tol:.3e} | {worst / tol if tol else 0:.3f} | {frac:.2e}")
+    terminalreporter.write_sep("-", "measured gradient errors (helpers.check_grad)")
+    for ln in lines:
+        terminalreporter.write_line(ln)
+    out = ROOT / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        (out / "parity_report.txt").write_text("\n".join(lines) + "\n")
+    except OSError:
+        pass

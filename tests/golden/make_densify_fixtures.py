@@ -11,6 +11,7 @@ CLI defaults of scripts/train.py:187-214, a real ``torch.optim.Adam(model.parame
   * ``update_grad_accum``        (model_gaussian.py:130-132)
   * ``densify_and_prune``        (model_gaussian.py:138-195, incl. GaussianDistribution.sample :533-572)
   * ``update_state(optim, mask)`` (model_gaussian.py:197-242, the prune-only use of train.py:103-105)
+    and ``update_state(optim, mask, tensors)`` with caller-made rows
   * ``reset_opacities``          (model_gaussian.py:134-136)
 
 storing the state before and after.  The unit normal draws behind ``torch.normal(mean, std)``
@@ -142,12 +143,35 @@ def make_prune(mg, name, n, k_rest, seed):
     print(f"{name}: N {n} -> {out['post_means'].shape[0]}")
 
 
+def make_append(mg, name, n, k_rest, seed, extra):
+    """update_state(optim, mask, tensors) with caller-made rows (model_gaussian.py:197-242): the general
+    form densify_and_prune itself uses (:193)."""
+    m, optim, g = build_model(mg, n, k_rest, seed, 100)
+    out = {"n": n, "extra": extra}
+    m.means_grad_accum = torch.rand(n, generator=g)
+    snapshot(m, optim, "pre", out)
+    mask = torch.rand(n, generator=g) < 0.3
+    rows = {"means": torch.randn(extra, 3, generator=g), "colors_dc": torch.randn(extra, 3, generator=g),
+            "colors_rest": torch.randn(extra, k_rest, 3, generator=g) * 0.1,
+            "scales": torch.randn(extra, 3, generator=g) - 4.0, "quats": torch.randn(extra, 4, generator=g),
+            "opacities": torch.randn(extra, 1, generator=g)}
+    with torch.no_grad():
+        m.update_state(optim, mask, {k: v.clone() for k, v in rows.items()})
+    out["mask"] = mask.numpy()
+    for k, v in rows.items():
+        out[f"rows_{k}"] = v.numpy()
+    snapshot(m, optim, "post", out)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: N {n} -> {out['post_means'].shape[0]} ({extra} caller rows)")
+
+
 def main():
     make_fixtures.load_reference()
     mg = importlib.import_module("tinysplat.splatting.model_gaussian")
     make_densify(mg, "densify_n1200_k15", 1200, 15, 5, 100, 1920, 1080, 700)
     make_densify(mg, "densify_n300_k0", 300, 0, 6, 7, 640, 480, 700)
     make_prune(mg, "prune_n1500_k3", 1500, 3, 7)
+    make_append(mg, "append_n900_k8", 900, 8, 8, 37)
 
 
 if __name__ == "__main__":

@@ -46,3 +46,36 @@ def assert_close_masked(a, b, atol, mask=None, max_bad_frac=0.0, what=""):
         err = torch.where(m.expand_as(err), err, torch.zeros_like(err))
     bad = (err > atol).double().mean().item()
     assert bad <= max_bad_frac, f"{what}: {bad:.3e} of entries exceed {atol} (max err {err.max():.3e})"
+
+
+# --------------------------------------------------------------------------------------------------
+# gradient comparison with a record of what was actually measured
+# --------------------------------------------------------------------------------------------------
+PARITY_LOG = []          # (test, tensor, max_abs_err, ref_inf_norm, tol, frac_over); printed by conftest
+
+
+def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0, mask=None):
+    """|got - ref| <= rel * max(1, |ref|_inf) per entry (north_star: 1e-5 abs, scaled by the magnitude
+    of the reference tensor), for all but ``max_bad_frac`` of the entries.  Every call records the
+    worst absolute error, the reference magnitude and the worst error / tolerance, which the GPU test
+    session prints at its end (and writes to gpurun_out/parity_report.txt)."""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    if mask is not None:
+        m = mask
+        while m.dim() < err.dim():
+            m = m[..., None]
+        err = torch.where(m.expand_as(err), err, torch.zeros_like(err))
+    mag = ref.abs().max().item() if ref.numel() else 0.0
+    tol = rel * max(1.0, mag)
+    worst = err.max().item() if err.numel() else 0.0
+    frac = (err > tol).double().mean().item() if err.numel() else 0.0
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    PARITY_LOG.append((test, what, worst, mag, tol, frac))
+    if os.environ.get("TS_PARITY_REPORT_ONLY") == "1":       # survey run: record, do not fail
+        return worst / tol if tol > 0 else 0.0
+    assert frac <= max_bad_frac, (f"{what}: {frac:.3e} of entries exceed {tol:.3e} "
+                                  f"(max err {worst:.3e}, |ref|_inf {mag:.3e}); allowed {max_bad_frac:.1e}")
+    return worst / tol if tol > 0 else 0.0

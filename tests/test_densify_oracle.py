@@ -61,6 +61,21 @@ def test_prune_only_and_reset_match_reference():
     assert torch.equal(r, torch.from_numpy(z["reset_opacities"]))
 
 
+def test_update_state_with_caller_rows_matches_reference():
+    """update_state(optim, mask, tensors) of model_gaussian.py:197-242 run by the REFERENCE: kept |
+    appended layout, zero Adam moments for the appended rows, accumulator = surviving rows only."""
+    z = np.load(GOLD / "append_n900_k8.npz")
+    p, m, v, accum = _state(z, "pre")
+    rows = {k: torch.from_numpy(z[f"rows_{k}"]) for k in D.FIELDS}
+    p2, m2, v2, a2 = D.compact(p, m, v, accum, torch.from_numpy(z["mask"]), rows)
+    rp, rm, rv, ra = _state(z, "post")
+    extra = int(z["extra"])
+    for k in D.FIELDS:
+        assert torch.equal(p2[k], rp[k]) and torch.equal(m2[k], rm[k]) and torch.equal(v2[k], rv[k]), k
+        assert torch.equal(rp[k][-extra:], rows[k]) and not rm[k][-extra:].any() and not rv[k][-extra:].any()
+    assert torch.equal(a2, ra) and ra.shape[0] == rp["means"].shape[0] - extra
+
+
 def test_split_is_empty_safe():
     n = 16
     g = torch.Generator().manual_seed(0)

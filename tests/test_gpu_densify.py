@@ -99,6 +99,24 @@ def test_prune_only_matches_reference_fixture():
     assert torch.equal(model.opacities.detach(), before)
 
 
+def test_update_state_with_caller_rows_matches_reference_fixture():
+    """model_gaussian.py:197-242 with caller-made rows, against the state the reference's own
+    GaussianModel.update_state + torch.optim.Adam left behind (tests/golden/append_n900_k8.npz)."""
+    z = np.load(GOLD / "append_n900_k8.npz")
+    p, m, v, accum = _load(z, "pre")
+    model, optim = _on_device(p, m, v)
+    dens = Densifier(model)
+    dens.means_grad_accum = accum.to(DEV)
+    rows = {k: torch.from_numpy(z[f"rows_{k}"]).to(DEV) for k in D.FIELDS}
+    dens.update_state(optim, torch.from_numpy(z["mask"]).to(DEV), rows)
+    rp, rm, rv, ra = _load(z, "post")
+    _check_state(model, optim, dens, rp, rm, rv, ra)
+    assert dens.means_grad_accum.shape[0] == model.means.shape[0] - int(z["extra"])      # :242
+    with pytest.raises(ValueError):                  # ragged appends are refused
+        dens.update_state(optim, torch.zeros(model.means.shape[0], dtype=torch.bool, device=DEV),
+                          {"means": torch.zeros(3, 3, device=DEV)})
+
+
 def _random_state(n, k_rest, seed):
     g = torch.Generator().manual_seed(seed)
     base = torch.empty(n, 1).uniform_(-7.5, -2.0, generator=g)

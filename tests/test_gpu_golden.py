@@ -56,10 +56,21 @@ def test_adapter_frame_on_gpu_matches_reference_adapter_frame(name):
     a64 = [a.double() if isinstance(a, torch.Tensor) and a.is_floating_point() else a for a in ra]
     _, _, aux = O.rasterize_gaussians(*a64, return_aux=True)
     stable = aux["margin"] > 1e-4
-    same = (extras["radii"].cpu() == torch.from_numpy(z["radii"])).double().mean()
-    assert same > 0.995          # exp(scales) runs in torch on a different device here
-    if same == 1.0:
-        assert_close_masked(rgb, torch.from_numpy(z["rgb"]), 2e-5, stable, what="rgb")
-        assert_close_masked(extras["depth"], torch.from_numpy(z["depth"]), 2e-4, stable, what="depth")
+    r_mine, r_gold = extras["radii"].cpu(), torch.from_numpy(z["radii"])
+    differ = r_mine != r_gold
+    assert differ.double().mean() < 0.005      # exp(scales) runs in torch on a different device here
+    # A Gaussian whose integer radius differs (a 1-ulp difference in exp() crossing a ceil()) is listed
+    # in a different set of tiles: the pixels of either footprint are excluded, every other pixel of
+    # the frame is compared with the fixture.
+    clean = torch.ones(dims[1], dims[0], dtype=torch.bool)
+    xy = extras["xys"].cpu()
+    for i in torch.nonzero(differ)[:, 0].tolist():
+        r = int(max(r_mine[i], r_gold[i])) + 17            # the tile rectangle reaches up to 16 px further
+        x0, x1 = int(xy[i, 0]) - r, int(xy[i, 0]) + r + 1
+        y0, y1 = int(xy[i, 1]) - r, int(xy[i, 1]) + r + 1
+        clean[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = False
+    assert clean.double().mean() > 0.5
+    assert_close_masked(rgb, torch.from_numpy(z["rgb"]), 2e-5, stable & clean, what="rgb")
+    assert_close_masked(extras["depth"], torch.from_numpy(z["depth"]), 2e-4, stable & clean, what="depth")
     assert extras["camera"] == {"height": dims[1], "width": dims[0]}
     assert extras["xys"].shape == (int(z["n"]), 2)

@@ -16,7 +16,7 @@ from oracle import gsplat_oracle as O
 from tinysplat_amd import ops
 from tinysplat_amd.rasterizer import GaussianRasterizer, project_args, raster_args, sh_args, tile_bounds
 
-from helpers import assert_close_masked, oracle_frame, scene_args
+from helpers import check_grad, assert_close_masked, oracle_frame, scene_args
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -59,9 +59,7 @@ def test_project_bwd():
     live = radii > 0
     for got, ref, nm in ((md.grad, m64.grad, "means"), (sd.grad, s64.grad, "scales"),
                          (qd.grad, q64.grad, "quats")):
-        ref = ref[live]
-        err = (got.cpu().double()[live] - ref).abs().max() / ref.abs().max()
-        assert err < 2e-4, f"v_{nm}: {err:.2e}"
+        check_grad("project_bwd v_" + nm, got.cpu()[live], ref[live], rel=2e-5)
         assert torch.all(got.cpu()[~live] == 0)
 
 
@@ -208,11 +206,7 @@ def test_raster_bwd(n, w, h, seed, mult, use_alpha):
         loss = loss + (alpha * w_a.to(DEV)).sum()
     loss.backward()
     for i, nm in ((0, "v_xy"), (3, "v_conic"), (5, "v_colors"), (6, "v_opacity")):
-        ref = leaves64[i].grad
-        got = leaves[i].grad.cpu().double()
-        tol = 1e-5 * max(1.0, ref.abs().max().item())
-        bad = ((got - ref).abs() > tol).double().mean().item()
-        assert bad < 1e-4, f"{nm}: {bad:.2e} entries off by more than {tol:.2e}; max {(got-ref).abs().max():.3e}"
+        check_grad(nm, leaves[i].grad, leaves64[i].grad, rel=1e-5)
     # depth is not differentiable through the sort key
     assert da[1].grad is None
 
@@ -277,10 +271,7 @@ def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
     for (a, b), nm in zip(pairs, names):
         if b.grad is None or b.numel() == 0:
             continue
-        ref, got = b.grad, a.grad.cpu().double()
-        tol = 2e-5 * max(1.0, ref.abs().max().item())
-        bad = ((got - ref).abs() > tol).double().mean().item()
-        assert bad < 2e-4, f"grad {nm}: {bad:.2e} off by > {tol:.2e}; max {(got-ref).abs().max():.3e} of {ref.abs().max():.3e}"
+        check_grad(nm, a.grad, b.grad, rel=2e-5)
 
 
 def test_cpu_tensors_raise():
@@ -498,10 +489,7 @@ def test_frame_path_with_opaque_and_faint_gaussians_matches_oracle():
     for a, b, nm in [(md.means, m64.means, "means"), (md.scales, m64.scales, "scales"),
                      (md.quats, m64.quats, "quats"), (md.opacities, m64.opacities, "opacities"),
                      (md.colors_dc, m64.colors_dc, "colors_dc"), (md.colors_rest, m64.colors_rest, "rest")]:
-        ref, got = b.grad, a.grad.cpu().double()
-        tol = 2e-5 * max(1.0, ref.abs().max().item())
-        bad = ((got - ref).abs() > tol).double().mean().item()
-        assert bad < 5e-4, f"grad {nm}: {bad:.2e} off by > {tol:.2e}; max {(got - ref).abs().max():.3e}"
+        check_grad(nm, a.grad, b.grad, rel=2e-5)
 
 
 def test_split_blocks_mapping_matches_one_wave_per_tile():
@@ -588,10 +576,7 @@ def _raster_parity(args, h, w, atol_img=1e-5, use_alpha=True, seed=5):
     assert_close_masked(img, ref_img, atol_img, stable, what="out_img")
     assert_close_masked(alpha, ref_alpha, 1e-5, stable, what="out_alpha")
     for i, nm in ((0, "v_xy"), (3, "v_conic"), (5, "v_colors"), (6, "v_opacity")):
-        ref, got = leaves64[i].grad, leaves[i].grad.cpu().double()
-        tol = 1e-5 * max(1.0, ref.abs().max().item())
-        bad = ((got - ref).abs() > tol).double().mean().item()
-        assert bad < 1e-4, f"{nm}: {bad:.2e} entries off by more than {tol:.2e}; max {(got - ref).abs().max():.3e}"
+        check_grad(nm, leaves[i].grad, leaves64[i].grad, rel=1e-5)
 
 
 def test_raster_four_channels():

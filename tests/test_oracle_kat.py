@@ -198,6 +198,36 @@ def test_vectorised_rasterizer_equals_pixel_loop():
     assert torch.equal(aux["final_index"], fI)
 
 
+def test_tile_batching_does_not_change_results():
+    """rasterize_gaussians groups tiles of similar list length and composites a group with one set of
+    padded tensor ops; tile by tile (batch_elems=0), small groups and one big group must agree: index
+    outputs and final T exactly, colours to summation-order rounding of the per-pixel colour sum, and
+    so must the gradients.  Image height not a multiple of 16 (partial last tile row) and a stripe."""
+    model, cam = scene_args(4000, 1, 200, 120, seed=9, scale_mult=3.0)
+    dims = (200, 120)
+    res = []
+    for be in (0, 1 << 14, 1 << 26):
+        m2, _ = scene_args(4000, 1, 200, 120, seed=9, scale_mult=3.0)
+        m2.requires_grad_(True)
+        f = oracle_frame(m2, cam, dims, depth=False)
+        bg = torch.tensor([0.1, 0.2, 0.3])
+        args = (f["xys"], f["depths"], f["radii"], f["conics"], f["nth"], f["colors"],
+                torch.sigmoid(m2.opacities), 120, 200, bg)
+        img, alpha, aux = O.rasterize_gaussians(*args, return_aux=True, batch_elems=be)
+        part, _ = O.rasterize_gaussians(*args, tile_rows=(2, 5), batch_elems=be)
+        assert torch.equal(part, img[32:80])
+        g = torch.Generator().manual_seed(3)
+        ((img * torch.rand(img.shape, generator=g)).sum() + (alpha * torch.rand(alpha.shape, generator=g)).sum()).backward()
+        res.append((img.detach(), alpha.detach(), aux, [p_.grad.clone() for p_ in m2.parameters()]))
+    ref = res[0]
+    for img, alpha, aux, grads in res[1:]:
+        assert torch.equal(alpha, ref[1]) and torch.equal(aux["final_index"], ref[2]["final_index"])
+        assert torch.equal(aux["final_Ts"], ref[2]["final_Ts"]) and torch.equal(aux["margin"], ref[2]["margin"])
+        assert (img - ref[0]).abs().max() < 1e-6
+        for a, b in zip(grads, ref[3]):
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
+
+
 def test_gradcheck_float64():
     torch.manual_seed(0)
     W, H = 32, 32

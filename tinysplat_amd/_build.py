@@ -39,29 +39,56 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+def _stamp_path(obj: Path) -> Path:
+    return obj.with_suffix(obj.suffix + ".flags")
+
+
+def _flags_match(obj: Path, cmd) -> bool:
+    """An object is only as good as the command line that produced it: ablation builds
+    (TS_EXTRA_HIPCC_FLAGS, e.g. -DTS_ABLATE=3 which makes results WRONG) leave objects that are newer
+    than the sources, so the exact flag list is recorded next to each object and compared."""
+    sp = _stamp_path(obj)
+    return sp.exists() and sp.read_text() == " ".join(cmd[1:])
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     # developer knob for ablation runs (tools/time_raster.py): extra -D flags, implies a rebuild
     extra_env = os.environ.get("TS_EXTRA_HIPCC_FLAGS", "").split()
-    force = force or bool(extra_env)
     headers = [CSRC / "splat_math.h", CSRC.parent.parent / "include" / "tinysplat_hip.h",
                Path(__file__)]          # the flags live in this file
     objs = []
+    relink = False
     for src, extra in SOURCES:
         s = CSRC / src
         o = CSRC / (Path(src).stem + ".o")
-        if force or _stale(o, [s, *headers]):
-            cmd = [hipcc, *COMMON, *extra, *extra_env, "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, *COMMON, *extra, *extra_env, "-c", str(s), "-o", str(o)]
+        if force or _stale(o, [s, *headers]) or not _flags_match(o, cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
+            _stamp_path(o).unlink(missing_ok=True)
             subprocess.run(cmd, check=True)
+            _stamp_path(o).write_text(" ".join(cmd[1:]))
+            relink = True
         objs.append(str(o))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+    # the library records the flag sets of all its objects: a variant library is relinked by the
+    # next default build even though it is newer than every source
+    want = "\n".join(_stamp_path(Path(o)).read_text() for o in objs)
+    lib_stamp = _stamp_path(LIB_PATH)
+    if force or relink or _stale(LIB_PATH, objs) or not lib_stamp.exists() or lib_stamp.read_text() != want:
         if verbose:
             print(" ".join(cmd), flush=True)
+        lib_stamp.unlink(missing_ok=True)
         subprocess.run(cmd, check=True)
+        lib_stamp.write_text(want)
     return LIB_PATH
+
+
+def library_is_default_build() -> bool:
+    """True if the library on disk was built without developer -D overrides (tests/test_abi.py)."""
+    sp = _stamp_path(LIB_PATH)
+    return sp.exists() and "-DTS_" not in sp.read_text()
 
 
 if __name__ == "__main__":

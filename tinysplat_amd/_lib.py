@@ -6,11 +6,12 @@ the ops raises.  Build it with ``python -m tinysplat_amd._build`` (or ``__graft_
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class TsCamera(ctypes.Structure):
@@ -86,6 +87,11 @@ def load() -> ctypes.CDLL:
         raise HipLibraryError(
             f"{LIB_PATH} is missing: tinysplat_amd has no CPU or PyTorch fallback. "
             "Build it with `python -m tinysplat_amd._build` (needs hipcc, targets gfx950).")
+    stamp = LIB_PATH.with_suffix(LIB_PATH.suffix + ".flags")
+    if stamp.exists() and "-DTS_" in stamp.read_text() and os.environ.get("TS_ALLOW_VARIANT_LIB") != "1":
+        raise HipLibraryError(
+            f"{LIB_PATH} was built with developer -DTS_* overrides (ablation variant; its results may be "
+            "wrong). Rebuild with `python -m tinysplat_amd._build`, or set TS_ALLOW_VARIANT_LIB=1.")
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         try:

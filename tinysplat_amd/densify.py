@@ -130,17 +130,34 @@ class Densifier:
     # ------------------------------------------------------------------ :197-242
     @torch.no_grad()
     def update_state(self, optim, mask: Tensor, _tensors=None) -> None:
-        """Drop the rows where ``mask`` is True (the prune-only use, train.py:103-105)."""
-        if _tensors:
-            raise NotImplementedError("appending caller-made rows goes through densify_and_prune")
+        """model_gaussian.py:197-242: drop the rows where ``mask`` is True and append the caller's
+        rows.  Layout kept | appended, exactly the reference's ``cat((param[~mask], tensors[name]))``;
+        Adam moments of appended rows are zero; ``means_grad_accum`` keeps the surviving rows only
+        (``accum[~mask]``, :242 - shorter than the new N until the caller resets it, as in the
+        reference).  ``_tensors`` may name any subset of the six fields; missing ones append nothing,
+        and all given ones must append the same number of rows (the reference would build ragged
+        parameters otherwise).  The prune-only use is train.py:103-105."""
         dev = _need_hip(self.model.means)
         if mask.dtype != torch.bool or mask.shape != (self.model.means.shape[0],):
             raise ValueError("mask must be bool [N]")
+        append = {}
+        for f, t in (_tensors or {}).items():
+            if f not in FIELDS:
+                raise KeyError(f"unknown parameter {f!r}")
+            want = tuple(getattr(self.model, f).shape[1:])
+            if tuple(t.shape[1:]) != want:
+                raise ValueError(f"{f}: rows must have shape {want}")
+            append[f] = _f32c(t.detach().to(dev))
+        live = [f for f in FIELDS if _row_floats(getattr(self.model, f)) > 0]
+        counts = {f: append[f].shape[0] for f in live if f in append}
+        extra = max(counts.values(), default=0)
+        if extra > 0 and (set(counts) != set(live) or set(counts.values()) != {extra}):
+            raise ValueError("every parameter must append the same number of rows")
         flags = mask.to(device=dev, dtype=torch.uint8) * 4          # TS_DENSIFY_PRUNE
-        self._rebuild(optim, flags, None)
+        self._rebuild(optim, flags, None, append=append if extra > 0 else None)
 
     # ------------------------------------------------------------------
-    def _rebuild(self, optim, flags: Tensor, z: Optional[Tensor]) -> None:
+    def _rebuild(self, optim, flags: Tensor, z: Optional[Tensor], append=None) -> None:
         m = self.model
         dev = _need_hip(*[getattr(m, f) for f in FIELDS], flags)
         n = m.means.shape[0]
@@ -160,12 +177,19 @@ class Densifier:
                   _ptr(src_of), s)
             K, C, S, n2 = (int(v) for v in counts.tolist())        # the one host read: sizes the tensors
             self.last_counts = (K, C, S, n2)
-            if K == n and C == 0 and S == 0:
+            extra = 0 if not append else max(t.shape[0] for t in append.values())
+            if K == n and C == 0 and S == 0 and extra == 0:
                 return
-            new = {f: torch.empty((n2,) + tuple(old[f].shape[1:]), **f32) for f in FIELDS}
+            rows = n2 + extra                 # kept | cloned | split samples | caller-made rows
+            new = {f: torch.empty((rows,) + tuple(old[f].shape[1:]), **f32) for f in FIELDS}
             live = [f for f in FIELDS if _row_floats(old[f]) > 0]
             src = {f: old[f].detach() for f in FIELDS}
-            _gather(src, new, live, n2, n2, src_of, dev)
+            _gather(src, new, live, rows, n2, src_of, dev)
+            if extra:
+                for f in FIELDS:
+                    if f in append:
+                        new[f][n2:].copy_(append[f])
+            n2 = rows
             if S > 0:
                 if z is None:
                     z = torch.randn((2 * S, 3), **f32)

@@ -21,7 +21,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import _lib
-from .ops import (TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
+from .ops import (ROWS_PER_PAIR, TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
                   _tile_bounds, deg_from_sh)
 
 # Tight tile lists (see ts_bin_count): (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255
@@ -133,7 +133,7 @@ class _RenderFrame(torch.autograd.Function):
             v_conic = flat[2 * n:5 * n].view(n, 3)
             v_cols = flat[5 * n:(5 + ch) * n].view(n, ch)
             v_opac = flat[(5 + ch) * n:]
-            rows = max(total, 1) * (4 if ctx.split else 1)
+            rows = max(total, 1) * ROWS_PER_PAIR          # one partial row per (tile, Gaussian, 8x8 block)
             partials = torch.empty((rows, 12), **f32)
             row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
             _call("ts_raster_bwd", lib.ts_raster_bwd, ch, ctx.split, total, cam, _ptr(tile_bins), _ptr(ids),
@@ -160,7 +160,12 @@ class _RenderFrame(torch.autograd.Function):
             _call("ts_project_bwd", lib.ts_project_bwd, n, _ptr(means), _ptr(scales), _ptr(quats),
                   _ptr(view34), _ptr(projview), cam, 3, _ptr(radii), _ptr(v_xy), _ptr(v_depth),
                   _ptr(v_conic), None, _ptr(v_means), _ptr(v_scales), _ptr(v_quats), s)
-        ctx.xys_out.grad = v_xy        # what extras['xys'].grad holds in the reference (model_gaussian.py:130-132)
+        # what extras['xys'].grad holds in the reference (model_gaussian.py:130-132).  `xys` carries no
+        # autograd edge on this fused path (retain_grad() is not needed and would raise); the gradient
+        # is a compact copy - not a view that pins the n*(6+ch) buffer - and accumulates like a
+        # retained grad when a second backward reaches the same frame.
+        xo = ctx.xys_out
+        xo.grad = v_xy.clone() if xo.grad is None else xo.grad + v_xy
         return (v_means, v_scales, v_quats, v_opac.view(ctx.opacity_shape), v_dc, v_rest) + (None,) * 12
 
 

@@ -84,6 +84,33 @@ def _colors(model, camera, ops, device, fused_colors):
     return torch.clamp(colors + 0.5, min=0.0)
 
 
+def render_stripe(model, camera, dims, device, rank: int = 0, world_size: int = 1, group=None,
+                  tile_rows: Optional[Tuple[int, int]] = None, with_depth: bool = False,
+                  collective: Optional[bool] = None):
+    """This rank's tile-row stripe of the reference frame (rasterize.py:26-62) through the one-node
+    HIP frame (frame.py): RGB (clamped to <= 1 by the kernels) and, with ``with_depth``, the depth
+    output of rasterize.py:47-51 as channel 3, composited in the same pass.  In backward the flat
+    per-Gaussian 2-D gradient buffer (v_xy | v_conic | v_colors[+v_depth] | v_opacity, (36 + 4 ch) N
+    bytes) is summed over the ranks with ONE all-reduce between the compositing backward and the
+    replicated SH / projection backward, so every rank ends with the complete parameter gradients.
+
+    -> (out[rows, W, 3 or 4], (row_begin_px, row_end_px), xys[N,2]).  ``world_size == 1`` renders the
+    whole frame without a collective; ``collective`` overrides whether the all-reduce runs.
+    """
+    from . import frame as _frame
+    w, h = dims
+    tby = tile_bounds(dims)[1]
+    if tile_rows is None:
+        tile_rows = stripe_rows(tby, world_size, rank)
+    sharded = (world_size > 1) if collective is None else collective
+    view, projview, origin = camera_on_device(camera, device)
+    grp = (group if group is not None else dist.group.WORLD) if sharded else None
+    out, xys, _ = _frame.render_frame(model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
+                                      w, h, with_depth, tile_rows, grp)
+    y0 = 16 * tile_rows[0]
+    return out, (y0, y0 + out.shape[0]), xys
+
+
 def render_rgb_stripe(model, camera, dims, ops, device, rank: int = 0, world_size: int = 1,
                       group=None, tile_rows: Optional[Tuple[int, int]] = None,
                       fused_colors: bool = True, collective: Optional[bool] = None,

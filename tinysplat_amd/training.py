@@ -95,7 +95,7 @@ class _FrameLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_loss, *_):
         (v_frame,) = ctx.saved_tensors
-        return (None if v_frame is None else v_frame.mul_(v_loss)), None, None, None, None
+        return (None if v_frame is None else v_frame * v_loss), None, None, None, None   # out of place: retain_graph re-runs this (train.py:71)
 
 
 def frame_loss(frame: Tensor, target: Tensor, depth_target: Optional[Tensor] = None,

@@ -31,17 +31,23 @@ class ViewRenderer:
         self._pinned = {}
 
     def _host_buffer(self, shape, dtype):
+        """Two pinned buffers per (shape, dtype), used alternately: the array handed out by one
+        request stays valid while the next request renders (an encoder / websocket send may still
+        hold it, viewer.py:44-56) and is overwritten by the request after that."""
         key = (tuple(shape), dtype)
-        buf = self._pinned.get(key)
-        if buf is None:
-            buf = torch.empty(shape, dtype=dtype, pin_memory=True)
-            self._pinned = {key: buf}
-        return buf
+        pair = self._pinned.get(key)
+        if pair is None:
+            pair = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)]
+            self._pinned = {key: pair}
+        pair.reverse()
+        return pair[0]
 
     def render(self, position, quat, as_uint8: bool = False) -> np.ndarray:
         """One ``renderRequest`` (viewer.py:82-95) -> image [H, W, 3] scaled to 0..255:
         float32 exactly as the reference hands it to its encoder (``img * 255``), or rounded
-        uint8 when ``as_uint8`` (what a JPEG encoder consumes)."""
+        uint8 when ``as_uint8`` (what a JPEG encoder consumes).  The returned array is a view of a
+        pinned host buffer that stays untouched until the SECOND following call (double-buffered);
+        copy it to keep it longer."""
         self.camera.update_view_matrix(np.asarray(position, dtype=np.float32),
                                        np.asarray(quat, dtype=np.float32))                 # :84-87
         with torch.no_grad():                                                               # :90

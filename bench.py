@@ -124,11 +124,14 @@ def _median(xs):
     return sorted(xs)[len(xs) // 2]
 
 
-def cpu_baseline(budget_s: float = 120.0):
-    """D6: the pure-PyTorch CPU oracle (kind "port") driven through the adapter's recipe, with
-    ``torch.set_num_threads(<all available cores>)``, 2 warm-ups, median of 5 runs:
+def cpu_baseline(budget_s: float = 100.0):
+    """D6: the pure-PyTorch CPU oracle (kind "port") driven through the adapter's recipe, 2 warm-ups,
+    median of up to 5 runs, everything under a wall-clock budget:
 
-      * BASELINE config 1 (10 k Gaussians, SH 0, 256x256, forward RGB) - always;
+      * BASELINE config 1 (10 k Gaussians, SH 0, 256x256, forward RGB) with
+        ``torch.set_num_threads(<all available cores>)`` as D6 states, and again with 16 threads (the
+        oracle is thousands of small tensor ops; on a many-core host the thread-pool hand-off costs
+        more than it buys) - the faster setting is used for config 2 and both are reported;
       * BASELINE config 2 (100 k, SH 3, 1920x1080, fwd+bwd RGB): first on a bounded sample - the
         same scene, camera and resolution, compositing only tile rows 30..37 of 68 (11.9 % of the
         pixels; projection and SH for all N, as one rank of a sharded frame would) - and, when the
@@ -142,21 +145,19 @@ def cpu_baseline(budget_s: float = 120.0):
     from tinysplat_amd.synthetic import loss_weights, make_scene
     t_begin = time.perf_counter()
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+        avail = os.cpu_count() or 1
     cpu = _cpu_model()
 
     def timed(fn, warm=2, runs=5, deadline=None):
-        for _ in range(warm):
-            fn()
         ts = []
-        for _ in range(runs):
+        for i in range(warm + runs):
             t0 = time.perf_counter()
             fn()
-            ts.append(time.perf_counter() - t0)
-            if deadline is not None and time.perf_counter() > deadline and len(ts) >= 3:
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+            if deadline is not None and time.perf_counter() > deadline and len(ts) >= 1:
                 break
         return _median(ts), len(ts)
 
@@ -170,9 +171,16 @@ def cpu_baseline(budget_s: float = 120.0):
             col = torch.clamp(O.spherical_harmonics(*sh_args(m1, c1, "cpu")) + 0.5, min=0.0)
             O.rasterize_gaussians(*raster_args(m1, xys, depths, radii, conics, nth, col, (w1, h1)))
 
-    t1, r1 = timed(fwd1)
-    config1 = {"value": n1 * w1 * h1 / t1, "ms_per_frame": t1 * 1e3, "runs": r1,
-               "workload": "BASELINE configs[0]: 10k Gaussians, SH 0, 256x256, forward RGB"}
+    config1 = {"workload": "BASELINE configs[0]: 10k Gaussians, SH 0, 256x256, forward RGB"}
+    best_t, cores = None, avail
+    for th in sorted({avail, min(16, avail)}, reverse=True):
+        torch.set_num_threads(th)
+        t1, r1 = timed(fwd1, deadline=t_begin + 0.15 * budget_s * (1 if th == avail else 2))
+        config1[f"threads_{th}"] = {"value": n1 * w1 * h1 / t1, "ms_per_frame": t1 * 1e3, "runs": r1}
+        if best_t is None or t1 < best_t:
+            best_t, cores = t1, th
+    torch.set_num_threads(cores)
+    config1["value"] = n1 * w1 * h1 / best_t
 
     # config 2: fwd+bwd, bounded sample (a stripe of tile rows), then the full frame if affordable
     n2, w2, h2, sh2 = 100_000, 1920, 1080, 3
@@ -199,22 +207,39 @@ def cpu_baseline(budget_s: float = 120.0):
     sample = {"value": n2 * px_s / ts, "ms": ts * 1e3, "runs": rs, "pixels": px_s,
               "workload": f"BASELINE configs[1] (100k Gaussians, SH 3, 1920x1080, fwd+bwd RGB), tile rows "
                           f"{rows[0]}..{rows[1] - 1} of {tby} only ({100.0 * px_s / (w2 * h2):.1f} % of the pixels)"}
-    out = {"value": sample["value"], "unit": "Gaussians*pixels/s", "cores": cores, "kind": "port",
-           "cpu": cpu, "config1_fwd": config1, "config2_sample": sample}
+    out = {"value": sample["value"], "unit": "Gaussians*pixels/s", "cores": cores, "cores_available": avail,
+           "kind": "port", "cpu": cpu, "config1_fwd": config1, "config2_sample": sample}
     est_full = ts * (w2 * h2) / px_s
     left = budget_s - (time.perf_counter() - t_begin)
-    if 5.0 * est_full <= left:           # 2 warm-ups + >= 3 timed runs fit
+    if 4.0 * est_full <= left:           # 2 warm-ups + >= 2 timed runs fit
         tf, rf = timed(fwd_bwd2((0, tby)), deadline=t_begin + budget_s)
         out["config2_full"] = {"value": n2 * w2 * h2 / tf, "ms_per_frame": tf * 1e3, "runs": rf}
         out["value"] = out["config2_full"]["value"]
         what = f"whole frame, median of {rf} runs = {tf * 1e3:.0f} ms/frame"
     else:
         what = (f"bounded sample: tile rows {rows[0]}..{rows[1] - 1} of {tby}, median of {rs} runs = "
-                f"{ts * 1e3:.0f} ms (whole frame predicted {est_full:.0f} s/frame: over the {budget_s:.0f} s budget)")
-    out["sample"] = (f"oracle (pure PyTorch, CPU) through the adapter recipe on {cores} threads of {cpu}; "
+                f"{ts * 1e3:.0f} ms (whole frame predicted {est_full:.1f} s/frame: 2 warm-ups + runs do not fit "
+                f"the {budget_s:.0f} s budget)")
+    out["sample"] = (f"oracle (pure PyTorch, CPU) through the adapter recipe on {cores} of {avail} threads of {cpu}; "
                      f"BASELINE configs[1] 100k SH3 1920x1080 fwd+bwd RGB, {what}; configs[0] forward "
-                     f"{t1 * 1e3:.0f} ms/frame = {config1['value']:.3g} G*px/s; 2 warm-ups each")
+                     f"{best_t * 1e3:.0f} ms/frame = {config1['value']:.3g} G*px/s; 2 warm-ups each")
     return out
+
+
+def cpu_baseline_guarded(timeout_s: float = 240.0):
+    """Runs cpu_baseline() in a child process so that a pathological host (thread-pool stalls) can
+    never hang the bench: on a timeout the bench line carries an explanatory stub instead."""
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-only"],
+                           capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "Gaussians*pixels/s", "cores": 0, "kind": "port",
+                "sample": f"cpu_baseline child failed (rc {r.returncode}): {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "Gaussians*pixels/s", "cores": 0, "kind": "port",
+                "sample": f"cpu_baseline child exceeded {timeout_s:.0f} s and was stopped"}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -320,7 +345,11 @@ def main():
     ap.add_argument("--config", type=int, default=None,
                     help="BASELINE.json config shortcut: 2 = 100k/1080p, 3 = 1M/1080p (default), "
                          "5 = 5M/4K with depth")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if args.config == 2:
         args.n = 100_000
     elif args.config == 5:
@@ -570,7 +599,7 @@ def main():
             out["pmc_per_dispatch"] = {e: {k_: round(v, 1) for k_, v in c.items()} for e, c in sorted(pmc.items())}
         if world == 1 and not args.no_cpu_baseline:
             _log("CPU baseline (oracle on the host cores)")
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline_guarded()
             _log("CPU baseline done")
     if world > 1 or args.force_dist:
         dist.destroy_process_group()

@@ -34,15 +34,14 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 2
+#define TS_ABI_VERSION 1
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
 
 #define TS_TILE 16
 #define TS_SPLAT_RECORD_FLOATS 12   /* packed per-Gaussian record, see ts_pack_splats */
-#define TS_PARTIAL_ROW_FLOATS 12    /* floats per gradient row, see ts_raster_bwd */
-#define TS_ROWS_PER_PAIR 4          /* every (tile, Gaussian) owns one row per 8x8 block: row 4 s + k */
+#define TS_PARTIAL_ROW_FLOATS 12    /* per-(tile,Gaussian) gradient row, see ts_raster_bwd */
 
 int ts_abi_version(void);
 
@@ -169,20 +168,20 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
  * where channel c passes gradient (value <= 1, torch's rule) for ts_raster_bwd. */
 #define TS_RASTER_CLAMP_RGB 2
 /* TS_RASTER_SPLIT_BLOCKS: four waves per tile, one per 8x8 block (same results per pixel).  For launches
- * with fewer tiles than the GPU has SIMDs (a tile-row stripe of a multi-GPU frame, a small image). */
+ * with fewer tiles than the GPU has SIMDs (a tile-row stripe of a multi-GPU frame, a small image).  In
+ * ts_raster_bwd / ts_reduce_partials the flag makes every (tile, Gaussian) own FOUR partial rows (slot
+ * 4 s + block): partials must hold 4 * num_intersects rows and row_flags 4 * num_intersects bytes. */
 #define TS_RASTER_SPLIT_BLOCKS 4
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
                   void* stream);
 
-/* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw sums per contributing
- * (tile, Gaussian, 8x8 block) - row TS_ROWS_PER_PAIR * s + k for list slot s and block k - with
- * v_s = dL/dsigma of a pixel and d = xy - pixel:
+/* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
+ * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
  *   {S v_s, S v_s dx, S v_s dy, S v_s dx^2, S v_s dx dy, S v_s dy^2, v_c0, v_c1, v_c2, v_c3, -, -}
- * partials must hold TS_ROWS_PER_PAIR * I rows and row_flags TS_ROWS_PER_PAIR * I bytes; the flags are
- * zeroed by this call and set to 1 for every row written; rows whose flag stays 0 keep stale
- * contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL.
+ * row_flags[I] (bytes) is zeroed by this call and set to 1 for every row written; rows whose flag
+ * stays 0 keep stale contents and must be ignored (ts_reduce_partials does).  v_out_alpha may be NULL.
  * clamp_mask: NULL, or the mask ts_raster_fwd wrote under TS_RASTER_CLAMP_RGB (v_out_img is then the
  * gradient w.r.t. the clamped image and is zeroed where the clamp was active). */
 int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const ts_camera* cam_host,

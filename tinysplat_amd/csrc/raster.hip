@@ -3,45 +3,35 @@
 // What gsplat's rasterize_forward / rasterize_backward compute for tinysplat's calls at
 // /root/reference/tinysplat/splatting/rasterize.py:44,50 (front-to-back alpha compositing of the
 // depth-sorted per-tile lists, and the back-to-front replay that produces v_xy / v_conic /
-// v_colors / v_opacity), re-designed around the 64-wide wavefront.  Both kernels are VALU-issue bound
-// (one wave64 VALU instruction = 4 cycles of a SIMD), so the design minimises instructions per listed
-// (tile, Gaussian) pair:
+// v_colors / v_opacity), re-designed around the 64-wide wavefront:
 //
 //   * ONE WAVE OWNS ONE 16x16 TILE, seen as four 8x8 pixel blocks.  Lane l sits at (l & 7, l >> 3)
 //     of every block: four pixels per lane, and one VALU instruction covers exactly one block, so
-//     a block is the unit of skipping.  No workgroup barrier anywhere: the four waves of a
+//     a block is the unit of skipping.  There is no workgroup barrier anywhere: the four waves of a
 //     256-thread workgroup run four different tiles independently; early-out is a wave ballot.
 //   * Per 64-entry chunk of the tile's sorted list each lane gathers ONE Gaussian's 48-byte packed
-//     record and tests it exactly against the pixels of each block that still matter (minimum of the
-//     conic form over their bounding rectangle vs. the alpha >= 1/255 level set - conservative, so
-//     results are unchanged).
-//   * BLOCK RECORDS WITH A POLYNOMIAL EXPONENT.  For every (Gaussian, block) that survives, the
-//     Gaussian's lane expands  sigma*log2e - log2(opacity)  around the block centre:
-//         s(X, Y) = c0 + c1 X + c2 Y + c3 X^2 + c4 XY + c5 Y^2,   X, Y = lane position - 3.5,
-//     and appends {c0..c5, colour, list index} to an LDS list of that block (ballot + prefix count).
-//     X, Y, X^2, XY, Y^2 are five per-lane constants of the whole kernel, so the inner loop evaluates
-//     the exponent with 5 FMAs on wave-uniform (LDS-broadcast) coefficients and nothing else has to be
-//     set up per entry and lane (the previous design spent 17 issues per entry on dx, dy and the
-//     partial products of both halves of the tile, whether or not a half was touched).  The four blocks
-//     are walked one after the other ("k-major"): pixels of different blocks are independent, and
-//     inside a block the list order is preserved.
-//   * Per-pixel bodies are branch free inside a block and lean: log2(opacity) is folded into c0, the
-//     compositing weight is T_old - T_new (telescoping), a finished pixel is marked by the sign of
-//     T, and the sigma >= 0 / 0.999-clamp tests exist only in the instantiation used when a staged
-//     Gaussian can trigger them.
-//   * BACKWARD WITHOUT A PER-ENTRY CROSS-LANE REDUCTION.  The gradient of a (tile, Gaussian) is a
-//     sum over pixels, and pixels are lanes: the previous design reduced nine values over the wave
-//     per entry with a merged DPP butterfly (~37 issues per entry, the largest single cost).  Now
-//     pass A (lane = pixel) only resolves the transmittance chain and stores two numbers per pixel -
-//     v_sigma and alpha*T - as one 64-float line per (Gaussian, block) in LDS; every 16 lines, pass B
-//     runs TRANSPOSED (lane = line x pixel quarter): it reads its 16 pixels of both lines and
-//     accumulates the six geometric moments (against compile-time pixel offsets) and the colour sums
-//     (against the block's v_out, kept in an LDS table) in registers, converts the moments to the
-//     Gaussian-centred sums of the row format, combines the four quarters with 2-issue
-//     v_permlane16/32_swap merges and writes 16 rows with three stores.  ~9 issues per line instead
-//     of ~30, no float atomics, and the gradients stay bit-reproducible run to run.
-//   * One partial row per (tile, Gaussian, block): slot 4 s + k.  reduce_partials sums each
-//     Gaussian's flagged rows in a fixed order and applies the conic / opacity factors once.
+//     record (3 x 16 B loads) and tests it exactly against each 8x8 block (minimum of the conic
+//     form over the block rectangle vs. the alpha >= 1/255 level set - conservative, so results
+//     are unchanged).  Gaussians that can reach a still-unfinished block are compacted into LDS
+//     with a wave ballot + prefix count, carrying a 4-bit block mask; the inner loop reads each
+//     survivor back with wave-uniform (broadcast) ds_read_b128s and runs the per-pixel math only
+//     for the blocks in its mask (scalar branches).  The rectangle a Gaussian is tested against is
+//     not the whole block but the bounding box of the block's pixels that still matter (forward:
+//     not yet saturated; backward: list already started), recomputed per chunk from a ballot with
+//     scalar bit arithmetic, so dense scenes shed work pixel row by pixel row and stop early.
+//   * Per-pixel bodies are branch free inside a block and lean: log2(opacity) is folded into the
+//     exponent, the compositing weight is T_old - T_new (telescoping), a finished pixel is marked
+//     by the sign of T, and Gaussians that need the sigma >= 0 / 0.999-clamp tests are flagged at
+//     staging so that the common chunk runs a loop without them.  Both kernels are VALU-issue
+//     bound (~4 cycles per wave64 VALU op), so instruction count is what sets their time; this
+//     file is built with -fno-slp-vectorize because the SLP packer's register shuffles cost more
+//     issue slots than its v_pk_* ops save.
+//   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
+//     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
+//     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot
+//     that is contiguous per Gaussian.  reduce_partials sums each Gaussian's rows in a fixed order
+//     and applies the conic / opacity factors once: no float atomics, and the gradients are
+//     bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"
@@ -66,10 +56,6 @@ namespace {
 #endif
 constexpr int kWaves = TS_RASTER_WAVES;   // tiles (= waves) per workgroup; waves never synchronise
 constexpr int kThreads = 64 * kWaves;
-constexpr int kRows = 16;                 // (Gaussian, block) lines per pass B of the backward kernel
-constexpr int kRowStride = 68;            // floats per line: 4 * odd -> the strided b128 reads of pass B
-                                          // start in 16 different bank groups
-constexpr int kVoStride = 65;             // float4s per block of the v_out table (bank stagger)
 using ts::kLog2e;
 using ts::kLog2_255;
 
@@ -86,6 +72,12 @@ __device__ __forceinline__ int wave_max_int(int v) {
     return v;
 }
 
+// sigma * log2(e) for one pixel; explicit fmas so that forward and backward (which must replay the
+// forward's alpha >= 1/255 decisions) evaluate bit-identical values whatever the optimiser does.
+__device__ __forceinline__ float sigma_l2(float diag, float Bdx, float dy) {
+    return __builtin_fmaf(dy, Bdx, diag);      // diag = hA dx^2 + hC dy^2
+}
+
 // XCD-aware workgroup -> tile-group mapping.  Workgroup b is observed to run on XCD (b % 8), and
 // every XCD has a private 4 MiB L2.  Handing XCD x the x-th contiguous eighth of the tile groups
 // (a band of tile rows) keeps the packed-record gathers of neighbouring tiles, which share most of
@@ -99,8 +91,14 @@ __device__ __forceinline__ int xcd_tile_group(int num_groups) {
     return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 }
 
+struct Staged {          // what a lane derives from the Gaussian it gathered
+    int mask;            // bit k set: the alpha >= 1/255 level set may reach 8x8 block k of the tile
+    float gx, gy, hA, B, hC, lo;   // conic and opacity in the log2 domain
+};
+
 // Bounding rectangle (in lane coordinates 0..7) of the pixels of an 8x8 block selected by a 64-bit
 // lane mask (bit = ly*8 + lx).  Pure scalar bit arithmetic on the ballot.  Returns false if empty.
+struct BlockRect { float x0, x1, y0, y1; };          // inclusive sample-position bounds
 __device__ __forceinline__ bool mask_rect(unsigned long long m, int& xmin, int& xmax, int& ymin,
                                           int& ymax) {
     if (m == 0ull) return false;
@@ -115,9 +113,49 @@ __device__ __forceinline__ bool mask_rect(unsigned long long m, int& xmin, int& 
     return true;
 }
 
-// Writes rects[k] = {x0, x1, y0, y1} (sample-position bounds, inclusive) of the pixels selected by
-// `sel[k]` (one bool per lane and block) and returns the mask of non-empty blocks.  Lane 0 stores;
-// callers fence before reading.
+// gather + exact cull against the four 8x8 pixel blocks of the tile (block k: bx = k&1, by = k>>1).
+// rects[k] = sample-position bounding rectangle of the pixels of block k that still matter (all of
+// the block at first; it shrinks as pixels saturate in the forward pass / covers only the pixels
+// whose lists have started in the backward pass), kept in LDS so that the rolled loop can index it.
+// blocks = bit mask of the blocks whose rectangle is non-empty.
+__device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const float4 q1,
+                                              const float4* __restrict__ rects, int blocks) {
+    Staged s;
+    s.gx = q0.x; s.gy = q0.y;
+    const float A = q0.w, Bc = q1.x, Cc = q1.y, op = q0.z;
+    s.hA = 0.5f * kLog2e * A;
+    s.B = kLog2e * Bc;
+    s.hC = 0.5f * kLog2e * Cc;
+    s.lo = __log2f(op);
+    s.mask = 0;
+    // bit 4 ("general"): the per-pixel code must test sigma >= 0 and apply the 0.999 clamp.  For a
+    // positive-definite conic and opacity <= 0.99 neither can trigger (sigma >= 0 up to rounding,
+    // alpha = opacity * exp(-sigma) <= opacity), and the kernels take a leaner wave-uniform path.
+    const bool general = !(s.hA > 0.0f && s.hC > 0.0f && 4.0f * s.hA * s.hC > s.B * s.B && op <= 0.99f);
+    if (have && op > 0.0f) {
+        const float tau = s.lo + kLog2_255;            // sigma' <= tau  <=>  alpha >= 1/255
+        if (tau >= -0.02f) {
+            if (s.hA > 0.0f && s.hC > 0.0f) {
+                const float inv2A = 0.5f / s.hA, inv2C = 0.5f / s.hC;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {           // rolled: runs once per 64 entries, keeps VGPRs low
+                    if (!(blocks & (1 << k))) continue;
+                    const float4 r = rects[k];          // {x0, x1, y0, y1}, wave-uniform
+                    if (ts::rect_may_contribute(s.hA, s.B, s.hC, inv2A, inv2C, tau, s.gx, s.gy, r.x, r.y, r.z,
+                                                r.w))
+                        s.mask |= (1 << k);
+                }
+            } else {
+                s.mask = blocks;                        // not a PSD conic: no geometric cull
+            }
+            if (s.mask != 0 && general) s.mask |= 16;
+        }
+    }
+    return s;
+}
+
+// Writes rects[k] for the pixels selected by `sel[k]` (one bool per lane and block) and returns the
+// mask of non-empty blocks.  Lane 0 stores; callers fence before reading.
 __device__ __forceinline__ int update_rects(const bool sel[4], float X0, float Y0, float4* rects,
                                             int lane) {
     int blocks = 0;
@@ -140,112 +178,64 @@ using mask64 = unsigned long long;
 #define TS_BALLOT(c) __builtin_amdgcn_ballot_w64(c)          // lane condition -> 64-bit scalar mask
 #define TS_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)    // scalar mask -> lane condition
 
-// Per-lane constants: the lane's sample position relative to the centre of its 8x8 block (the same
-// in all four blocks) and the monomials the exponent polynomial needs.
-struct Geom { float X, Y, XX, XY, YY; };
-__device__ __forceinline__ Geom lane_geom(int lane) {
-    Geom g;
-    g.X = (float)(lane & 7) - 3.5f;
-    g.Y = (float)(lane >> 3) - 3.5f;
-    g.XX = g.X * g.X; g.XY = g.X * g.Y; g.YY = g.Y * g.Y;
-    return g;
-}
-
-// What a lane derives once per chunk from the Gaussian it gathered (lane = list entry).
-struct Staged {
-    bool cand;           // may contribute at all (opacity > 0, level set not empty)
-    bool psd;            // positive-definite conic: the geometric cull applies
-    bool general;        // the per-pixel code must test sigma >= 0 and apply the 0.999 clamp
-    float gx, gy, hA, B, hC, lo, tau, inv2A, inv2C;
-};
-
-__device__ __forceinline__ Staged stage_gaussian(bool have, const float4 q0, const float4 q1) {
-    Staged s;
-    s.gx = q0.x; s.gy = q0.y;
-    const float op = q0.z;
-    s.hA = 0.5f * kLog2e * q0.w;
-    s.B = kLog2e * q1.x;
-    s.hC = 0.5f * kLog2e * q1.y;
-    s.lo = __log2f(op);
-    s.tau = s.lo + kLog2_255;                      // sigma' <= tau  <=>  alpha >= 1/255
-    s.psd = s.hA > 0.0f && s.hC > 0.0f;
-    s.inv2A = 0.5f / s.hA; s.inv2C = 0.5f / s.hC;
-    // For a positive-definite conic and opacity <= 0.99 neither the sigma >= 0 test nor the 0.999
-    // clamp can trigger (sigma >= 0 up to rounding, alpha <= opacity): the lean loop is exact.
-    s.general = !(s.psd && 4.0f * s.hA * s.hC > s.B * s.B && op <= 0.99f);
-    s.cand = have && op > 0.0f && s.tau >= -0.02f;
-    return s;
-}
-
-// Can the Gaussian reach alpha >= 1/255 inside the rectangle r = {x0, x1, y0, y1} of a block?
-__device__ __forceinline__ bool block_hit(const Staged& s, const float4 r) {
-    if (!s.cand) return false;
-    if (!s.psd) return true;                       // not a PSD conic: no geometric cull
-    return ts::rect_may_contribute(s.hA, s.B, s.hC, s.inv2A, s.inv2C, s.tau, s.gx, s.gy, r.x, r.y, r.z, r.w);
-}
-
-// Expansion of  hA dx^2 + B dx dy + hC dy^2 - log2(opacity),  d = xy - pixel,  around a block centre:
-// with (dxc, dyc) = xy - centre and pixel = centre + (X, Y):  dx = dxc - X, dy = dyc - Y.
-struct Coefs { float c0, c1, c2; };
-__device__ __forceinline__ Coefs block_coefs(const Staged& s, float dxc, float dyc) {
-#pragma clang fp contract(off)
-    Coefs c;
-    const float t = s.B * dxc;
-    c.c0 = ((s.hA * dxc) * dxc + t * dyc) + ((s.hC * dyc) * dyc - s.lo);
-    c.c1 = -(2.0f * (s.hA * dxc) + s.B * dyc);
-    c.c2 = -(2.0f * (s.hC * dyc) + t);
-    return c;
-}
-
-// s(X, Y) of one pixel: explicit FMAs in a fixed order, so that forward and backward (which must
-// replay the forward's alpha >= 1/255 decisions) evaluate bit-identical values.
-__device__ __forceinline__ float poly_sigma(const Geom& g, const float4 r0, const float4 r1) {
-    float s = __builtin_fmaf(g.X, r0.y, r0.x);
-    s = __builtin_fmaf(g.Y, r0.z, s);
-    s = __builtin_fmaf(g.XX, r0.w, s);
-    s = __builtin_fmaf(g.XY, r1.x, s);
-    return __builtin_fmaf(g.YY, r1.y, s);
-}
-
-// Composites the `cnt` records of one block into its 64 pixels (forward).
-//   T > 0 = transmittance of an unfinished pixel; T < 0 = finished (or outside the image) with final
-//   transmittance |T|; fidx = list index of the last Gaussian composited; acc = colour.
-// record = { c0 c1 c2 c3 | c4 c5 col0 col1 | col2 col3 idx log2(opacity) }
+// Composites the `cnt` staged Gaussians of one chunk into the wave's tile (forward).
+//   per pixel and block k: T > 0 = transmittance of an unfinished pixel; T < 0 = finished (or
+//   outside the image) with final transmittance |T|; fidx = list index of the last Gaussian
+//   composited; acc = colour.
 // vis = |T_old| - |T_new| equals alpha*T up to one rounding of T, is 0 for the stopping Gaussian
 // and for finished pixels, and makes the weights telescope (sum of vis = 1 - T_final exactly).
+// GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
+// positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
 template <int CH, bool GENERAL>
-__device__ __forceinline__ void fwd_records(const float4* __restrict__ lds, int cnt, const Geom g,
-                                            float& T, int& fidx, float (&acc)[CH]) {
-#pragma clang fp contract(off)          // both instantiations must round alike
+__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
+                                          float fpy0, float (&T)[4], int (&fidx)[4],
+                                          float (&acc)[4][CH]) {
+#pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
+        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
         const int idx = __float_as_int(r2.z);
-        // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
-        const float sgl = poly_sigma(g, r0, r1);
-        float a = __builtin_amdgcn_exp2f(-sgl);
-        bool ok = a >= ts::kAlphaMin;
-        if (GENERAL) {
-            a = fminf(ts::kAlphaMax, a);
-            ok = ok & (sgl >= -r2.w);                                 // sigma >= 0
+        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
+        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+        const float neg_lo = -r1.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Ax[h] = (r0.z * dxv[h]) * dxv[h];
+            Bx[h] = r0.w * dxv[h];
+            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
         }
-        // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, so
-        // either `stop` fires and -|T| puts T back, or ae = 0 and nT = T; vis is 0 both ways.
-        const float ae = ok ? a : 0.0f;
-        const float nT = __builtin_fmaf(-ae, T, T);
-        const bool stop = (nT <= ts::kTEps) & ok;
-        const float Tn = stop ? -__builtin_fabsf(T) : nT;            // the stopping Gaussian is not composited
-        const float vis = __builtin_fabsf(T) - __builtin_fabsf(Tn);
-        acc[0] = __builtin_fmaf(r1.z, vis, acc[0]);
-        acc[1] = __builtin_fmaf(r1.w, vis, acc[1]);
-        acc[2] = __builtin_fmaf(r2.x, vis, acc[2]);
-        if (CH == 4) acc[CH - 1] = __builtin_fmaf(r2.y, vis, acc[CH - 1]);
-        fidx = (ok & !stop) ? idx : fidx;
-        T = Tn;
+        float col[CH];
+        col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
+        if (CH == 4) col[CH - 1] = r2.y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(bm & (1 << k))) continue;                           // wave-uniform
+            // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
+            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dyv[k >> 1]);
+            float a = __builtin_amdgcn_exp2f(-sgl);
+            bool ok = a >= ts::kAlphaMin;
+            if (GENERAL) {
+                a = fminf(ts::kAlphaMax, a);
+                ok = ok & (sgl >= neg_lo);                            // sigma >= 0
+            }
+            // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, so
+            // either `stop` fires and -|T| puts T back, or ae = 0 and nT = T; vis is 0 both ways.
+            const float ae = ok ? a : 0.0f;
+            const float nT = __builtin_fmaf(-ae, T[k], T[k]);
+            const bool stop = (nT <= ts::kTEps) & ok;
+            const float Tn = stop ? -__builtin_fabsf(T[k]) : nT;   // the stopping Gaussian is not composited
+            const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
+            fidx[k] = (ok & !stop) ? idx : fidx[k];
+            T[k] = Tn;
+        }
     }
 }
 
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
-// that position in each of the four blocks k of the 16x16 tile (block k: bx = k & 1, by = k >> 1).
+// that position in each of the four blocks k of the 16x16 tile.
 // SPLIT: four waves per tile, each owning ONE 8x8 block (the other three count as outside the image).
 // Same list, same arithmetic per pixel; used when a launch has fewer tiles than the GPU has SIMDs (a
 // tile-row stripe of a multi-GPU frame, a small image), where one wave per tile leaves the vector ALUs
@@ -270,9 +260,9 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
     const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
     const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
-    const Geom geom = lane_geom(lane);
 
     // T > 0: transmittance of an unfinished pixel; T < 0: finished or outside, final value |T|
     float T[4], acc[4][CH];
@@ -293,7 +283,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
 
     // Software pipeline over 64-entry chunks: the id of chunk c+2 and the packed record of chunk
     // c+1 are in flight while chunk c is composited (two dependent gathers = ~2 us of latency
-    // that a wave with few co-resident waves per SIMD cannot hide otherwise).
+    // that a wave with ~3 co-resident waves per SIMD cannot hide otherwise).
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
     int id_next = 0;
@@ -321,31 +311,24 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             TS_WAVE_SYNC();
             if (live == 0) break;
         }
-        const Staged s = stage_gaussian(have, q0, q1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!(live & (1 << k))) continue;                         // wave-uniform
-            const bool hit = block_hit(s, rects[k]);
-            const mask64 mask = __ballot(hit);
-            if (mask == 0ull) continue;
-            const int cnt = __popcll(mask);
-            if (hit) {
-                const float bcx = X0 + (float)(8 * (k & 1)) + 3.5f, bcy = Y0 + (float)(8 * (k >> 1)) + 3.5f;
-                const Coefs c = block_coefs(s, s.gx - bcx, s.gy - bcy);
-                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-                lds[3 * pos] = make_float4(c.c0, c.c1, c.c2, s.hA);
-                lds[3 * pos + 1] = make_float4(s.B, s.hC, q1.z, q1.w);
-                lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), s.lo);
-            }
-            TS_WAVE_SYNC();
-            // the general per-pixel code is chosen once per block list, so that the common case runs
-            // a loop without the sigma >= 0 / clamp tests
-            if (__ballot(hit && s.general) != 0ull)
-                fwd_records<CH, true>(lds, cnt, geom, T[k], fidx[k], acc[k]);
-            else
-                fwd_records<CH, false>(lds, cnt, geom, T[k], fidx[k], acc[k]);
-            TS_WAVE_SYNC();
+        const Staged s = stage_splat(have, q0, q1, rects, live);
+        const bool keep = s.mask != 0;
+        const unsigned long long mask = __ballot(keep);
+        const int cnt = __popcll(mask);
+        if (keep) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            lds[3 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
+            lds[3 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
+            lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
+        TS_WAVE_SYNC();
+        // bit 4 of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
+        // once per chunk so that the common case runs a loop without those tests
+        if (__ballot(keep && (s.mask & 16)) != 0ull)
+            fwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, fidx, acc);
+        else
+            fwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, fidx, acc);
+        TS_WAVE_SYNC();
     }
 
     float bg[CH];
@@ -376,150 +359,161 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     }
 }
 
-// gfx950 row / half swaps: v_permlane16_swap exchanges the odd 16-lane rows of x with the even rows of
-// y, v_permlane32_swap the upper half of x with the lower half of y; x' + y' is then a butterfly MERGE
-// of two values across rows in 2 VALU issues (DPP cannot cross rows at all).
-__device__ __forceinline__ float swap16_add(float x, float y) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows: [x0+x1, y0+y1, x2+x3, y2+y3]
-}
-__device__ __forceinline__ float swap32_add(float x, float y) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // halves: [x_lo+x_hi, y_lo+y_hi]
+// Butterfly merge of two per-lane partial vectors: lanes whose `bit` is clear keep a, the others
+// keep b, and each adds the kept quantity of its partner lane (partner given by the DPP control).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float merge2(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
 }
 
-// Pass B of the backward kernel: turns up to kRows (Gaussian, block) lines of per-pixel {v_sigma,
-// alpha*T} into partial rows.  Lane = (line r = lane & 15, pixel quarter q = lane >> 4): the lane sums
-// the 16 pixels (two pixel rows) of its quarter.
-//   geometric part: moments of v against the pixel offsets (X = lx - 3.5 is a compile-time constant
-//     per step; the two pixel rows of a quarter are kept apart and shifted to the block-centred Y
-//     afterwards), then converted to the row format's Gaussian-centred sums with dx = dxc - X,
-//     dy = dyc - Y (dxc, dyc = Gaussian centre - block centre, from the line's meta record);
-//   colour part: sum of alpha*T times the pixel's v_out, read from the wave's LDS table of its tile;
-//   the four quarters are merged with v_permlane16/32_swap (2 issues per merge), after which the lane
-//     of quarter p holds values p, 4 + p and 8 + (p & 1) of line r, and stores them.
-// meta[r] = { dxc, dyc, row slot (int), block k (int) }.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_t(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// Reduces ten per-lane values over the wave in one merged butterfly.  On return lane l holds the wave
+// sum of value (l & 7) if bit 3 of l is clear, of value 8 + (l & 1) otherwise.
+//   level 1  partner l ^ 1 (quad_perm):  5 merges, lanes with bit 0 keep the odd value of each pair
+//   level 2  partner l ^ 2 (quad_perm):  2 merges (bit 1) + 1 plain add for the {8,9} pair
+//   level 3  row_ror:4:                  1 merge (bit 2) + 1 plain add
+//   level 4  row_ror:8:                  1 merge (bit 3): values 0..7 | values 8,9  -> row-of-16 totals
+//   rows are combined lane-wise through the LDS crossbar (ds_bpermute; the single-lane row_bcast forms
+//   cannot be used because lanes of a row hold different values).
+// 31 VALU issues + 2 ds_bpermute for 10 values (a plain DPP reduction is 6-8 per value).
+template <bool HAVE9>
+__device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const float u0 = merge2<0xB1>(v[0], v[1], b0), u1 = merge2<0xB1>(v[2], v[3], b0);
+    const float u2 = merge2<0xB1>(v[4], v[5], b0), u3 = merge2<0xB1>(v[6], v[7], b0);
+    // without a tenth value the {8,9} "pair" is a plain add (both lanes of a pair then hold value 8)
+    float t = HAVE9 ? merge2<0xB1>(v[8], v[9], b0) : dpp_add_t<0xB1, 0xF>(v[8]);
+    const float w0 = merge2<0x4E>(u0, u1, b1), w1 = merge2<0x4E>(u2, u3, b1);
+    t = dpp_add_t<0x4E, 0xF>(t);
+    float x = merge2<0x124>(w0, w1, b2);     // row_ror:4  (source lane differs in bit 2, same bits 1:0)
+    t = dpp_add_t<0x124, 0xF>(t);
+    x = merge2<0x128>(x, t, b3);             // row_ror:8
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+// Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
+// (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag).
 template <int CH>
-__device__ __forceinline__ void pass_b(const float* __restrict__ vbuf, const float* __restrict__ fbuf,
-                                       const float4* __restrict__ vo_tab, const float4* __restrict__ meta,
-                                       int nrows, float* __restrict__ partials,
-                                       unsigned char* __restrict__ row_flags, int lane) {
-    const int r = lane & 15, q = lane >> 4;
-    const float4 m = meta[r];
-    const float dxc = m.x, dyc = m.y;
-    const int slot = __float_as_int(m.z), k = __float_as_int(m.w) & 3;
-    const float4* vl = reinterpret_cast<const float4*>(vbuf + r * kRowStride + 16 * q);
-    const float4* fl = reinterpret_cast<const float4*>(fbuf + r * kRowStride + 16 * q);
-    const float4* vo = vo_tab + k * kVoStride + 16 * q;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;   // pixel row 2q | 2q + 1
-    float col[CH];
+__device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
+                                          float* __restrict__ partials,
+                                          unsigned char* __restrict__ row_flags, int lane) {
+    float r;
+    if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
+        r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + v[8];
+    } else {
+        float v10[10];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) col[c] = 0.0f;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const float4 v4 = vl[h], f4 = fl[h];
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int s = 4 * h + e;
-            const float X = (float)(s & 7) - 3.5f;
-            if (s < 8) {
-                a0 += vv[e];
-                a1 = __builtin_fmaf(vv[e], X, a1);
-                a2 = __builtin_fmaf(vv[e], X * X, a2);
-            } else {
-                b0 += vv[e];
-                b1 = __builtin_fmaf(vv[e], X, b1);
-                b2 = __builtin_fmaf(vv[e], X * X, b2);
-            }
-            const float4 w = vo[s];
-            col[0] = __builtin_fmaf(ff[e], w.x, col[0]);
-            col[1] = __builtin_fmaf(ff[e], w.y, col[1]);
-            col[2] = __builtin_fmaf(ff[e], w.z, col[2]);
-            if (CH == 4) col[CH - 1] = __builtin_fmaf(ff[e], w.w, col[CH - 1]);
-        }
+        for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
+        r = wave_sum10<(CH == 4)>(v10, lane);
     }
-    // block-centred moments of this quarter: Y = y' + Yq with y' in {0, 1}
-    const float Yq = (float)(2 * q) - 3.5f;
-    const float M0 = a0 + b0, Mx = a1 + b1, Mxx = a2 + b2;
-    const float My = __builtin_fmaf(Yq, M0, b0);
-    const float Mxy = __builtin_fmaf(Yq, Mx, b1);
-    const float Myy = __builtin_fmaf(Yq, __builtin_fmaf(Yq, M0, 2.0f * b0), b0);
-    // Gaussian-centred sums (dx = dxc - X, dy = dyc - Y):  S v, S v dx, S v dy, S v dx^2, S v dx dy, S v dy^2
-    float val[10];
-    val[0] = M0;
-    val[1] = __builtin_fmaf(dxc, M0, -Mx);
-    val[2] = __builtin_fmaf(dyc, M0, -My);
-    val[3] = __builtin_fmaf(dxc, __builtin_fmaf(dxc, M0, -2.0f * Mx), Mxx);
-    val[4] = __builtin_fmaf(dxc, __builtin_fmaf(dyc, M0, -My), __builtin_fmaf(-dyc, Mx, Mxy));
-    val[5] = __builtin_fmaf(dyc, __builtin_fmaf(dyc, M0, -2.0f * My), Myy);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) val[6 + c] = c < CH ? col[c] : 0.0f;
-    // merge the four quarters: quarter p ends with values p, 4 + p, 8 + (p & 1)
-    const float q0 = swap32_add(swap16_add(val[0], val[1]), swap16_add(val[2], val[3]));
-    const float q1 = swap32_add(swap16_add(val[4], val[5]), swap16_add(val[6], val[7]));
-    const float t = swap16_add(val[8], CH == 4 ? val[9] : val[8]);
-    const float q2 = t + __shfl_xor(t, 32, 64);
-    if (r < nrows) {
-        float* p = partials + (size_t)slot * TS_PARTIAL_ROW_FLOATS;
-        p[q] = q0;
-        p[4 + q] = q1;
-        if (q < 2 && 8 + q < 6 + CH) p[8 + q] = q2;
-        if (q == 3) row_flags[slot] = 1;                       // this row now holds data
+    const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
+    const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
+    (void)num_isects;
+    if (w >= 0) {
+        if (w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
+        else if (w == 10) row_flags[slot] = 1;                 // this row now holds data
     }
 }
 
-// Pass A of the backward kernel for the records of one block, record index j0 .. cnt-1 (records are
-// staged back to front).  Resolves the transmittance chain per pixel and stores one line per record
-// with a contributing pixel; stops when kRows lines are pending and returns the next record index.
-//   T = transmittance behind the Gaussian being replayed, R = T_final * (v_alpha - bg . v_out) -
-//   sum over the Gaussians already replayed of fac * (colour . v_out), vo = v_out, fidx = index of
-//   the last Gaussian the forward pass composited.
-// record = { c0 c1 c2 c3 | c4 c5 col0 col1 | col2 col3 idx log2(opacity) | dxc dyc slot k }
-// A lane that is not valid uses alpha = 0 (ra = 1, fac = 0, v_sig = 0) and changes nothing.
+// Replays the `cnt` staged Gaussians of one chunk back to front (backward).
+//   per pixel and block k: T = transmittance behind the Gaussian being replayed, R = T_final *
+//   (v_alpha - bg . v_out) - sum over the Gaussians already replayed of fac * (colour . v_out),
+//   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
+// Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
+// (ra = 1, fac = 0, v_sig = 0) and changes nothing.
 template <int CH, bool GENERAL>
-__device__ __forceinline__ int bwd_records(const float4* __restrict__ lds, int j0, int cnt, const Geom g,
-                                           float& T, float& R, const float (&vo)[CH], const int fidx,
-                                           float* __restrict__ vbuf, float* __restrict__ fbuf,
-                                           float4* __restrict__ meta, int& nrows, int lane) {
+__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
+                                          float fpy0, float (&T)[4], float (&R)[4],
+                                          const float (&vo)[4][CH], const int (&fidx)[4],
+                                          float (&acc)[6 + CH], long long num_isects,
+                                          float* __restrict__ partials,
+                                          unsigned char* __restrict__ row_flags, int lane) {
     // Every fused multiply-add below is written out; implicit contraction is switched off so that the
-    // GENERAL and the lean instantiation round identically.
+    // GENERAL and the lean instantiation round identically (otherwise `acc[0] += -am * v_a` fuses
+    // in one and not in the other, and a gradient would depend on which chunk an entry lands in).
 #pragma clang fp contract(off)
-    int j = j0;
-    for (; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
+    for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
+        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
         const int idx = __float_as_int(r2.z);
-        const float sgl = poly_sigma(g, r0, r1);
-        const float araw = __builtin_amdgcn_exp2f(-sgl);             // opacity * exp(-sigma)
-        float a = araw;
-        mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx);
-        if (GENERAL) {
-            a = fminf(ts::kAlphaMax, araw);
-            validm &= TS_BALLOT(sgl >= -r2.w);                       // sigma >= 0
+        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
+        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
+        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
+        const float neg_lo = -r1.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Ax[h] = (r0.z * dxv[h]) * dxv[h];
+            Bx[h] = r0.w * dxv[h];
+            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
         }
-        if (validm == 0ull) continue;                                // wave-uniform
-        const float am = TS_LANE(validm) ? a : 0.0f;
-        const float ra = __builtin_amdgcn_rcpf(1.0f - am);
-        const float Tk = T * ra;                        // transmittance in front of the Gaussian
-        const float fac = am * Tk;
-        float cv = r1.z * vo[0];                        // colour . v_out of this pixel
-        cv = __builtin_fmaf(r1.w, vo[1], cv);
-        cv = __builtin_fmaf(r2.x, vo[2], cv);
-        if (CH == 4) cv = __builtin_fmaf(r2.y, vo[CH - 1], cv);
-        // dL/dalpha = Tk (c . v_out) + ra (T_final (v_alpha - bg . v_out) - S_behind fac' c' . v_out)
-        const float v_a = __builtin_fmaf(Tk, cv, ra * R);
-        R = __builtin_fmaf(-fac, cv, R);
-        T = Tk;
-        // d alpha / d sigma = -alpha, or 0 where the 0.999 clamp is active
-        float v_sig = -am * v_a;
-        if (GENERAL) v_sig = TS_LANE(TS_BALLOT(araw > ts::kAlphaMax)) ? 0.0f : v_sig;
-        vbuf[nrows * kRowStride + lane] = v_sig;
-        fbuf[nrows * kRowStride + lane] = fac;
-        if (lane == 0) meta[nrows] = lds[4 * j + 3];
-        ++nrows;
-        if (nrows == kRows) { ++j; break; }
+        float col[CH];
+        col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
+        if (CH == 4) col[CH - 1] = r2.y;
+
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(bm & (1 << k))) continue;                           // wave-uniform
+            const float dx = dxv[k & 1], dy = dyv[k >> 1];
+            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dy);
+            const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
+            float a = araw;
+            mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx[k]);
+            if (GENERAL) {
+                a = fminf(ts::kAlphaMax, araw);
+                validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
+            }
+            if (validm == 0ull) continue;                              // wave-uniform
+            any = 1;
+            const float am = TS_LANE(validm) ? a : 0.0f;
+            const float ra = __builtin_amdgcn_rcpf(1.0f - am);
+            const float Tk = T[k] * ra;                 // transmittance in front of the Gaussian
+            const float fac = am * Tk;
+            float cv = col[0] * vo[k][0];               // colour . v_out of this pixel
+#pragma unroll
+            for (int c = 1; c < CH; ++c) cv = __builtin_fmaf(col[c], vo[k][c], cv);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[6 + c] = __builtin_fmaf(fac, vo[k][c], acc[6 + c]);
+            // dL/dalpha = Tk (c . v_out) + ra (T_final (v_alpha - bg . v_out) - S_behind fac' c' . v_out)
+            const float v_a = __builtin_fmaf(Tk, cv, ra * R[k]);
+            R[k] = __builtin_fmaf(-fac, cv, R[k]);
+            T[k] = Tk;
+            // d alpha / d sigma = -alpha, or 0 where the 0.999 clamp is active
+            float v_sig = -am * v_a;
+            if (GENERAL) v_sig = TS_LANE(TS_BALLOT(araw > ts::kAlphaMax)) ? 0.0f : v_sig;
+            const float vdx = v_sig * dx, vdy = v_sig * dy;
+            acc[0] += v_sig; acc[1] += vdx; acc[2] += vdy;
+            acc[3] = __builtin_fmaf(vdx, dx, acc[3]);
+            acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
+            acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
+        }
+        // `any` is wave-uniform.  It is passed through an empty asm so that the compiler cannot prove
+        // "block 3 ran => a flush follows": with that knowledge it specialises the last block body
+        // (results in fresh registers) and pays for it with 10-17 register copies per entry on the
+        // joining paths; kept opaque, all four bodies accumulate in place and the flush reads acc.
+        asm volatile("" : "+s"(any));
+        if (any) {
+            flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
+                          partials, row_flags, lane);
+            // zero the accumulators two at a time (v_mov_b64 on a register pair)
+#pragma unroll
+            for (int c = 0; c + 1 < 6 + CH; c += 2) {
+                f2 z = (f2)(0.0f);
+                asm volatile("" : "+v"(z));
+                acc[c] = z.x; acc[c + 1] = z.y;
+            }
+            if ((6 + CH) & 1) acc[5 + CH] = 0.0f;
+        }
     }
-    return j;
 }
 
 template <int CH, bool SPLIT>
@@ -533,38 +527,30 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     __shared__ float4 lds_all[kWaves][64 * 4];
     __shared__ float4 rect_all[kWaves][4];
-    __shared__ float vbuf_all[kWaves][kRows * kRowStride];
-    __shared__ float fbuf_all[kWaves][kRows * kRowStride];
-    __shared__ float4 vo_all[kWaves][4 * kVoStride];
-    __shared__ float4 meta_all[kWaves][kRows];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? 4 * num_tiles : num_tiles;
     const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
     if (unit >= units) return;
     const int tile = SPLIT ? unit >> 2 : unit;
-    const int only = SPLIT ? unit & 3 : -1;
+    const int only = SPLIT ? unit & 3 : -1;       // SPLIT: this wave owns block `only`, row slot*4 + only
     float4* rects = rect_all[wave];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     if (range.y <= range.x) return;
     float4* lds = lds_all[wave];
-    float* vbuf = vbuf_all[wave];
-    float* fbuf = fbuf_all[wave];
-    float4* vo_tab = vo_all[wave];
-    float4* meta = meta_all[wave];
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
     const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
     const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
     const int row_off = cam.tile_row0 * 16;
-    const Geom geom = lane_geom(lane);
 
     float bg[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) bg[c] = background[c];
 
     // per pixel: T = transmittance behind the Gaussian being replayed; R = T_final*(v_alpha - bg.v_out)
-    // - sum over the Gaussians already replayed of fac * (colour . v_out)   (see bwd_records)
+    // - sum over the Gaussians already replayed of fac * (colour . v_out)   (see the inner loop)
     float T[4], R[4], vo[4][CH];
     int fidx[4], bmax[4];
     int fmax = -1;
@@ -591,13 +577,17 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
             R[k] = T[k] * (va - dotbg);
         }
-        // the tile's v_out, for pass B (which reads pixels of other lanes)
-        vo_tab[k * kVoStride + lane] = make_float4(vo[k][0], vo[k][1], vo[k][2], CH == 4 ? vo[k][CH - 1] : 0.0f);
         bmax[k] = wave_max_int(fidx[k]);            // last list index any pixel of block k used
         fmax = max(fmax, bmax[k]);
     }
     const int last = min(range.y - 1, fmax);
-    int nrows = 0;                                  // lines waiting for pass B (carried across blocks and chunks)
+
+    // per-lane sums over its (up to) four pixels for the Gaussian being replayed, updated in place
+    // by the block bodies and zeroed after each row is written:
+    // {S v, S v dx, S v dy, S v dx^2, S v dx dy, S v dy^2, v_c0, v_c1, ...}
+    float acc[6 + CH];
+#pragma unroll
+    for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
 
     // same software pipeline as the forward kernel, walking the list back to front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -626,56 +616,36 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             blocks = update_rects(sel, X0, Y0, rects, lane);
             TS_WAVE_SYNC();
         }
-        const Staged s = stage_gaussian(have, q0, q1);
-        // one partial row per (tile, Gaussian, block): slot 4 * pair + k
-        const int pair_slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
+        Staged s = stage_splat(have, q0, q1, rects, blocks);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!(blocks & (1 << k))) continue;                       // wave-uniform
-            // nothing in block k got further than bmax[k] in forward
-            const bool hit = (i <= bmax[k]) && block_hit(s, rects[k]);
-            const mask64 mask = __ballot(hit);
-            if (mask == 0ull) continue;
-            const int cnt = __popcll(mask);
-            if (hit) {
-                const float bcx = X0 + (float)(8 * (k & 1)) + 3.5f, bcy = Y0 + (float)(8 * (k >> 1)) + 3.5f;
-                const float dxc = s.gx - bcx, dyc = s.gy - bcy;
-                const Coefs c = block_coefs(s, dxc, dyc);
-                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-                lds[4 * pos] = make_float4(c.c0, c.c1, c.c2, s.hA);
-                lds[4 * pos + 1] = make_float4(s.B, s.hC, q1.z, q1.w);
-                lds[4 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), s.lo);
-                lds[4 * pos + 3] = make_float4(dxc, dyc, __int_as_float(4 * pair_slot + k), __int_as_float(k));
-            }
-            TS_WAVE_SYNC();
-            const bool general = __ballot(hit && s.general) != 0ull;
-            int j = 0;
-            while (j < cnt) {
-                j = general ? bwd_records<CH, true>(lds, j, cnt, geom, T[k], R[k], vo[k], fidx[k], vbuf, fbuf,
-                                                    meta, nrows, lane)
-                            : bwd_records<CH, false>(lds, j, cnt, geom, T[k], R[k], vo[k], fidx[k], vbuf, fbuf,
-                                                     meta, nrows, lane);
-                if (nrows == kRows) {
-                    TS_WAVE_SYNC();
-                    pass_b<CH>(vbuf, fbuf, vo_tab, meta, kRows, partials, row_flags, lane);
-                    TS_WAVE_SYNC();
-                    nrows = 0;
-                }
-            }
-            TS_WAVE_SYNC();
+        for (int k = 0; k < 4; ++k)
+            if (i > bmax[k]) s.mask &= ~(1 << k);   // nothing in block k got this far in forward
+        const bool keep = s.mask != 0;
+        const unsigned long long mask = __ballot(keep);
+        const int cnt = __popcll(mask);
+        if (keep) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            int slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
+            if (SPLIT) slot = 4 * slot + only;       // one partial row per (tile, Gaussian, block)
+            lds[4 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
+            lds[4 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
+            lds[4 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(slot));
+            lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
-    }
-    if (nrows > 0) {
         TS_WAVE_SYNC();
-        pass_b<CH>(vbuf, fbuf, vo_tab, meta, nrows, partials, row_flags, lane);
+        if (__ballot(keep && (s.mask & 16)) != 0ull)
+            bwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+                                row_flags, lane);
+        else
+            bwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+                                 row_flags, lane);
+        TS_WAVE_SYNC();
     }
-    (void)num_isects;
 }
 
-// Row layout (raw sums over the pixels of one block of one tile, see pass_b):
+// Row layout (raw sums over the pixels of one tile, see raster_bwd_kernel):
 //   [ S v_sigma, S v_sigma dx, S v_sigma dy, S v_sigma dx^2, S v_sigma dx dy, S v_sigma dy^2, c0..c3, -, - ]
-// with d = xy - pixel.  Every (tile, Gaussian) owns four rows (slot 4 s + block) and one 32-bit flag
-// word; the conic / opacity factors are applied once per Gaussian here.
+// with d = xy - pixel.  The conic / opacity factors are applied once per Gaussian here.
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, int flags, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
@@ -693,13 +663,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
         a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
         a2.x += p2.x; a2.y += p2.y;
     };
-    const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
-    for (long long s = end - cnt; s < end; ++s) {
-        const unsigned int f = flags4[s];
-        if (f == 0u) continue;                    // never written this pass (stale contents)
+    if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
+        const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
+        for (long long s = end - cnt; s < end; ++s) {
+            const unsigned int f = flags4[s];
+            if (f == 0u) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (f & (0xffu << (8 * k))) add_row(4 * s + k);
+            for (int k = 0; k < 4; ++k)
+                if (f & (0xffu << (8 * k))) add_row(4 * s + k);
+        }
+    } else {
+        for (long long s = end - cnt; s < end; ++s) {
+            if (!row_flags[s]) continue;          // never written this pass (stale contents)
+            add_row(s);
+        }
     }
     float vx = 0.f, vy = 0.f, vop = 0.f;
     if (cnt > 0) {
@@ -763,7 +740,7 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
-    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * TS_ROWS_PER_PAIR, s);
+    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * (split ? 4 : 1), s);
     if (e != hipSuccess) return (int)e;
     const int units = split ? 4 * nt : nt;
     const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group

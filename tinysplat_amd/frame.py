@@ -21,7 +21,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import _lib
-from .ops import (ROWS_PER_PAIR, TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
+from .ops import (TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
                   _tile_bounds, deg_from_sh)
 
 # Tight tile lists (see ts_bin_count): (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255
@@ -133,7 +133,7 @@ class _RenderFrame(torch.autograd.Function):
             v_conic = flat[2 * n:5 * n].view(n, 3)
             v_cols = flat[5 * n:(5 + ch) * n].view(n, ch)
             v_opac = flat[(5 + ch) * n:]
-            rows = max(total, 1) * ROWS_PER_PAIR          # one partial row per (tile, Gaussian, 8x8 block)
+            rows = max(total, 1) * (4 if ctx.split else 1)
             partials = torch.empty((rows, 12), **f32)
             row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
             _call("ts_raster_bwd", lib.ts_raster_bwd, ch, ctx.split, total, cam, _ptr(tile_bins), _ptr(ids),

@@ -22,7 +22,6 @@ from . import _lib
 from ._lib import TsCamera
 
 BLOCK = 16            # rasterize.py:19-20
-ROWS_PER_PAIR = 4     # TS_ROWS_PER_PAIR of include/tinysplat_hip.h: partial gradient rows per (tile, Gaussian)
 CLIP_THRESH = 0.01    # gsplat's default near-plane threshold for project_gaussians
 
 
@@ -492,8 +491,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         v_conic = flat[2 * n:5 * n].view(n, 3)
         v_colors = flat[5 * n:(5 + ch) * n].view(n, ch)
         v_opacity = flat[(5 + ch) * n:]
-        partials = torch.empty((ROWS_PER_PAIR * max(total, 1), 12), **f32)      # one row per (tile, Gaussian, 8x8 block)
-        row_flags = torch.empty((ROWS_PER_PAIR * max(total, 1),), dtype=torch.uint8, device=dev)
+        partials = torch.empty((max(total, 1), 12), **f32)
+        row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
         lib = _lib.load()
         s = _stream(dev)
         with torch.cuda.device(dev):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 1
+#define TS_ABI_VERSION 2
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -74,7 +74,7 @@ int ts_project_fwd(int32_t n, const float* means3d, const float* scales, const f
                    int32_t* num_tiles_hit, float* cov3d, void* stream);
 
 /* Backward.  v_conic uses the true-partial convention for the off-diagonal entry.  v_cov3d may be
- * NULL (tinysplat discards cov3d, rasterize.py:32).  Gaussians with radii == 0 receive zeros. */
+ * NULL (tinysplat discards cov3d, rasterize.py:32); v_depth may be NULL (no gradient reaches depths).  Gaussians with radii == 0 receive zeros. */
 int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const float* quats,
                    const float* viewmat, const float* projmat, const ts_camera* cam_host,
                    int32_t flags, const int32_t* radii, const float* v_xy, const float* v_depth,
@@ -153,12 +153,13 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
 
 /* Packs the per-Gaussian operands of the compositing kernels into one 48-byte record:
  *   {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 | c2, c3, slot_base(int), bbox_w(int)}
- * channels = 3 (colors[n,3]; c3 = 0) or 4 (colors[n,4]).  slot_base/bbox_w locate the
+ * channels = 3 (colors[n,3]; c3 = 0) or 4 (colors[n,4]; or, with `depths` non-NULL, colors[n,3] and
+ * c3 = depths[i]: the RGB + depth frame of rasterize.py:42-51 in one pass).  slot_base/bbox_w locate the
  * (tile,Gaussian) row of the backward partial buffer: slot = slot_base + ty*bbox_w + tx. */
 int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys, const int32_t* radii,
                    const float* conics, const float* colors, const float* opacity,
-                   const int32_t* cum_tiles_hit, const ts_camera* cam_host, float* splats,
-                   void* stream);
+                   const int32_t* cum_tiles_hit, const ts_camera* cam_host, const float* depths,
+                   float* splats, void* stream);
 
 /* Front-to-back compositing.  out_img[rows,W,channels], final_Ts[rows,W], final_index[rows,W]
  * where rows = min(16*tile_rows, H - 16*tile_row0).  background: `channels` floats.  final_Ts and
@@ -196,7 +197,62 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
 int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
-                       float* v_colors, float* v_opacity, void* stream);
+                       float* v_colors, float* v_opacity, float* v_depth, void* stream);
+/* v_depth: NULL, or (channels == 4) the gradient of channel 3 as its own array [n]; v_colors is then
+ * [n,3] - the layout the RGB + depth frame hands to ts_sh_colors_bwd / ts_project_bwd. */
+
+/* ============== whole-frame executor (the adapter's recipe, rasterize.py:26-62, in five calls) ======
+ * The reference's GaussianRasterizer.__call__ enqueues ~30 small operations per frame from Python; on
+ * scenes of 100 k Gaussians and on multi-GPU tile stripes that host time exceeds the GPU time.  These
+ * entries enqueue the same kernels, in the same order, as the per-stage entries above - nothing else -
+ * from native code: one ts_frame describes a frame (all buffers caller-allocated; device pointers
+ * unless noted), and a frame costs five calls instead of thirty:
+ *   ts_frame_fwd_project    project_fwd, scan_tiles, then an async copy of the intersection count
+ *                           cum_tiles_hit[n-1] into total_host (pinned host memory) - the caller
+ *                           records an event behind this call and waits for it only before step 3
+ *   ts_frame_fwd_prepare    sh_colors_fwd, pack_splats, bin_count, tile_offsets   (do not need the count)
+ *   ts_frame_fwd_composite  bin_scatter, sort_tiles, raster_fwd   (needs bucket_ids / gaussian_ids_sorted
+ *                           sized by the count; num_intersects must be set)
+ *   ts_frame_bwd_composite  raster_bwd, reduce_partials -> the flat 2-D gradients v_xy | v_conic |
+ *                           v_colors | [v_depth] | v_opacity (multi-GPU: all-reduce them after this call)
+ *   ts_frame_bwd_params     sh_colors_bwd, project_bwd -> gradients of the six parameter tensors
+ * flags: TS_FRAME_TIGHT (tight tile lists: drop (Gaussian, tile) pairs that cannot reach alpha >= 1/255),
+ * TS_FRAME_SPLIT (TS_RASTER_SPLIT_BLOCKS for the compositing launches).  channels = 3 (RGB) or 4 (RGB +
+ * depth composited in one pass).  Forward-only rendering: final_Ts = final_index = clamp_mask = sh_mask = NULL. */
+#define TS_FRAME_TIGHT 1
+#define TS_FRAME_SPLIT 2
+typedef struct ts_frame {
+    int32_t n, num_bases, sh_degree, channels, flags, reserved;
+    ts_camera cam;
+    /* parameters and camera (rasterize.py:64-86): log-scales, raw quaternions, opacity logits */
+    const float *means, *scales, *quats, *opacities, *colors_dc, *colors_rest;
+    const float *view34, *projview, *origin, *background;     /* background: `channels` floats */
+    /* per-Gaussian outputs / intermediates */
+    float *xys, *depths, *conics, *colors, *splats;
+    int32_t *radii, *num_tiles_hit, *cum_tiles_hit;
+    uint8_t* sh_mask;
+    int32_t *scan_ws, *bin_ws, *tile_bins;
+    int32_t* total_host;                      /* pinned HOST int32 */
+    /* per-intersection buffers and the count they are sized by */
+    int64_t num_intersects;
+    int32_t *bucket_ids, *gaussian_ids_sorted;
+    /* image outputs */
+    float *out_img, *final_Ts;
+    int32_t* final_index;
+    uint8_t* clamp_mask;
+    /* backward */
+    const float* v_out_img;
+    float* partials;
+    uint8_t* row_flags;
+    float *v_xy, *v_conic, *v_colors, *v_depth, *v_opacity;
+    float *v_means, *v_scales, *v_quats, *v_colors_dc, *v_colors_rest;
+} ts_frame;
+int32_t ts_frame_struct_bytes(void);       /* sizeof(ts_frame): bindings check their mirror against it */
+int ts_frame_fwd_project(const ts_frame* f, void* stream);
+int ts_frame_fwd_prepare(const ts_frame* f, void* stream);
+int ts_frame_fwd_composite(const ts_frame* f, void* stream);
+int ts_frame_bwd_composite(const ts_frame* f, void* stream);
+int ts_frame_bwd_params(const ts_frame* f, void* stream);
 
 /* ============ training-step ops around the path (scripts/train.py:58-63,97) ===== */
 

@@ -36,10 +36,12 @@ def test_binding_covers_the_header_and_version_matches():
     from tinysplat_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.ts_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 2
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 48
+    assert lib.ts_frame_struct_bytes() == ctypes.sizeof(_lib.TsFrame)
+    assert lib.ts_frame_fwd_project(None, None) == -1 and lib.ts_frame_bwd_params(None, None) == -1
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -51,7 +53,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_sh_fwd(4, 0, 5, None, None, None, None) == -2      # 5 is not a base count
     assert lib.ts_project_fwd(-3, *([None] * 5), None, 0, *([None] * 7)) == -1
     cam = _lib.TsCamera(1, 1, 0, 0, 16, 16, 1, 1, 0, 1, 1.0, 0.01)
-    assert lib.ts_pack_splats(4, 5, 0, *([None] * 6), cam, None, None) == -1
+    assert lib.ts_pack_splats(4, 5, 0, *([None] * 6), cam, None, None, None) == -1
     assert lib.ts_raster_fwd(2, 0, cam, *([None] * 9)) == -1
 
 

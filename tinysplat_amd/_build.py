@@ -21,6 +21,7 @@ SOURCES = [
     ("train.hip", []),
     ("densify.hip", ["-ffp-contract=off"]),
     ("formats.hip", []),
+    ("frame.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

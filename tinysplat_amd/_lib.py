@@ -11,7 +11,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class TsCamera(ctypes.Structure):
@@ -35,6 +35,27 @@ class TsDensifyPolicy(ctypes.Structure):
                 ("scale_thresh", c_float)]
 
 
+class TsFrame(ctypes.Structure):
+    """struct ts_frame of include/tinysplat_hip.h: one frame of the adapter recipe for the native
+    executor (ts_frame_*).  Pointers travel as integer addresses; unset ones stay NULL."""
+    _fields_ = ([("n", c_int32), ("num_bases", c_int32), ("sh_degree", c_int32), ("channels", c_int32),
+                 ("flags", c_int32), ("reserved", c_int32), ("cam", TsCamera)]
+                + [(name, c_void_p) for name in (
+                    "means", "scales", "quats", "opacities", "colors_dc", "colors_rest",
+                    "view34", "projview", "origin", "background",
+                    "xys", "depths", "conics", "colors", "splats",
+                    "radii", "num_tiles_hit", "cum_tiles_hit", "sh_mask",
+                    "scan_ws", "bin_ws", "tile_bins", "total_host")]
+                + [("num_intersects", c_int64)]
+                + [(name, c_void_p) for name in (
+                    "bucket_ids", "gaussian_ids_sorted", "out_img", "final_Ts", "final_index", "clamp_mask",
+                    "v_out_img", "partials", "row_flags",
+                    "v_xy", "v_conic", "v_colors", "v_depth", "v_opacity",
+                    "v_means", "v_scales", "v_quats", "v_colors_dc", "v_colors_rest")])
+
+
+_FRAME = POINTER(TsFrame)
+
 # name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
 SIGNATURES = {
     "ts_abi_version": (c_int32, []),
@@ -51,7 +72,7 @@ SIGNATURES = {
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
-    "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P]),
+    "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_bench_stream_read": (c_int32, [_P, c_int64, _P, _P]),
@@ -68,7 +89,13 @@ SIGNATURES = {
     "ts_ply_row_floats": (c_int32, [c_int32]),
     "ts_ply_pack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_ply_unpack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_frame_struct_bytes": (c_int32, []),
+    "ts_frame_fwd_project": (c_int32, [_FRAME, _P]),
+    "ts_frame_fwd_prepare": (c_int32, [_FRAME, _P]),
+    "ts_frame_fwd_composite": (c_int32, [_FRAME, _P]),
+    "ts_frame_bwd_composite": (c_int32, [_FRAME, _P]),
+    "ts_frame_bwd_params": (c_int32, [_FRAME, _P]),
 }
 
 _lib = None
@@ -103,6 +130,8 @@ def load() -> ctypes.CDLL:
     v = lib.ts_abi_version()
     if v != ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    if lib.ts_frame_struct_bytes() != ctypes.sizeof(TsFrame):
+        raise HipLibraryError("struct ts_frame: the ctypes mirror does not match the library's layout")
     _lib = lib
     return lib
 

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
     int n, int channels, int flags, const float* __restrict__ xys, const int* __restrict__ radii,
     const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacity, const int* __restrict__ cum_tiles_hit, const ts_camera cam,
-    float4* __restrict__ splats) {
+    const float* __restrict__ depths, float4* __restrict__ splats) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const int r = radii[i];
@@ -718,9 +718,11 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
         if (flags & TS_RASTER_LOGIT_OPACITY) op = 1.0f / (1.0f + expf(-op));   // sigmoid, rasterize.py:86
         q0 = make_float4(xy.x, xy.y, op, conics[3 * i]);
         float c0, c1, c2, c3 = 0.0f;
-        if (channels == 4) {
+        if (channels == 4 && depths == nullptr) {
             const float4 c = reinterpret_cast<const float4*>(colors)[i];
             c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+        } else if (channels == 4) {      // RGB + depth in one pass: colors is [n,3], channel 3 = depths (rasterize.py:48-50)
+            c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2]; c3 = depths[i];
         } else {
             c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2];
         }
@@ -854,7 +856,7 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
 
 int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys, const int32_t* radii,
                    const float* conics, const float* colors, const float* opacity,
-                   const int32_t* cum_tiles_hit, const ts_camera* cam, float* splats,
+                   const int32_t* cum_tiles_hit, const ts_camera* cam, const float* depths, float* splats,
                    void* stream) {
     if (n < 0 || !cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
     if (n == 0) return 0;
@@ -862,7 +864,7 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
         return TS_E_BADARG;
     hipLaunchKernelGGL(pack_splats_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        (hipStream_t)stream, n, channels, (int)flags, xys, radii, conics, colors, opacity,
-                       cum_tiles_hit, *cam, reinterpret_cast<float4*>(splats));
+                       cum_tiles_hit, *cam, depths, reinterpret_cast<float4*>(splats));
     return launch_status();
 }
 

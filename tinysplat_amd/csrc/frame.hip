@@ -1,0 +1,96 @@
+// frame.hip - whole-frame executor: the render adapter's recipe
+// (/root/reference/tinysplat/splatting/rasterize.py:26-62: project -> SH colours -> rasterize RGB
+// [+ depth], and its backward) enqueued from native code.
+//
+// Nothing is computed here: every function below calls the per-stage C-ABI entries of this library
+// (project.hip, binning.hip, raster.hip) in the order frame.py used to call them one by one through
+// ctypes.  What it buys is host time: a frame is ~30 kernel launches, and issuing them from Python
+// costs ~0.45 ms per frame - more than the GPU needs for a 100 k-Gaussian scene or for one tile
+// stripe of a multi-GPU frame.  From here a launch costs ~2 us.  The one host round trip of the path
+// (the intersection count that sizes the per-intersection buffers) stays with the caller: it is
+// copied into pinned memory by ts_frame_fwd_project and awaited between _prepare and _composite.
+#include <hip/hip_runtime.h>
+
+#include "../../include/tinysplat_hip.h"
+
+#define TS_TRY(call)                 \
+    do {                             \
+        const int e_ = (call);       \
+        if (e_ != 0) return e_;      \
+    } while (0)
+
+namespace {
+inline bool bad(const ts_frame* f) {
+    return !f || f->n < 0 || (f->channels != 3 && f->channels != 4) || f->num_bases < 1;
+}
+inline int num_tiles(const ts_frame* f) { return f->cam.tile_rows * f->cam.tile_bounds_x; }
+inline int raster_flags(const ts_frame* f) {
+    return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0);
+}
+}  // namespace
+
+extern "C" {
+
+int32_t ts_frame_struct_bytes(void) { return (int32_t)sizeof(ts_frame); }
+
+int ts_frame_fwd_project(const ts_frame* f, void* stream) {
+    if (bad(f)) return TS_E_BADARG;
+    // flags 3: log-scales and raw quaternions go in as they are (rasterize.py:72-73 folded into the kernel);
+    // cov3d is not produced (the adapter discards it, rasterize.py:32)
+    TS_TRY(ts_project_fwd(f->n, f->means, f->scales, f->quats, f->view34, f->projview, &f->cam, 3, f->xys,
+                          f->depths, f->radii, f->conics, f->num_tiles_hit, nullptr, stream));
+    TS_TRY(ts_scan_tiles(f->n, f->num_tiles_hit, f->cum_tiles_hit, f->scan_ws, stream));
+    if (f->n > 0 && f->total_host) {
+        const hipError_t e = hipMemcpyAsync(f->total_host, f->cum_tiles_hit + (f->n - 1), sizeof(int32_t),
+                                            hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
+    if (bad(f)) return TS_E_BADARG;
+    TS_TRY(ts_sh_colors_fwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->colors_dc,
+                            f->num_bases > 1 ? f->colors_rest : nullptr, f->colors, f->sh_mask, stream));
+    // channel 3 of an RGB + depth frame is the depth itself (rasterize.py:48-50), taken from `depths`
+    TS_TRY(ts_pack_splats(f->n, f->channels, TS_RASTER_LOGIT_OPACITY, f->xys, f->radii, f->conics, f->colors,
+                          f->opacities, f->cum_tiles_hit, &f->cam, f->channels == 4 ? f->depths : nullptr,
+                          f->splats, stream));
+    const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
+    TS_TRY(ts_bin_count(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, stream));
+    TS_TRY(ts_tile_offsets(f->n, num_tiles(f), f->bin_ws, f->tile_bins, stream));
+    return 0;
+}
+
+int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
+    if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
+    if (f->num_intersects > 0) {
+        const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
+        TS_TRY(ts_bin_scatter(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, f->bucket_ids, stream));
+        TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
+                             f->bin_ws, stream));
+    }
+    return ts_raster_fwd(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
+                         f->background, f->out_img, f->final_Ts, f->final_index, f->clamp_mask, stream);
+}
+
+int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
+    if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
+    TS_TRY(ts_raster_bwd(f->channels, (f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0, f->num_intersects,
+                         &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background, f->final_Ts,
+                         f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags, stream));
+    return ts_reduce_partials(f->n, f->channels,
+                              TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0),
+                              f->num_tiles_hit, f->cum_tiles_hit, f->partials, f->row_flags, f->splats, f->v_xy,
+                              f->v_conic, f->v_colors, f->v_opacity, f->channels == 4 ? f->v_depth : nullptr, stream);
+}
+
+int ts_frame_bwd_params(const ts_frame* f, void* stream) {
+    if (bad(f)) return TS_E_BADARG;
+    TS_TRY(ts_sh_colors_bwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->sh_mask, f->v_colors,
+                            f->v_colors_dc, f->num_bases > 1 ? f->v_colors_rest : nullptr, stream));
+    return ts_project_bwd(f->n, f->means, f->scales, f->quats, f->view34, f->projview, &f->cam, 3, f->radii,
+                          f->v_xy, f->v_depth, f->v_conic, nullptr, f->v_means, f->v_scales, f->v_quats, stream);
+}
+
+}  // extern "C"

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
         if (v_cov3d) {
             for (int k = 0; k < 6; ++k) vcov[k] = v_cov3d[6 * (size_t)i + k];
         }
-        ts::project_one_vjp(C, m, s, q, vx, v_depth[i], vc, v_cov3d ? vcov : nullptr, g);
+        ts::project_one_vjp(C, m, s, q, vx, v_depth ? v_depth[i] : 0.0f, vc, v_cov3d ? vcov : nullptr, g);
         if (flags & TS_PROJECT_LOG_SCALES) {            // d exp(x) = exp(x) dx
             g.v_scale[0] *= s[0]; g.v_scale[1] *= s[1]; g.v_scale[2] *= s[2];
         }
@@ -390,7 +390,7 @@ int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const f
                    float* v_quats, void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
-    if (!means3d || !scales || !quats || !viewmat || !projmat || !radii || !v_xy || !v_depth ||
+    if (!means3d || !scales || !quats || !viewmat || !projmat || !radii || !v_xy ||
         !v_conic || !v_means3d || !v_scales || !v_quats)
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;

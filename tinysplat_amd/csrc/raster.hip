@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, int flags, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
     const float4* __restrict__ partials, const unsigned char* __restrict__ row_flags,
     const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_opacity) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacity, float* __restrict__ v_depth) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
@@ -690,8 +690,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     reinterpret_cast<float2*>(v_xy)[i] = make_float2(vx, vy);
     v_opacity[i] = vop;
     v_conic[3 * i] = 0.5f * a0.w; v_conic[3 * i + 1] = a1.x; v_conic[3 * i + 2] = 0.5f * a1.y;
-    if (CH == 4) {
+    if (CH == 4 && v_depth == nullptr) {
         reinterpret_cast<float4*>(v_colors)[i] = make_float4(a1.z, a1.w, a2.x, a2.y);
+    } else if (CH == 4) {                 // RGB + depth pass: v_colors is [n,3], channel 3 goes to v_depth[n]
+        v_colors[3 * i] = a1.z; v_colors[3 * i + 1] = a1.w; v_colors[3 * i + 2] = a2.x;
+        v_depth[i] = a2.y;
     } else {
         v_colors[3 * i] = a1.z; v_colors[3 * i + 1] = a1.w; v_colors[3 * i + 2] = a2.x;
     }
@@ -758,7 +761,7 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
 int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
-                       float* v_colors, float* v_opacity, void* stream) {
+                       float* v_colors, float* v_opacity, float* v_depth, void* stream) {
     if (n < 0 || (channels != 3 && channels != 4)) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!num_tiles_hit || !cum_tiles_hit || !row_flags || !splats || !v_xy || !v_conic || !v_colors || !v_opacity)
@@ -770,11 +773,11 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags,
                            num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth);
     else
         hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags,
                            num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth);
     return launch_status();
 }
 

@@ -1,18 +1,24 @@
 """Whole-frame autograd function: the render adapter's recipe (rasterize.py:26-62) as ONE
-``torch.autograd.Function`` over the C ABI.
+``torch.autograd.Function`` over the C ABI's frame executor.
 
 The three drop-in ops of ``ops.py`` each cost an autograd node, a dozen Python-level tensor
-allocations and a binning-cache lookup per frame; on small scenes and on multi-GPU stripes that
-host time (~0.5 ms) exceeds the GPU time.  This function enqueues the same kernels in the same order
-(project -> scan -> colour stage -> pack -> binning -> composite; backward: composite -> reduce ->
-[all-reduce across stripes] -> colour stage -> project) with the adapter's exp / normalise / sigmoid
-folded in (``TS_PROJECT_*`` / ``TS_RASTER_LOGIT_OPACITY`` flags), one 4-channel compositing pass for
-RGB + depth, tight tile lists, the adapter's clamp(max=1) inside the compositing kernels, and a single
-autograd node.  Results are bitwise those of the op-by-op path
+allocations and a binning-cache lookup per frame, and every kernel launch issued from Python costs
+~8 us; on small scenes and on multi-GPU stripes that host time (~0.5 ms) exceeds the GPU time.  This
+module describes a frame once in a ``ts_frame`` struct (a handful of workspace allocations) and lets
+``csrc/frame.hip`` enqueue the kernels (project -> scan -> colour stage -> pack -> binning ->
+composite; backward: composite -> reduce -> [all-reduce across stripes] -> colour stage -> project):
+three native calls forward, two backward, with the adapter's exp / normalise / sigmoid folded in
+(``TS_PROJECT_*`` / ``TS_RASTER_LOGIT_OPACITY``), one 4-channel compositing pass for RGB + depth,
+tight tile lists, the adapter's clamp(max=1) inside the compositing kernels, and a single autograd
+node.  Results are bitwise those of the op-by-op path
 (tests/test_gpu_parity.py: test_one_node_frame_is_bitwise_the_fused_op_recipe).
+
+While ``ops.kernel_timer`` is recording (bench.py's per-entry table) the same kernels are issued one
+C-ABI entry at a time from Python on the same buffers, so that each entry can be bracketed by events.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -21,8 +27,9 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import _lib
-from .ops import (TileBinning, _IntersectionCount, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows,
-                  _tile_bounds, deg_from_sh)
+from ._lib import TsFrame
+from .ops import (TileBinning, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows, _tile_bounds,
+                  deg_from_sh, kernel_timer)
 
 # Tight tile lists (see ts_bin_count): (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255
 # anywhere in the tile are dropped at binning time.  Results are bit-identical either way
@@ -37,136 +44,288 @@ SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
 
+TRACE = None            # developer hook (tools/host_breakdown.py): a list receiving (label, perf_counter) marks
+
+
+def _mark(label):
+    if TRACE is not None:
+        import time
+        TRACE.append((label, time.perf_counter()))
+
+
+_pinned_total = {}      # device index -> (pinned int32[1], event): the path's one host read
+_bg_cache = {}          # (storage address, version, channels) -> contiguous background with the depth channel
+
+
+def _total_slot(dev: torch.device):
+    slot = _pinned_total.get(dev.index)
+    if slot is None:
+        slot = (torch.zeros((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        _pinned_total[dev.index] = slot
+    return slot
+
+
+class _Frame:
+    """Buffers of one frame plus the ``ts_frame`` struct that points at them."""
+    __slots__ = ("fr", "cam", "n", "nb", "ch", "w", "h", "num_tiles", "total", "split", "keep",
+                 "wf", "wi", "bin_ws", "tile_bins", "sh_mask", "ids", "bucket_ids", "out_img", "final_Ts",
+                 "final_idx", "clamp_mask", "xys", "radii", "nth", "cum", "inputs", "bg")
+
+
+def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background,
+             fx, fy, width, height, sh_degree, with_depth, tile_rows, keep: bool) -> _Frame:
+    """Enqueues the forward frame; ``keep`` = also produce what the backward pass needs."""
+    _mark("fwd:enter")
+    dev = _need_hip(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background)
+    n = means.shape[0]
+    nb = colors_rest.shape[1] + 1
+    if sh_degree < 0 or sh_degree > deg_from_sh(nb):
+        raise ValueError("sh_degree exceeds the stored coefficients")
+    means, scales, quats = _f32c(means), _f32c(scales), _f32c(quats)
+    opacities, colors_dc, colors_rest = _f32c(opacities), _f32c(colors_dc), _f32c(colors_rest)
+    view34, projview, origin = _f32c(view34), _f32c(projview), _f32c(origin)
+    w, h = int(width), int(height)
+    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
+    ch = 4 if with_depth else 3
+    if with_depth:          # channel 3 is composited over background[0], as the reference's depth pass (:86)
+        key = (background.data_ptr(), background._version, dev.index)
+        hit = _bg_cache.get(key)
+        if hit is None:
+            if len(_bg_cache) > 16:
+                _bg_cache.clear()
+            # the source tensor is kept alive with the entry, so that its address cannot be reused
+            hit = _bg_cache[key] = (_f32c(torch.cat([background, background[:1]])), background)
+        bg = hit[0]
+    else:
+        bg = _f32c(background)
+    lib = _lib.load()
+    s = _stream(dev)
+    F = _Frame()
+    F.cam, F.n, F.nb, F.ch, F.w, F.h, F.keep = cam, n, nb, ch, w, h, keep
+    F.inputs = (means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin)
+    F.bg = bg
+    num_tiles = cam.tile_rows * cam.tile_bounds_x
+    F.num_tiles = num_tiles
+    F.split = 0 < num_tiles <= SPLIT_BLOCKS_BELOW
+    rows = _stripe_rows(cam)
+    m = max(n, 1)
+    _mark("fwd:inputs checked")
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev)
+    try:
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        # ONE allocation for every fixed-size intermediate (a torch.empty costs ~3 us of host time, and a
+        # frame used to make a dozen); 256-byte aligned sections:
+        #   splats[12n] f32 | xys[2n] | conics[3n] | colors[3n] | depths[n] | radii[n] i32 | nth[n] | cum[n] |
+        #   scan_ws | bin_ws | tile_bins[2T] | sh_mask[n] u8 | final_Ts[P] f32 | final_index[P] i32 | clamp_mask[P] u8
+        nscan = int(lib.ts_scan_ws_ints(n))
+        nbin = int(lib.ts_bin_ws_ints(n, num_tiles))
+        px = rows * w
+        sizes = [48 * m, 8 * m, 12 * m, 12 * m, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
+                 8 * max(num_tiles, 1)] + ([m, 4 * px, 4 * px, px] if keep else [])
+        offs, off = [], 0
+        for sz in sizes:
+            offs.append(off)
+            off += (sz + 255) & ~255
+        F.wf = torch.empty((off,), dtype=torch.uint8, device=dev)
+        base = F.wf.data_ptr()
+        ptr = [base + o for o in offs]
+        F.out_img = torch.empty((rows, w, ch), **f32)
+
+        def view(k, dtype, count, shape):
+            return F.wf[offs[k]:offs[k] + count * dtype.itemsize].view(dtype).view(shape)
+        F.xys = view(1, torch.float32, 2 * n, (n, 2))
+        F.radii = view(5, torch.int32, n, (n,))
+        F.nth = view(6, torch.int32, n, (n,))
+        F.cum = view(7, torch.int32, n, (n,))
+        F.tile_bins = view(10, torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
+        F.wi = F.bin_ws = F.sh_mask = F.final_Ts = F.final_idx = F.clamp_mask = None    # live inside F.wf
+        host, event = _total_slot(dev)
+        fr = TsFrame()
+        fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
+        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0)
+        fr.cam = cam
+        fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
+        fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
+        fr.view34, fr.projview, fr.origin, fr.background = view34.data_ptr(), projview.data_ptr(), origin.data_ptr(), bg.data_ptr()
+        fr.splats, fr.xys, fr.conics, fr.colors, fr.depths = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4]
+        fr.radii, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws = ptr[5], ptr[6], ptr[7], ptr[8]
+        fr.bin_ws, fr.tile_bins = ptr[9], ptr[10]
+        fr.total_host = host.data_ptr()
+        fr.out_img = F.out_img.data_ptr()
+        if keep:
+            fr.sh_mask, fr.final_Ts, fr.final_index, fr.clamp_mask = ptr[11], ptr[12], ptr[13], ptr[14]
+        F.fr = fr
+        _mark("fwd:allocated + struct")
+        timed = kernel_timer.enabled
+        if timed:
+            _steps_project(lib, fr, s)
+            if n > 0:
+                host.copy_(F.cum[-1:], non_blocking=True)
+        else:
+            _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
+        _mark("fwd:call project")
+        event.record(torch.cuda.current_stream(dev))
+        # the kernels that do not need the count run while it travels to the host
+        if timed:
+            _steps_prepare(lib, fr, s)
+        else:
+            _lib.check(lib.ts_frame_fwd_prepare(ctypes.byref(fr), s), "ts_frame_fwd_prepare")
+        _mark("fwd:call prepare")
+        total = 0
+        if n > 0:
+            event.synchronize()                                   # the one host sync of the path
+            total = int(host[0])
+            if total < 0:
+                raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
+                                    "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
+        _mark("fwd:waited for count")
+        F.total = total
+        cap = (max(total, 1) + 63) & ~63
+        F.bucket_ids = torch.empty((2 * cap,), **i32)             # bucket_ids | gaussian_ids_sorted
+        F.ids = F.bucket_ids[cap:cap + total]
+        fr.num_intersects = total
+        fr.bucket_ids, fr.gaussian_ids_sorted = F.bucket_ids.data_ptr(), F.bucket_ids.data_ptr() + 4 * cap
+        if timed:
+            _steps_composite(lib, fr, s)
+        else:
+            _lib.check(lib.ts_frame_fwd_composite(ctypes.byref(fr), s), "ts_frame_fwd_composite")
+        _mark("fwd:call composite")
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
+    b = TileBinning()
+    b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
+    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = F.tile_bins[:num_tiles], F.ids, F.cum, F.nth
+    last_binning[dev.index] = b
+    _mark("fwd:exit")
+    return F
+
+
+# ---- the executor's calls, one C-ABI entry at a time (per-entry timing only; mirrors csrc/frame.hip) ----
+def _steps_project(lib, fr, s):
+    _call("ts_project_fwd", lib.ts_project_fwd, fr.n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview,
+          fr.cam, 3, fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, None, s)
+    _call("ts_scan_tiles", lib.ts_scan_tiles, fr.n, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws, s)
+
+
+def _steps_prepare(lib, fr, s):
+    _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
+          fr.colors_dc, fr.colors_rest if fr.num_bases > 1 else None, fr.colors, fr.sh_mask, s)
+    _call("ts_pack_splats", lib.ts_pack_splats, fr.n, fr.channels, 1, fr.xys, fr.radii, fr.conics, fr.colors,
+          fr.opacities, fr.cum_tiles_hit, fr.cam, fr.depths if fr.channels == 4 else None, fr.splats, s)
+    tight = fr.splats if fr.flags & 1 else None
+    _call("ts_bin_count", lib.ts_bin_count, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws, s)
+    _call("ts_tile_offsets", lib.ts_tile_offsets, fr.n, fr.cam.tile_rows * fr.cam.tile_bounds_x, fr.bin_ws,
+          fr.tile_bins, s)
+
+
+def _steps_composite(lib, fr, s):
+    tight = fr.splats if fr.flags & 1 else None
+    nt = fr.cam.tile_rows * fr.cam.tile_bounds_x
+    if fr.num_intersects > 0:
+        _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
+              fr.bucket_ids, s)
+        _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
+              fr.gaussian_ids_sorted, fr.bin_ws, s)
+    _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0), fr.cam, fr.tile_bins,
+          fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.final_Ts, fr.final_index,
+          fr.clamp_mask, s)
+
+
+def _steps_bwd_composite(lib, fr, s):
+    split = 4 if fr.flags & 2 else 0
+    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split, fr.num_intersects, fr.cam, fr.tile_bins,
+          fr.gaussian_ids_sorted, fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None,
+          fr.clamp_mask, fr.partials, fr.row_flags, s)
+    _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split, fr.num_tiles_hit,
+          fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, fr.v_xy, fr.v_conic, fr.v_colors,
+          fr.v_opacity, fr.v_depth if fr.channels == 4 else None, s)
+
+
+def _steps_bwd_params(lib, fr, s):
+    _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
+          fr.sh_mask, fr.v_colors, fr.v_colors_dc, fr.v_colors_rest if fr.num_bases > 1 else None, s)
+    _call("ts_project_bwd", lib.ts_project_bwd, fr.n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview,
+          fr.cam, 3, fr.radii, fr.v_xy, fr.v_depth, fr.v_conic, None, fr.v_means, fr.v_scales, fr.v_quats, s)
+
 
 class _RenderFrame(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacities, colors_dc, colors_rest, view34, projview,
                 origin, background, fx, fy, width, height, sh_degree, with_depth, tile_rows, group):
-        dev = _need_hip(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview,
-                        origin, background)
-        n = means.shape[0]
-        nb = colors_rest.shape[1] + 1
-        if sh_degree < 0 or sh_degree > deg_from_sh(nb):
-            raise ValueError("sh_degree exceeds the stored coefficients")
-        means, scales, quats = _f32c(means), _f32c(scales), _f32c(quats)
-        opacities, colors_dc, colors_rest = _f32c(opacities), _f32c(colors_dc), _f32c(colors_rest)
-        view34, projview, origin = _f32c(view34), _f32c(projview), _f32c(origin)
-        w, h = int(width), int(height)
-        tb = _tile_bounds(h, w)
-        cam = _camera(fx, fy, w / 2, h / 2, h, w, tb, 1.0, tile_rows=tile_rows)
-        ch = 4 if with_depth else 3
-        bg = _f32c(torch.cat([background, background[:1]]) if with_depth else background)
-        f32 = dict(dtype=torch.float32, device=dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        lib = _lib.load()
-        s = _stream(dev)
-        with torch.cuda.device(dev):
-            xys = torch.empty((n, 2), **f32); depths = torch.empty((n,), **f32)
-            radii = torch.empty((n,), **i32); conics = torch.empty((n, 3), **f32)
-            nth = torch.empty((n,), **i32)
-            _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means), _ptr(scales), _ptr(quats),
-                  _ptr(view34), _ptr(projview), cam, 3, _ptr(xys), _ptr(depths), _ptr(radii),
-                  _ptr(conics), _ptr(nth), None, s)          # cov3d: the adapter discards it (rasterize.py:32)
-            # binning, first half; the intersection count travels to the host while the kernels
-            # that do not need it (colour stage, per-tile counts, offsets) run
-            num_tiles = cam.tile_rows * cam.tile_bounds_x
-            cum = torch.empty((n,), **i32)
-            ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
-            _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth), _ptr(cum), _ptr(ws), s)
-            pending = _IntersectionCount(cum, dev)
-            colors = torch.empty((n, 3), **f32)
-            mask = torch.empty((n,), dtype=torch.uint8, device=dev)
-            _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, n, int(sh_degree), nb, _ptr(means),
-                  _ptr(origin), _ptr(colors_dc), _ptr(colors_rest) if nb > 1 else None, _ptr(colors),
-                  _ptr(mask), s)
-            cols = torch.cat([colors, depths[:, None]], dim=1) if with_depth else colors
-            bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
-            tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-            splats = torch.empty((max(n, 1), 12), **f32)
-            _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1, _ptr(xys), _ptr(radii), _ptr(conics),
-                  _ptr(cols), _ptr(opacities), _ptr(cum), cam, _ptr(splats), s)
-            tight = _ptr(splats) if TIGHT_BINNING else None      # drop pairs that cannot contribute
-            _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), tight, cam, _ptr(bin_ws), s)
-            _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
-            total = pending.wait()                                # the one host sync of the path
-            bucket_ids = torch.empty((max(total, 1),), **i32)
-            ids = torch.empty((max(total, 1),), **i32)
-            if total > 0:
-                _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), tight, cam,
-                      _ptr(bin_ws), _ptr(bucket_ids), s)
-                _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
-                      _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
-            # compositing
-            rows = _stripe_rows(cam)
-            out_img = torch.empty((rows, w, ch), **f32)
-            final_Ts = torch.empty((rows, w), **f32)
-            final_idx = torch.empty((rows, w), **i32)
-            clamp_mask = torch.empty((rows, w), dtype=torch.uint8, device=dev)
-            split = 4 if 0 < num_tiles <= SPLIT_BLOCKS_BELOW else 0      # TS_RASTER_SPLIT_BLOCKS
-            _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2 | split, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
-                  _ptr(bg), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx), _ptr(clamp_mask), s)
-        b = TileBinning()
-        b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
-        b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
-        last_binning[dev.index] = b
-        ctx.cam, ctx.ch, ctx.n, ctx.nb, ctx.total, ctx.split = cam, ch, n, nb, total, split
-        ctx.sh_degree, ctx.group = int(sh_degree), group
+        F = _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin,
+                     background, fx, fy, width, height, sh_degree, with_depth, tile_rows, keep=True)
+        ctx.frame, ctx.group = F, group
         ctx.opacity_shape = opacities.shape
+        ctx.rest_shape = colors_rest.shape
+        xys, radii = F.xys, F.radii
         ctx.xys_out = xys
-        ctx.save_for_backward(means, scales, quats, view34, projview, origin, radii, nth, cum,
-                              tile_bins, ids, splats, bg, final_Ts, final_idx, mask, clamp_mask)
         ctx.mark_non_differentiable(xys, radii)
-        return out_img, xys, radii
+        # the image must not stay reachable from ctx: it is the differentiable output, its grad_fn owns
+        # ctx, and the cycle would keep every buffer of the frame alive until the garbage collector runs
+        out, F.out_img = F.out_img, None
+        return out, xys, radii
 
     @staticmethod
     def backward(ctx, v_img, _v_xys, _v_radii):
-        (means, scales, quats, view34, projview, origin, radii, nth, cum, tile_bins, ids, splats, bg,
-         final_Ts, final_idx, mask, clamp_mask) = ctx.saved_tensors
-        dev, n, ch, cam, total = means.device, ctx.n, ctx.ch, ctx.cam, ctx.total
+        _mark("bwd:enter")
+        F = ctx.frame
+        if F is None:
+            raise RuntimeError("the frame's buffers were released by an earlier backward pass")
+        fr, n, ch = F.fr, F.n, F.ch
+        dev = F.wf.device
         f32 = dict(dtype=torch.float32, device=dev)
         lib = _lib.load()
         s = _stream(dev)
         v_img = _f32c(v_img)
+        _mark("bwd:v_img contiguous")
         with torch.cuda.device(dev):
-            flat = torch.empty((n * (6 + ch),), **f32)        # v_xy | v_conic | v_colors | v_opacity
-            v_xy = flat[:2 * n].view(n, 2)
-            v_conic = flat[2 * n:5 * n].view(n, 3)
-            v_cols = flat[5 * n:(5 + ch) * n].view(n, ch)
-            v_opac = flat[(5 + ch) * n:]
-            rows = max(total, 1) * (4 if ctx.split else 1)
+            _mark("bwd:device ctx")
+            # v_xy | v_conic | v_colors | [v_depth] | v_opacity: ONE buffer, so that the multi-GPU path
+            # can all-reduce it in place
+            flat = torch.empty((n * (6 + ch),), **f32)
+            rows = max(F.total, 1) * (4 if F.split else 1)
             partials = torch.empty((rows, 12), **f32)
             row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
-            _call("ts_raster_bwd", lib.ts_raster_bwd, ch, ctx.split, total, cam, _ptr(tile_bins), _ptr(ids),
-                  _ptr(splats), _ptr(bg), _ptr(final_Ts), _ptr(final_idx), _ptr(v_img), None,
-                  _ptr(clamp_mask), _ptr(partials), _ptr(row_flags), s)
-            _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, 1 | ctx.split, _ptr(nth), _ptr(cum),
-                  _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
-                  _ptr(v_cols), _ptr(v_opac), s)
-            if ctx.group is not None:                          # tile-stripe sharding: sum over ranks
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
-            if ch == 4:
-                v_colors = v_cols[:, :3].contiguous()
-                v_depth = v_cols[:, 3].contiguous()
-            else:
-                v_colors, v_depth = v_cols, torch.zeros((n,), **f32)
-            v_dc = torch.empty((n, 3), **f32)
-            v_rest = torch.empty((n, ctx.nb - 1, 3), **f32)
-            _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, n, ctx.sh_degree, ctx.nb, _ptr(means),
-                  _ptr(origin), _ptr(mask), _ptr(v_colors), _ptr(v_dc),
-                  _ptr(v_rest) if ctx.nb > 1 else None, s)
+            _mark("bwd:flat+partials+flags")
             v_means = torch.empty((n, 3), **f32)
             v_scales = torch.empty((n, 3), **f32)
             v_quats = torch.empty((n, 4), **f32)
-            _call("ts_project_bwd", lib.ts_project_bwd, n, _ptr(means), _ptr(scales), _ptr(quats),
-                  _ptr(view34), _ptr(projview), cam, 3, _ptr(radii), _ptr(v_xy), _ptr(v_depth),
-                  _ptr(v_conic), None, _ptr(v_means), _ptr(v_scales), _ptr(v_quats), s)
+            v_dc = torch.empty((n, 3), **f32)
+            v_rest = torch.empty(tuple(ctx.rest_shape), **f32)
+            p = flat.data_ptr()
+            fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
+            fr.v_xy, fr.v_conic, fr.v_colors = p, p + 8 * n, p + 20 * n
+            fr.v_depth = p + 32 * n if ch == 4 else None
+            fr.v_opacity = p + (20 + 4 * ch) * n
+            fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
+            fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
+            _mark("bwd:allocated")
+            timed = kernel_timer.enabled
+            if timed:
+                _steps_bwd_composite(lib, fr, s)
+            else:
+                _lib.check(lib.ts_frame_bwd_composite(ctypes.byref(fr), s), "ts_frame_bwd_composite")
+            if ctx.group is not None:                          # tile-stripe sharding: sum over ranks
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+            if timed:
+                _steps_bwd_params(lib, fr, s)
+            else:
+                _lib.check(lib.ts_frame_bwd_params(ctypes.byref(fr), s), "ts_frame_bwd_params")
+        _mark("bwd:calls")
+        v_xy = flat[:2 * n].view(n, 2)
+        v_opac = flat[(5 + ch) * n:]
         # what extras['xys'].grad holds in the reference (model_gaussian.py:130-132).  `xys` carries no
         # autograd edge on this fused path (retain_grad() is not needed and would raise); the gradient
         # is a compact copy - not a view that pins the n*(6+ch) buffer - and accumulates like a
         # retained grad when a second backward reaches the same frame.
         xo = ctx.xys_out
         xo.grad = v_xy.clone() if xo.grad is None else xo.grad + v_xy
-        return (v_means, v_scales, v_quats, v_opac.view(ctx.opacity_shape), v_dc, v_rest) + (None,) * 12
+        _mark("bwd:exit")
+        return (v_means, v_scales, v_quats, v_opac.view(ctx.opacity_shape).clone(), v_dc, v_rest) + (None,) * 12
 
 
 @torch.no_grad()
@@ -177,66 +336,11 @@ def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: flo
     viewer.py:89-93): the kernels of ``render_frame`` without anything kept for a backward pass -
     no cov3d, clamp mask, final_Ts / final_index outputs, no autograd node.
     -> (image[rows, W, 3 or 4] with RGB clamped to <= 1, xys[N,2], radii[N])."""
-    ps = [model.means, model.scales, model.quats, model.opacities, model.colors_dc, model.colors_rest,
-          view34, projview, origin, model.background]
-    dev = _need_hip(*ps)
-    means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background = (
-        _f32c(t.detach()) for t in ps)
-    n, nb = means.shape[0], colors_rest.shape[1] + 1
-    sh_degree = int(model.active_sh_degree)
-    if sh_degree < 0 or sh_degree > deg_from_sh(nb):
-        raise ValueError("sh_degree exceeds the stored coefficients")
-    w, h = int(width), int(height)
-    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
-    ch = 4 if with_depth else 3
-    bg = _f32c(torch.cat([background, background[:1]]) if with_depth else background)
-    f32 = dict(dtype=torch.float32, device=dev)
-    i32 = dict(dtype=torch.int32, device=dev)
-    lib = _lib.load()
-    s = _stream(dev)
-    with torch.cuda.device(dev):
-        xys = torch.empty((n, 2), **f32); depths = torch.empty((n,), **f32)
-        radii = torch.empty((n,), **i32); conics = torch.empty((n, 3), **f32)
-        nth = torch.empty((n,), **i32)
-        _call("ts_project_fwd", lib.ts_project_fwd, n, _ptr(means), _ptr(scales), _ptr(quats),
-              _ptr(view34), _ptr(projview), cam, 3, _ptr(xys), _ptr(depths), _ptr(radii),
-              _ptr(conics), _ptr(nth), None, s)
-        num_tiles = cam.tile_rows * cam.tile_bounds_x
-        cum = torch.empty((n,), **i32)
-        ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
-        _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth), _ptr(cum), _ptr(ws), s)
-        pending = _IntersectionCount(cum, dev)
-        cols = torch.empty((n, ch), **f32)
-        colors = cols if ch == 3 else torch.empty((n, 3), **f32)
-        _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, n, sh_degree, nb, _ptr(means), _ptr(origin),
-              _ptr(colors_dc), _ptr(colors_rest) if nb > 1 else None, _ptr(colors), None, s)
-        if ch == 4:
-            torch.cat([colors, depths[:, None]], dim=1, out=cols)
-        bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
-        tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-        splats = torch.empty((max(n, 1), 12), **f32)
-        _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1, _ptr(xys), _ptr(radii), _ptr(conics),
-              _ptr(cols), _ptr(opacities), _ptr(cum), cam, _ptr(splats), s)
-        tight = _ptr(splats) if TIGHT_BINNING else None
-        _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys), _ptr(radii), tight, cam, _ptr(bin_ws), s)
-        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
-        total = pending.wait()
-        bucket_ids = torch.empty((max(total, 1),), **i32)
-        ids = torch.empty((max(total, 1),), **i32)
-        if total > 0:
-            _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys), _ptr(radii), tight, cam,
-                  _ptr(bin_ws), _ptr(bucket_ids), s)
-            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths),
-                  _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), s)
-        out_img = torch.empty((_stripe_rows(cam), w, ch), **f32)
-        split = 4 if 0 < num_tiles <= SPLIT_BLOCKS_BELOW else 0
-        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 2 | split, cam, _ptr(tile_bins), _ptr(ids), _ptr(splats),
-              _ptr(bg), _ptr(out_img), None, None, None, s)
-    b = TileBinning()
-    b.cam, b.n, b.num_tiles, b.num_intersects = cam, n, num_tiles, total
-    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = tile_bins[:num_tiles], ids[:total], cum, nth
-    last_binning[dev.index] = b
-    return out_img, xys, radii
+    F = _forward(model.means.detach(), model.scales.detach(), model.quats.detach(), model.opacities.detach(),
+                 model.colors_dc.detach(), model.colors_rest.detach(), view34, projview, origin,
+                 model.background, fx, fy, width, height, int(model.active_sh_degree), with_depth, tile_rows,
+                 keep=False)
+    return F.out_img, F.xys, F.radii
 
 
 def render_frame(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,

@@ -461,7 +461,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call("ts_pack_splats", lib.ts_pack_splats, n, ch, 1 if logit_opacity else 0, _ptr(xys_c), _ptr(b._keep[2]), _ptr(conics_c),
                                           _ptr(colors_c), _ptr(opac_c), _ptr(b.cum_tiles_hit), cam,
-                                          _ptr(splats), s)
+                                          None, _ptr(splats), s)
             _call("ts_raster_fwd", lib.ts_raster_fwd, ch, 0, cam, _ptr(b.tile_bins), _ptr(b.gaussian_ids_sorted),
                                          _ptr(splats), _ptr(bg_c), _ptr(out_img), _ptr(final_Ts),
                                          _ptr(final_idx), None, s)
@@ -502,7 +502,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _ptr(v_out_alpha), None, _ptr(partials), _ptr(row_flags), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, ctx.logit, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
                                               _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
-                                              _ptr(v_colors), _ptr(v_opacity), s)
+                                              _ptr(v_colors), _ptr(v_opacity), None, s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
                 None, None, None, None, None)
 

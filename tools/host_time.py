@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from tinysplat_amd import ops
 from tinysplat_amd.rasterizer import GaussianRasterizer
-from tinysplat_amd.sharding import render_rgb_stripe
+from tinysplat_amd.sharding import render_stripe
 from tinysplat_amd.synthetic import loss_weights, make_scene
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 w, h, dev = 1920, 1080, torch.device("cuda:0")
@@ -16,7 +16,7 @@ w_rgb = loss_weights(w, h)[0].to(dev)
 ad = GaussianRasterizer(model, None, device=dev)
 def step():
     for p in model.parameters(): p.grad = None
-    rgb, (y0, y1), _ = render_rgb_stripe(model, cam, (w, h), ad.ops, dev, 0, 1)
+    rgb, (y0, y1), _ = render_stripe(model, cam, (w, h), dev, 0, 1)
     (rgb * w_rgb).sum().backward()
 for _ in range(5): step()
 torch.cuda.synchronize()

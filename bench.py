@@ -321,6 +321,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale-mult", type=float, default=1.0)
     ap.add_argument("--depth", action="store_true", help="also render and differentiate the depth output")
+    ap.add_argument("--spatial-sort", action="store_true",
+                    help="reorder the synthetic scene along a Morton curve of the means before it is rendered "
+                         "(SplatModel.spatial_sort_: same scene, different memory order; outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not re-run the workload under rocprofv3 --pmc for roofline.traffic / valu_roofline")
@@ -388,7 +391,10 @@ def main():
 
     n, w, h, sh = args.n, args.width, args.height, args.sh_degree
     model, cam = make_scene(n, sh, w, h, seed=0, scale_mult=args.scale_mult)
-    model = model.to(dev).requires_grad_(True)
+    model = model.to(dev)
+    if args.spatial_sort:
+        model.spatial_sort_()
+    model.requires_grad_(True)
     w_rgb, w_d = loss_weights(w, h)
     w_rgb, w_d = w_rgb.to(dev), w_d.to(dev)
     adapter = GaussianRasterizer(model, None, device=dev)
@@ -500,6 +506,7 @@ def main():
         if world == 1 and not args.no_pmc and not args.train_step:
             wl = ["--n", str(n), "--sh-degree", str(sh), "--width", str(w), "--height", str(h),
                   "--scale-mult", str(args.scale_mult)] + (["--depth"] if args.depth else []) \
+                 + (["--spatial-sort"] if args.spatial_sort else []) \
                  + (["--forward-only"] if args.forward_only else []) \
                  + (["--emulate-ranks", str(args.emulate_ranks), "--emulate-rank", str(args.emulate_rank)]
                     if args.emulate_ranks > 1 else [])
@@ -586,6 +593,8 @@ def main():
                        "parallelism": (f"tile-row stripes x{world}" + (" (ALL RANKS ON ONE GPU: functional test, "
                                        "not a measurement)" if args.single_device else "")) if world > 1 else "single GPU",
                        "scale_mult": args.scale_mult,
+                       "gaussian_order": "Morton curve of the means (--spatial-sort)" if args.spatial_sort
+                                         else "as generated (i.i.d.)",
                        **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "
                                               "(per-rank estimate, not a multi-GPU measurement)"}
                           if args.emulate_ranks > 1 and world == 1 else {})},

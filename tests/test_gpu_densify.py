@@ -214,3 +214,59 @@ def test_training_with_densification_changes_n_and_keeps_rendering():
         assert getattr(model, f).shape[0] == sizes[-1]
         assert trainer.optimizer.exp_avg[f].shape == getattr(model, f).shape
     assert dens.means_grad_accum.shape[0] == sizes[-1]
+
+
+def test_spatial_order_is_a_permutation_that_leaves_the_frame_unchanged():
+    """SplatModel.spatial_sort_ / DensifyConfig.spatial_order (not in the reference): the rows are
+    permuted along a Morton curve; the rendered frame is the same (depth ties aside) and every
+    gradient row moves with its Gaussian."""
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    from tinysplat_amd.synthetic import make_scene
+    w, h, n = 320, 200, 30000
+    res = []
+    for sort in (False, True):
+        model, cam = make_scene(n, 2, w, h, seed=11, scale_mult=2.5)
+        model = model.to(DEV)
+        perm = model.spatial_sort_() if sort else torch.arange(n, device=DEV)
+        model.requires_grad_(True)
+        rgb, ex = GaussianRasterizer(model, None, device=torch.device(DEV))(cam, (w, h), 2)
+        g = torch.Generator().manual_seed(2)
+        ((rgb * torch.rand(h, w, 3, generator=g).to(DEV)).sum() + ex["depth"].sum()).backward()
+        res.append((rgb.detach(), ex["depth"].detach(), perm, [p.grad for p in model.parameters()], ex["radii"]))
+    (rgb0, d0, _, g0, r0), (rgb1, d1, perm, g1, r1) = res
+    assert sorted(perm.tolist()) == list(range(n)) and not torch.equal(perm, torch.arange(n, device=DEV))
+    assert torch.equal(r0[perm], r1)
+    assert (rgb0 - rgb1).abs().max() < 1e-6 and (d0 - d1).abs().max() < 1e-5
+    for a, b in zip(g0, g1):
+        assert (a[perm] - b).abs().max() <= 1e-5 * max(1.0, a.abs().max().item())
+    # densification with spatial_order: same multiset of rows as without, moments and accumulator follow
+    p, m, v, accum, g = _random_state(20000, 3, 5)
+    z = None
+    outs = []
+    for so in (False, True):
+        model, optim = _on_device(p, m, v)
+        dens = Densifier(model, DensifyConfig(interval_densify=100, spatial_order=so))
+        dens.means_grad_accum = accum.to(DEV)
+        flags = dens.classify(1920, 1080)
+        s_cnt = int(((flags & 2) != 0).sum())
+        if z is None:
+            z = torch.randn(2 * s_cnt, 3, generator=g).to(DEV)
+        assert dens.densify_and_prune(700, optim, {"camera": {"width": 1920, "height": 1080}}, z=z)
+        outs.append((model, optim))
+    (ma, oa), (mb, ob) = outs
+    for f in D.FIELDS:
+        assert getattr(ma, f).shape == getattr(mb, f).shape
+    col = lambda t: torch.sort(t.detach().reshape(t.shape[0], -1)[:, 0]).values
+    assert torch.equal(col(ma.means), col(mb.means)) and torch.equal(col(ma.scales), col(mb.scales))
+    # kept rows carry their (unique, non-zero) Adam moments: match them up by exp_avg["means"][:, 0]
+    ka, kb = oa.exp_avg["means"][:, 0], ob.exp_avg["means"][:, 0]
+    ia, ib = torch.argsort(ka, stable=True), torch.argsort(kb, stable=True)
+    kept = ka[ia] != 0
+    assert torch.equal(kept, kb[ib] != 0) and int(kept.sum()) > 1000
+    for f in D.FIELDS:
+        assert torch.equal(getattr(ma, f).detach()[ia][kept], getattr(mb, f).detach()[ib][kept]), f
+        assert torch.equal(oa.exp_avg_sq[f][ia][kept], ob.exp_avg_sq[f][ib][kept]), f
+        assert not ob.exp_avg[f][ib][~kept].any()                                     # new rows: zero moments
+    d = (mb.means.detach()[1:] - mb.means.detach()[:-1]).norm(dim=1).mean()
+    d0 = (ma.means.detach()[1:] - ma.means.detach()[:-1]).norm(dim=1).mean()
+    assert d < 0.5 * d0                                     # neighbours in memory are neighbours in space

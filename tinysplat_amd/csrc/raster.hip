@@ -22,10 +22,15 @@
 //   * Per-pixel bodies are branch free inside a block and lean: log2(opacity) is folded into the
 //     exponent, the compositing weight is T_old - T_new (telescoping), a finished pixel is marked
 //     by the sign of T, and Gaussians that need the sigma >= 0 / 0.999-clamp tests are flagged at
-//     staging so that the common chunk runs a loop without them.  Both kernels are VALU-issue
-//     bound (~4 cycles per wave64 VALU op), so instruction count is what sets their time; this
-//     file is built with -fno-slp-vectorize because the SLP packer's register shuffles cost more
-//     issue slots than its v_pk_* ops save.
+//     staging so that the common chunk runs a loop without them.  Nothing is set up per entry: a
+//     flagged block evaluates dx, dy and the exponent itself (8 issues, sigma_l2).  Both kernels
+//     are VALU-issue bound - 97 % / 89 % of the 39.3 T lane-operations/s that non-packed wave64
+//     instructions can issue (bench.py: valu_roofline) - so instruction count is what sets their
+//     time.  Packed fp32 (v_pk_fma_f32 does issue at twice the scalar rate on this part,
+//     tools/micro/pk_bench.hip) does not apply: the per-pixel chain is compare / select /
+//     transcendental heavy and its multiply-adds are serially dependent; this file is built with
+//     -fno-slp-vectorize because the SLP packer's register shuffles cost more issue slots than its
+//     v_pk_* ops save.
 //   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
 //     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
 //     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot
@@ -72,10 +77,18 @@ __device__ __forceinline__ int wave_max_int(int v) {
     return v;
 }
 
-// sigma * log2(e) for one pixel; explicit fmas so that forward and backward (which must replay the
-// forward's alpha >= 1/255 decisions) evaluate bit-identical values whatever the optimiser does.
-__device__ __forceinline__ float sigma_l2(float diag, float Bdx, float dy) {
-    return __builtin_fmaf(dy, Bdx, diag);      // diag = hA dx^2 + hC dy^2
+// sigma * log2(e) - log2(opacity) of one pixel from d = xy - pixel: six explicit operations in a
+// fixed order, so that forward and backward (which must replay the forward's alpha >= 1/255
+// decisions) evaluate bit-identical values whatever the optimiser does.
+// Evaluated PER FLAGGED BLOCK (8 issues with dx, dy), with nothing set up per entry.  The first
+// version shared dx, dy, hA dx^2, B dx and hC dy^2 - lo between the two halves of the tile: 17 issues
+// per entry plus 2 per block, which pays from 2.8 blocks per entry up - but with tight tile lists and
+// the per-block cull an entry reaches 1.2 blocks on average, so the shared set-up was mostly spent on
+// halves that are never evaluated.
+__device__ __forceinline__ float sigma_l2(float hA, float B, float hC, float neg_lo, float dx, float dy) {
+    float s = __builtin_fmaf(hC * dy, dy, neg_lo);      // hC dy^2 - log2(opacity)
+    s = __builtin_fmaf(hA * dx, dx, s);
+    return __builtin_fmaf(B * dx, dy, s);
 }
 
 // XCD-aware workgroup -> tile-group mapping.  Workgroup b is observed to run on XCD (b % 8), and
@@ -187,24 +200,15 @@ using mask64 = unsigned long long;
 // GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
 // positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
 template <int CH, bool GENERAL>
-__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
-                                          float fpy0, float (&T)[4], int (&fidx)[4],
+__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[2],
+                                          const float (&fpy)[2], float (&T)[4], int (&fidx)[4],
                                           float (&acc)[4][CH]) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
         const int idx = __float_as_int(r2.z);
-        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
-        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
-        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
         const float neg_lo = -r1.y;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Ax[h] = (r0.z * dxv[h]) * dxv[h];
-            Bx[h] = r0.w * dxv[h];
-            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
-        }
         float col[CH];
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
@@ -212,7 +216,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
         for (int k = 0; k < 4; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
-            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dyv[k >> 1]);
+            const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k & 1], r0.y - fpy[k >> 1]);
             float a = __builtin_amdgcn_exp2f(-sgl);
             bool ok = a >= ts::kAlphaMin;
             if (GENERAL) {
@@ -260,7 +264,9 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
     const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
-    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
+    // sample positions of the lane's pixel in the left / right and the upper / lower blocks
+    const float fpx[2] = {(float)px0 + ts::kPixOff, (float)(px0 + 8) + ts::kPixOff};
+    const float fpy[2] = {(float)py0 + ts::kPixOff, (float)(py0 + 8) + ts::kPixOff};
     const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
 
@@ -325,9 +331,9 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         // bit 4 of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
         // once per chunk so that the common case runs a loop without those tests
         if (__ballot(keep && (s.mask & 16)) != 0ull)
-            fwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, fidx, acc);
+            fwd_chunk<CH, true>(lds, cnt, fpx, fpy, T, fidx, acc);
         else
-            fwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, fidx, acc);
+            fwd_chunk<CH, false>(lds, cnt, fpx, fpy, T, fidx, acc);
         TS_WAVE_SYNC();
     }
 
@@ -431,8 +437,8 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
 // Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
 // (ra = 1, fac = 0, v_sig = 0) and changes nothing.
 template <int CH, bool GENERAL>
-__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, float fpx0,
-                                          float fpy0, float (&T)[4], float (&R)[4],
+__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[2],
+                                          const float (&fpy)[2], float (&T)[4], float (&R)[4],
                                           const float (&vo)[4][CH], const int (&fidx)[4],
                                           float (&acc)[6 + CH], long long num_isects,
                                           float* __restrict__ partials,
@@ -445,16 +451,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
         const int idx = __float_as_int(r2.z);
-        float dxv[2], dyv[2], Ax[2], Bx[2], Cyl[2];
-        dxv[0] = r0.x - fpx0; dxv[1] = dxv[0] - 8.0f;
-        dyv[0] = r0.y - fpy0; dyv[1] = dyv[0] - 8.0f;
         const float neg_lo = -r1.y;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Ax[h] = (r0.z * dxv[h]) * dxv[h];
-            Bx[h] = r0.w * dxv[h];
-            Cyl[h] = __builtin_fmaf(r1.x * dyv[h], dyv[h], neg_lo);   // hC dy^2 - log2(opacity)
-        }
         float col[CH];
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
@@ -463,8 +460,8 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
-            const float dx = dxv[k & 1], dy = dyv[k >> 1];
-            const float sgl = sigma_l2(Ax[k & 1] + Cyl[k >> 1], Bx[k & 1], dy);
+            const float dx = r0.x - fpx[k & 1], dy = r0.y - fpy[k >> 1];
+            const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, dx, dy);
             const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
             float a = araw;
             mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx[k]);
@@ -540,7 +537,9 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const int tbx = cam.tile_bounds_x;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
     const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
-    const float fpx0 = (float)px0 + ts::kPixOff, fpy0 = (float)py0 + ts::kPixOff;
+    // sample positions of the lane's pixel in the left / right and the upper / lower blocks
+    const float fpx[2] = {(float)px0 + ts::kPixOff, (float)(px0 + 8) + ts::kPixOff};
+    const float fpy[2] = {(float)py0 + ts::kPixOff, (float)(py0 + 8) + ts::kPixOff};
     const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
     const int row_off = cam.tile_row0 * 16;
@@ -634,10 +633,10 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
         }
         TS_WAVE_SYNC();
         if (__ballot(keep && (s.mask & 16)) != 0ull)
-            bwd_chunk<CH, true>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+            bwd_chunk<CH, true>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
                                 row_flags, lane);
         else
-            bwd_chunk<CH, false>(lds, cnt, fpx0, fpy0, T, R, vo, fidx, acc, num_isects, partials,
+            bwd_chunk<CH, false>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
                                  row_flags, lane);
         TS_WAVE_SYNC();
     }

@@ -41,6 +41,13 @@ class DensifyConfig:
     epsilon_alpha: float = 0.005
     tau_means: float = 0.0002
     densify_scale_thresh: float = 0.01
+    # Not in the reference: after a rebuild, order the rows along a Morton curve of the means
+    # (synthetic.morton_order).  The reference appends clones and split samples at the end
+    # (model_gaussian.py:179-195), so a trained model's memory order is an accident of its history; the
+    # binning scatter and the compositing gathers run measurably faster when neighbours in space are
+    # neighbours in memory (5 M Gaussians at 4K, 5.6 -> 4.9 ms per frame).  Off by default:
+    # with it the rows are a permutation of the reference's layout.
+    spatial_order: bool = False
 
 
 def _row_floats(t: Tensor) -> int:
@@ -125,7 +132,29 @@ class Densifier:
         self._rebuild(optim, flags, z)
         self.means_grad_accum = torch.zeros(self.model.means.shape[0], dtype=torch.float32,
                                             device=self.model.means.device)        # :195
+        if self.cfg.spatial_order:
+            self.reorder(optim)
         return True
+
+    @torch.no_grad()
+    def reorder(self, optim, perm: Optional[Tensor] = None) -> Tensor:
+        """Permutes the rows of the six parameter tensors, both Adam moments and the gradient
+        accumulator (default: along a Morton curve of the means, synthetic.morton_order) and returns
+        the permutation.  Not in the reference - see DensifyConfig.spatial_order."""
+        from .synthetic import morton_order
+        m = self.model
+        if perm is None:
+            perm = morton_order(m.means)
+        for f in FIELDS:
+            old = getattr(m, f)
+            p = old.detach().index_select(0, perm).requires_grad_(old.requires_grad)
+            setattr(m, f, p)
+            optim.params[f] = p
+            optim.exp_avg[f] = optim.exp_avg[f].index_select(0, perm)
+            optim.exp_avg_sq[f] = optim.exp_avg_sq[f].index_select(0, perm)
+        if self.means_grad_accum.shape[0] == perm.shape[0]:
+            self.means_grad_accum = self.means_grad_accum.index_select(0, perm)
+        return perm
 
     # ------------------------------------------------------------------ :197-242
     @torch.no_grad()

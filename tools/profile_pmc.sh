@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CNT --output-format csv -d "$OUT/raw" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
+rocprofv3 --pmc $CNT --output-format csv -d "$OUT/raw" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-pmc --no-bandwidth "$@" > "$OUT/bench.log" 2>&1
 F=$(find "$OUT/raw" -name "*counter_collection.csv" | head -1)
 python - "$F" "$OUT/${TAG}_pmc_summary.csv" <<'PY'
 import csv, sys, collections

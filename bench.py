@@ -150,16 +150,21 @@ def cpu_baseline(budget_s: float = 100.0):
         avail = os.cpu_count() or 1
     cpu = _cpu_model()
 
-    def timed(fn, warm=2, runs=5, deadline=None):
-        ts = []
+    def timed(fn, warm=2, runs=5, max_seconds=None):
+        """-> (median seconds, timed runs).  Stops as soon as `max_seconds` have passed (checked after
+        every call, warm-ups included); if not even one timed run fitted, the last warm-up stands in
+        and the run count is reported as 0."""
+        t_in = time.perf_counter()
+        ts, last = [], None
         for i in range(warm + runs):
             t0 = time.perf_counter()
             fn()
+            last = time.perf_counter() - t0
             if i >= warm:
-                ts.append(time.perf_counter() - t0)
-            if deadline is not None and time.perf_counter() > deadline and len(ts) >= 1:
+                ts.append(last)
+            if max_seconds is not None and time.perf_counter() - t_in > max_seconds:
                 break
-        return _median(ts), len(ts)
+        return (_median(ts), len(ts)) if ts else (last, 0)
 
     # config 1: forward only
     n1, w1, h1 = 10_000, 256, 256
@@ -175,7 +180,7 @@ def cpu_baseline(budget_s: float = 100.0):
     best_t, cores = None, avail
     for th in sorted({avail, min(16, avail)}, reverse=True):
         torch.set_num_threads(th)
-        t1, r1 = timed(fwd1, deadline=t_begin + 0.15 * budget_s * (1 if th == avail else 2))
+        t1, r1 = timed(fwd1, max_seconds=0.08 * budget_s)
         config1[f"threads_{th}"] = {"value": n1 * w1 * h1 / t1, "ms_per_frame": t1 * 1e3, "runs": r1}
         if best_t is None or t1 < best_t:
             best_t, cores = t1, th
@@ -202,7 +207,7 @@ def cpu_baseline(budget_s: float = 100.0):
         return run
 
     rows = (30, 38)
-    ts, rs = timed(fwd_bwd2(rows), deadline=t_begin + 0.5 * budget_s)
+    ts, rs = timed(fwd_bwd2(rows), max_seconds=0.3 * budget_s)
     px_s = (min(16 * rows[1], h2) - 16 * rows[0]) * w2
     sample = {"value": n2 * px_s / ts, "ms": ts * 1e3, "runs": rs, "pixels": px_s,
               "workload": f"BASELINE configs[1] (100k Gaussians, SH 3, 1920x1080, fwd+bwd RGB), tile rows "
@@ -212,7 +217,7 @@ def cpu_baseline(budget_s: float = 100.0):
     est_full = ts * (w2 * h2) / px_s
     left = budget_s - (time.perf_counter() - t_begin)
     if 4.0 * est_full <= left:           # 2 warm-ups + >= 2 timed runs fit
-        tf, rf = timed(fwd_bwd2((0, tby)), deadline=t_begin + budget_s)
+        tf, rf = timed(fwd_bwd2((0, tby)), max_seconds=left)
         out["config2_full"] = {"value": n2 * w2 * h2 / tf, "ms_per_frame": tf * 1e3, "runs": rf}
         out["value"] = out["config2_full"]["value"]
         what = f"whole frame, median of {rf} runs = {tf * 1e3:.0f} ms/frame"

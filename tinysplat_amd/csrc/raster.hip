@@ -26,11 +26,11 @@
 //     flagged block evaluates dx, dy and the exponent itself (8 issues, sigma_l2).  Both kernels
 //     are VALU-issue bound - 97 % / 89 % of the 39.3 T lane-operations/s that non-packed wave64
 //     instructions can issue (bench.py: valu_roofline) - so instruction count is what sets their
-//     time.  Packed fp32 (v_pk_fma_f32 does issue at twice the scalar rate on this part,
-//     tools/micro/pk_bench.hip) does not apply: the per-pixel chain is compare / select /
-//     transcendental heavy and its multiply-adds are serially dependent; this file is built with
-//     -fno-slp-vectorize because the SLP packer's register shuffles cost more issue slots than its
-//     v_pk_* ops save.
+//     time.  Packed fp32 does not help here although an isolated stream of v_pk_fma_f32 issues at
+//     twice the scalar rate (tools/micro/pk_bench.hip): packing the natural pairs of the bodies -
+//     (dx, dy), (hA dx, hC dy), (v dx, v dy), the moment and colour accumulators - removed 12 % of
+//     the instructions and none of the time.  The file is built with
+//     -fno-slp-vectorize because the SLP packer's register shuffles cost issue slots on top.
 //   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
 //     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
 //     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot

@@ -68,8 +68,7 @@ def _total_slot(dev: torch.device):
 class _Frame:
     """Buffers of one frame plus the ``ts_frame`` struct that points at them."""
     __slots__ = ("fr", "cam", "n", "nb", "ch", "w", "h", "num_tiles", "total", "split", "keep",
-                 "wf", "wi", "bin_ws", "tile_bins", "sh_mask", "ids", "bucket_ids", "out_img", "final_Ts",
-                 "final_idx", "clamp_mask", "xys", "radii", "nth", "cum", "inputs", "bg")
+                 "wf", "tile_bins", "ids", "bucket_ids", "out_img", "xys", "radii", "nth", "cum", "inputs", "bg")
 
 
 def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background,
@@ -141,7 +140,6 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         F.nth = view(6, torch.int32, n, (n,))
         F.cum = view(7, torch.int32, n, (n,))
         F.tile_bins = view(10, torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
-        F.wi = F.bin_ws = F.sh_mask = F.final_Ts = F.final_idx = F.clamp_mask = None    # live inside F.wf
         host, event = _total_slot(dev)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch

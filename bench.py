@@ -36,9 +36,11 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak; 256 CUs x 4 SIMDs x 16 lanes at
-# 2.4 GHz = 39.3 T fp32 lane-operations/s for non-packed VALU instructions (one wave64 instruction
-# occupies a SIMD for 4 cycles), 157.3 TFLOP/s with packed (2-wide) FMAs
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak.  VALU yardstick: one wave64
+# instruction per 4 cycles = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-operations/s.  That
+# flat rate is what compare / select / DPP instructions cost (4.2-4.4 cycles measured,
+# tools/micro/op_bench.hip); FMA-class instructions with VGPR operands issue faster (~3), exp2 / rcp
+# slower (~8.3) - DESIGN.md section 4 has the table.  157.3 TFLOP/s is the chip's fp32 vector peak.
 HBM_PEAK_GBS = 8000.0
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 VALU_FP32_PEAK_TFLOPS = 157.3

@@ -39,6 +39,7 @@ COV2D_BLUR = 0.3            # low-pass added to the 2D covariance diagonal
 ALPHA_MAX = 0.999           # forward alpha clamp
 ALPHA_MIN = 1.0 / 255.0     # contribution threshold
 T_EPS = 1e-4                # transmittance early-termination threshold
+F32_SIGMA_ULPS = 2.0         # unit roundoffs (2^-24 of the largest term) one float32 evaluation of sigma may be off by: ~5 roundings, measured 0.1-0.5 (checker margins only)
 PIXEL_CENTER_OFFSET = 0.0   # pixel (j, i) is sampled at (j + off, i + off); 0.1.3-era: 0
 
 SH_C0 = 0.28209479177387814          # == tinysplat/utils.py:8
@@ -357,7 +358,8 @@ def _composite_tiles(xys, conics, colors, opacity, gids, starts, ends, tx, ty, r
     per-(pixel, Gaussian) arithmetic below is elementwise, and the products / index reductions run
     along the list axis of each pixel independently.  All 256 pixels of a tile are evaluated; the
     caller crops those beyond the image.
-    -> pix [B,256,C] (colour without background), T_fin [B,256], f_idx [B,256] int64, margin [B,256] f64 | None
+    -> pix [B,256,C] (colour without background), T_fin [B,256], f_idx [B,256] int64,
+       aux None | (margin, margin_f32, cond, mag_max), each [B,256] f64 - see rasterize_gaussians
     """
     dt = xys.dtype
     B = starts.shape[0]
@@ -404,17 +406,38 @@ def _composite_tiles(xys, conics, colors, opacity, gids, starts, ends, tx, ty, r
             mag = (0.5 * ((cA * dx * dx).abs() + (cC * dy * dy).abs()) + (cB * dx * dy).abs()).double()
             m_s = torch.where(seen & (mag > 0), sigma.double().abs() / (mag + 1e-300), big)
             margin = torch.minimum(torch.minimum(m_a, m_t), m_s).min(dim=2).values
+            # The same distances, less what float32 rounding of sigma can move them.  gsplat evaluates
+            # sigma = 0.5 (A dx^2 + C dy^2) + B dx dy in float32: for elongated Gaussians far from the
+            # pixel the three terms (`mag`) are large and cancel, so sigma - hence log(alpha) - carries an
+            # absolute error of a few eps32 * mag whatever the order of the operations.
+            e32 = F32_SIGMA_ULPS * 5.9604645e-08
+            rel_T = torch.cumsum(torch.where(valid, a_eff / (1.0 - a_eff), torch.zeros_like(a_eff)).double() * mag,
+                                 dim=2)                            # d log(next_T) per unit of relative sigma error
+            m_a32 = torch.where(seen & (sigma >= 0), (raw.double() * 255.0 - 1.0).abs() - e32 * mag, big)
+            m_t32 = torch.where(seen & valid, (next_T.double() / T_EPS - 1.0).abs() - e32 * rel_T, big)
+            margin_f32 = torch.minimum(torch.minimum(m_a32, m_t32), m_s).min(dim=2).values
+            # first-order bound of a pixel's colour error per unit colour: |d pix / d sigma_g| <= 2 w_g |c|
+            cond = 2.0 * e32 * (wgt.double() * mag).sum(dim=2)
+            mag_max = torch.where(live, mag, torch.zeros_like(mag)).max(dim=2).values
+            margin = (margin, margin_f32, cond, mag_max)
     return pix, T_fin, f_idx, margin
 
 
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor,
                         num_tiles_hit: Tensor, colors: Tensor, opacity: Tensor, img_height: int,
                         img_width: int, background: Tensor, return_aux: bool = False,
-                        tile_rows=None, batch_elems: int = 1 << 22):
+                        tile_rows=None, batch_elems: int = 1 << 22, compute_dtype=None):
     """-> (out_img[H,W,C], out_alpha[H,W]); with return_aux also a dict of final_Ts, final_index,
     tile_bins, gaussian_ids_sorted and ``margin`` (per-pixel distance of the closest discrete decision
     - alpha >= 1/255, next_T <= 1e-4 - to its threshold, relative; pixels with a tiny margin are the
     ones where two correct float32 implementations may legitimately differ by a whole contribution).
+    ``margin_f32`` is that distance less what float32 rounding of the exponent can move it, and
+    ``cond`` [H,W] bounds, per unit of colour magnitude, how far a float32 evaluation of the exponent
+    can move the pixel; ``mag_max`` [H,W] is the largest sum of |terms| of the exponent among the
+    pixel's contributing Gaussians (all three matter for elongated Gaussians only: see _composite_tiles).
+
+    ``compute_dtype`` (e.g. torch.float64): binning and sorting use the inputs as given (float32 depth
+    bits), the compositing arithmetic runs in this dtype - "the same 2-D inputs, exact arithmetic".
 
     ``batch_elems`` bounds pixels x list length of the tiles composited together by one set of tensor
     ops (tiles of similar list length are grouped and padded); 0 = one tile at a time.  Grouping only
@@ -434,6 +457,9 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
         num_tiles_hit = full_frame_tiles_hit(xys, radii, (tbx, tby, 1))
     _, _, gids, tile_bins = bin_and_sort(xys, depths, radii, num_tiles_hit, (tbx, tby, 1))
     gids = gids.to(torch.int64)
+    if compute_dtype is not None:
+        dt = compute_dtype
+        xys, conics, colors, opacity = xys.to(dt), conics.to(dt), colors.to(dt), opacity.to(dt)
     bg = background.to(dt)
     row_lo, row_hi = (0, tby) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
     rows = row_hi - row_lo
@@ -448,6 +474,9 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     T_all = torch.ones(rows * tbx, P, dtype=dt)
     idx_all = torch.zeros(rows * tbx, P, dtype=torch.int64)
     margin_all = torch.full((rows * tbx, P), float("inf"), dtype=torch.float64)
+    margin32_all = torch.full((rows * tbx, P), float("inf"), dtype=torch.float64)
+    cond_all = torch.zeros((rows * tbx, P), dtype=torch.float64)
+    mag_all = torch.zeros((rows * tbx, P), dtype=torch.float64)
     parts, where = [], []
     k = 0
     while k < order.shape[0]:
@@ -465,7 +494,7 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
         parts.append(T_fin[:, :, None])                               # differentiable copy, see below
         idx_all[sel] = f_idx
         if margin is not None:
-            margin_all[sel] = margin
+            margin_all[sel], margin32_all[sel], cond_all[sel], mag_all[sel] = margin
     if where:
         sel = torch.cat(where)
         pix_all = pix_all.index_copy(0, sel, torch.cat(parts[0::2], dim=0))           # differentiable
@@ -485,7 +514,10 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
         aux = {"final_Ts": to_image(T_all[:, :, None])[:, :, 0].contiguous(),
                "final_index": to_image(idx_all[:, :, None])[:, :, 0].to(torch.int32).contiguous(),
                "tile_bins": tile_bins, "gaussian_ids_sorted": gids.to(torch.int32),
-               "margin": to_image(margin_all[:, :, None])[:, :, 0].contiguous()}
+               "margin": to_image(margin_all[:, :, None])[:, :, 0].contiguous(),
+               "margin_f32": to_image(margin32_all[:, :, None])[:, :, 0].contiguous(),
+               "cond": to_image(cond_all[:, :, None])[:, :, 0].contiguous(),
+               "mag_max": to_image(mag_all[:, :, None])[:, :, 0].contiguous()}
         return out_img, out_alpha, aux
     return out_img, out_alpha
 

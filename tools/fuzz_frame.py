@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Randomised sweep of the whole frame (the adapter's recipe, rasterize.py:26-62: project -> SH colours ->
+RGB + depth compositing, and its backward) on the GPU against the oracle frame (developer tool; the
+first cases also run as tests/test_gpu_fuzz.py).
+
+Each case draws a scene size, SH degree, image size (incl. sizes that are not multiples of 16 and
+images smaller than a tile), footprint scale, opacity law, background, a camera-space shift that puts
+part of the scene behind the near plane, optionally a rotated / translated camera, needle-shaped
+Gaussians (axis ratios up to 64 on top of the generator's 5), duplicated Gaussians (equal depths: the
+order inside a tile is then decided by the Gaussian id) and, now and then, 60 000 large Gaussians on a
+64x48 image (tile lists beyond the 4096-key sorting network).
+
+The reference values are the oracle frame with its compositing arithmetic in float64 on the float32
+2-D inputs (projection, SH, radii and lists are the float32, bit-exact ones).  Checked per case: radii
+exact; RGB within 1e-5 and depth within 1e-4 *plus the float32 bound of the pixel* - gsplat evaluates
+the exponent sigma = 0.5 (A dx^2 + C dy^2) + B dx dy in float32, and for a needle far from the pixel the
+terms are ~10^3..10^4 and cancel, so any float32 implementation (gsplat's, the oracle run in float32,
+this one) is off by a few eps32 * |terms| there; the oracle reports that bound per pixel (`cond`) and
+which pixels have a discrete decision within its reach (`margin_f32`: no weight in the loss).  For
+ordinary Gaussians the bound is below 1e-6 and the check is the plain 1e-5.  Gradients: within
+max(2e-5, 0.5 eps32 max|terms|) * max(1, |ref|_inf) per tensor, no outliers; means / scales / quats of needle
+scenes against the oracle run end to end in float64, allowing 4 x what the float32 projection VJP loses
+on exact inputs (gsplat's formula -X G X with a near-singular conic; measured per case on the host).
+
+usage: fuzz_frame.py [cases] [first_seed]
+"""
+import random
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import torch
+
+from helpers import check_grad, oracle_frame, scene_args     # oracle = checker
+from oracle import gsplat_oracle as O
+from tinysplat_amd.rasterizer import GaussianRasterizer
+
+DEV = "cuda:0"
+MARGIN = 1e-4           # same stability margin as tests/test_gpu_parity.py
+
+
+def draw_case(seed: int):
+    rnd = random.Random(seed)
+    case = dict(
+        seed=seed,
+        n=rnd.choice([1, 7, 300, 3000, 12000]),
+        sh=rnd.choice([0, 1, 2, 3]),
+        dims=rnd.choice([(16, 16), (5, 3), (33, 17), (200, 120), (257, 130), (480, 270)]),
+        scale_mult=rnd.choice([0.5, 1.0, 4.0, 12.0]),
+        opacity=rnd.choice(["normal", "wide", "opaque", "faint"]),
+        z_shift=rnd.choice([0.0, 0.0, -1.5, -3.0]),
+        duplicates=rnd.choice([0, 0, 3]),
+        background=[rnd.random(), rnd.random(), rnd.random()],
+    )
+    # drawn after the fields above so that earlier seeds keep their scenes
+    case["pose"] = rnd.choice([None, None, "random"])
+    case["aniso"] = rnd.choice([None, None, "needles"])
+    if rnd.random() < 0.08:                      # a tile list beyond the 4096-key network (sample sort path)
+        case.update(n=60000, dims=(64, 48), scale_mult=12.0)
+    return case
+
+
+def build(case, dtype=None):
+    w, h = case["dims"]
+    model, cam = scene_args(case["n"], case["sh"], w, h, seed=1000 + case["seed"], scale_mult=case["scale_mult"])
+    g = torch.Generator().manual_seed(2000 + case["seed"])
+    n = case["n"]
+    if case["opacity"] == "wide":
+        model.opacities = torch.empty(n, 1).uniform_(-6.0, 9.0, generator=g)
+    elif case["opacity"] == "opaque":
+        model.opacities = torch.empty(n, 1).uniform_(3.0, 12.0, generator=g)
+    elif case["opacity"] == "faint":
+        model.opacities = torch.empty(n, 1).uniform_(-7.0, -3.0, generator=g)
+    model.means = model.means + torch.tensor([0.0, 0.0, case["z_shift"]])
+    if case["duplicates"] and n >= 8:            # copies of the first rows: equal depth keys inside a tile
+        k = min(n // 2, 50 * case["duplicates"])
+        for name in ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities"):
+            t = getattr(model, name).clone()
+            t[n - k:] = t[:k]
+            setattr(model, name, t)
+        model.colors_dc[n - k:] += 0.25          # same geometry, different colour
+    model.background = torch.tensor(case["background"])
+    if case.get("aniso") == "needles" and n <= 3000:     # one axis 8x longer, one 8x shorter, at random
+        f = torch.tensor([8.0, 1.0, 1.0 / 8.0]).log()
+        idx = torch.stack([torch.randperm(3, generator=g) for _ in range(n)])
+        model.scales = model.scales + f[idx]
+    if case.get("pose") == "random":             # camera off the generator's axis: rotation + translation
+        q = torch.tensor([1.0, 0.0, 0.0, 0.0]) + 0.15 * torch.randn(4, generator=g)
+        pos = 0.4 * torch.randn(3, generator=g)
+        cam.update_view_matrix(pos.numpy(), (q / q.norm()).numpy())
+    return model, cam
+
+
+def _hostmath():
+    """g++ build of the kernels' math header for the host (the same build tests/conftest.py makes)."""
+    import ctypes
+    import subprocess
+    d = ROOT / "tests" / "hostmath"
+    so, src, hdr = d / "_hostmath.so", d / "hostmath.cpp", ROOT / "tinysplat_amd" / "csrc" / "splat_math.h"
+    if (not so.exists()) or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", str(src),
+                        "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def vjp_float32_floor(model, cam, dims, f64, r64):
+    """Relative error (of the tensor's magnitude) of the float32 projection VJP when it is handed the
+    EXACT 2-D gradients of the float64 oracle frame `f64` (model `r64`): what float32 costs in that step
+    alone, whatever produced its inputs.  -> {"means": e, "scales": e, "quats": e}"""
+    import ctypes
+    from conftest import HmCamera, fptr
+    from tinysplat_amd.rasterizer import project_args
+    hm = _hostmath()
+    pa = project_args(model, cam, dims, "cpu")
+    means, scales, gs, quats, vm, pm, fx, fy, cx, cy, H, W, tb = pa
+    n = means.shape[0]
+    hcam = HmCamera(fx, fy, cx, cy, W, H, tb[0], tb[1], 0, tb[1], gs, 0.01)
+    means, scales, quats = means.contiguous(), scales.contiguous(), quats.contiguous()
+    radii = f64["radii"].to(torch.int32).contiguous()
+    v_xy, v_d, v_c = (f64[k].grad.float().contiguous() for k in ("xys", "depths", "conics"))
+    v_m, v_s, v_q = torch.empty(n, 3), torch.empty(n, 3), torch.empty(n, 4)
+    hm.hm_project_bwd(n, fptr(means), fptr(scales), fptr(quats), fptr(vm.contiguous()), fptr(pm.contiguous()),
+                      ctypes.byref(hcam), fptr(radii), fptr(v_xy), fptr(v_d), fptr(v_c), None,
+                      fptr(v_m), fptr(v_s), fptr(v_q))
+    # the host function differentiates w.r.t. exp(scales); the model holds log-scales (d/dlog s = s d/ds)
+    g_s = r64.scales.grad
+    e_s = float((v_s.double() * torch.exp(r64.scales.detach()) - g_s).abs().max()) / max(1.0, float(g_s.abs().max()))
+    g_m = r64.means.grad
+    e_m = float((v_m.double() - g_m).abs().max()) / max(1.0, float(g_m.abs().max()))
+    return {"means": max(e_m, e_s), "scales": e_s, "quats": e_s}       # quats share the scales' path (v_M)
+
+
+def run_case(case):
+    """One case against the oracle frame with float64 compositing on the float32 2-D inputs.  Tolerances:
+    the north star's 1e-5 (1e-4 for depth) plus what float32 evaluation of the exponent can move a
+    pixel (oracle aux `cond`; zero to rounding for ordinary Gaussians, dominant for needles); pixels
+    whose discrete decisions float32 rounding can flip (`margin_f32`) carry no weight."""
+    w, h = case["dims"]
+    sh = case["sh"]
+    model, cam = build(case)
+    ref, _ = build(case)
+    ref.requires_grad_(True)
+    f = oracle_frame(ref, cam, (w, h), depth=True, raster_dtype=torch.float64)
+    aux = f["aux"]
+    stable = aux["margin_f32"] > MARGIN
+    g = torch.Generator().manual_seed(3000 + case["seed"])
+    w_rgb = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    w_d = torch.rand(h, w, generator=g) * stable
+    loss = (f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()
+    if loss.requires_grad:                       # nothing visible: the oracle frame is a constant
+        loss.backward()
+    md = model.to(DEV).requires_grad_(True)
+    rgb, extras = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), sh)
+    ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
+    assert torch.equal(extras["radii"].cpu(), f["radii"]), "radii differ"
+    vis = f["radii"] > 0
+    c_max = max(1.0, float(f["colors"][vis].detach().abs().max()) if vis.any() else 0.0, max(case["background"]))
+    d_max = max(1.0, float(f["depths"][vis].detach().abs().max()) if vis.any() else 0.0)
+    for got, want, base, scale, nm in ((rgb, f["rgb"], 1e-5, c_max, "rgb"),
+                                       (extras["depth"], f["depth"], 1e-4, d_max, "depth")):
+        err = (got.detach().cpu().double() - want.detach().double()).abs()
+        tol = base + scale * aux["cond"]
+        if err.dim() == 3:
+            tol = tol[..., None]
+        over = (err > tol) & (stable[..., None] if err.dim() == 3 else stable)
+        assert not over.any(), (f"{nm}: {int(over.sum())} stable entries beyond 1e-5 + float32 bound "
+                                f"(worst {float((err / tol)[over].max()):.2f} x tolerance)")
+    live = stable & (aux["mag_max"] > 0)
+    mag = float(aux["mag_max"][live].max()) if live.any() else 0.0
+    rel = max(2e-5, 0.25 * O.F32_SIGMA_ULPS * 5.96e-8 * mag)     # sums over pixels average the per-pixel bound down
+    names = ("means", "scales", "quats", "opacities", "colors_dc", "colors_rest")
+    # Needles also make the PROJECTION backward ill-conditioned: the conic is the inverse of a near-singular
+    # 2x2 covariance, and gsplat's VJP  v_cov2d = -X G X  (X = conic, G = v_conic; the same formula here)
+    # cancels terms of size |X||G||X| down to |X|^2 |G| / cond^2.  Fed with EXACT 2-D gradients the float32
+    # VJP alone is off by up to 4e-3 of the gradient's magnitude on such scenes (measured below with the
+    # host build of the kernels' own splat_math.h).  For those tensors the reference is the oracle run end
+    # to end in float64 and the allowance 4 x that measured floor - never below the plain tolerance.
+    exact, floor = None, {}
+    if case.get("aniso") == "needles" and mag > 100.0 and loss.requires_grad:
+        r64, _ = build(case)
+        for nm in names:
+            setattr(r64, nm, getattr(r64, nm).double())
+        r64.background = r64.background.double()
+        r64.requires_grad_(True)
+        f64 = oracle_frame(r64, cam, (w, h), depth=True)
+        if torch.equal(f64["radii"], f["radii"]):
+            f64["conics"].retain_grad()
+            f64["depths"].retain_grad()
+            ((f64["rgb"] * w_rgb.double()).sum() + (f64["depth"] * w_d.double()).sum()).backward()
+            exact = r64
+            floor = vjp_float32_floor(model, cam, (w, h), f64, r64)
+    for nm in names:
+        a, b = getattr(md, nm), getattr(ref, nm)
+        if b.grad is None:
+            assert a.grad is None or a.grad.numel() == 0 or float(a.grad.abs().max()) == 0.0, nm
+            continue
+        if exact is not None and nm in floor:
+            check_grad(nm, a.grad, getattr(exact, nm).grad, rel=max(rel, 4.0 * floor[nm]))
+        else:
+            check_grad(nm, a.grad, b.grad, rel=rel)
+    if f["xys"].grad is not None:
+        check_grad("xys.grad", extras["xys"].grad, f["xys"].grad, rel=rel)
+    return dict(visible=int(vis.sum()), stable=round(float(stable.float().mean()), 4), mag_max=round(mag, 1),
+                grad_rel_tol=rel, cond_max=float(aux["cond"][stable].max()) if stable.any() else 0.0)
+
+
+def main(cases=40, first=0):
+    bad = 0
+    for seed in range(first, first + cases):
+        case = draw_case(seed)
+        try:
+            info = run_case(case)
+            print(f"ok   {case} {info}", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"FAIL {case}: {e}", flush=True)
+    print(f"{cases - bad}/{cases} cases consistent with the oracle")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    sys.exit(main(*a))

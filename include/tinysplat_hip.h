@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 2
+#define TS_ABI_VERSION 3
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -55,7 +55,16 @@ typedef struct ts_camera {
     int32_t tile_row0, tile_rows;
     float glob_scale;
     float clip_thresh;
+    /* Tile shape of the LISTS (binning, sorting, compositing): 0 = gsplat's 16x16 tiles; 1 = wide 32x16
+     * tiles, each the union of two horizontally adjacent 16x16 tiles (column pairs 2j, 2j+1; the last one
+     * may be a single column).  Projection, num_tiles_hit / cum_tiles_hit and tile_row0 / tile_rows always
+     * count 16x16 tiles; images and gradients do not depend on the shape (a Gaussian is composited only
+     * into the 16x16 tiles of its tile box either way), only the number of list entries does. */
+    int32_t wide_tiles;
+    int32_t reserved;
 } ts_camera;
+/* tiles (= lists) of a launch: tile_rows * tile_bounds_x, or tile_rows * ceil(tile_bounds_x / 2) when wide */
+int32_t ts_num_tiles(const ts_camera* cam_host);
 
 /* ============================ project_gaussians (rasterize.py:32) ============================ */
 
@@ -152,10 +161,11 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
                                   /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */
 
 /* Packs the per-Gaussian operands of the compositing kernels into one 48-byte record:
- *   {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 | c2, c3, slot_base(int), bbox_w(int)}
+ *   {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 | c2, c3, slot_base(int), bbox_w | bbox_minx << 16 (int)}
  * channels = 3 (colors[n,3]; c3 = 0) or 4 (colors[n,4]; or, with `depths` non-NULL, colors[n,3] and
  * c3 = depths[i]: the RGB + depth frame of rasterize.py:42-51 in one pass).  slot_base/bbox_w locate the
- * (tile,Gaussian) row of the backward partial buffer: slot = slot_base + ty*bbox_w + tx. */
+ * (tile,Gaussian) row of the backward partial buffer: slot = slot_base + ty*bbox_w + tx (16x16 tile column tx;
+ * a wide tile uses the column of its left half, or of its right half where the box starts there). */
 int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys, const int32_t* radii,
                    const float* conics, const float* colors, const float* opacity,
                    const int32_t* cum_tiles_hit, const ts_camera* cam_host, const float* depths,
@@ -173,6 +183,8 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
  * ts_raster_bwd / ts_reduce_partials the flag makes every (tile, Gaussian) own FOUR partial rows (slot
  * 4 s + block): partials must hold 4 * num_intersects rows and row_flags 4 * num_intersects bytes. */
 #define TS_RASTER_SPLIT_BLOCKS 4
+/* with ts_camera.wide_tiles: keep one wave per 16x16 tile; each walks the list of the wide tile it lies in */
+#define TS_RASTER_NARROW_WAVES 8
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
@@ -221,6 +233,7 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
  * depth composited in one pass).  Forward-only rendering: final_Ts = final_index = clamp_mask = sh_mask = NULL. */
 #define TS_FRAME_TIGHT 1
 #define TS_FRAME_SPLIT 2
+#define TS_FRAME_NARROW_WAVES 8        /* TS_RASTER_NARROW_WAVES for the compositing launches (cam.wide_tiles) */
 typedef struct ts_frame {
     int32_t n, num_bases, sh_degree, channels, flags, reserved;
     ts_camera cam;

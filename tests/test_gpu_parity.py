@@ -463,6 +463,55 @@ def test_tight_binning_drops_only_pairs_that_contribute_nothing():
             assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
 
 
+def test_wide_tiles_change_no_pixel():
+    """frame.WIDE_TILES: lists and sort (mode 2, the default) or also the compositing waves (mode 1) on 32x16
+    tiles (two adjacent 16x16 tiles binned as one, a Gaussian composited only into the halves inside its
+    tile box), against gsplat's 16x16 lists (mode 0).  Image, depth and - through
+    them - every alpha / transmittance decision are bitwise those of 16x16 lists; gradients agree to
+    rounding (a Gaussian spanning both halves is reduced in one wave sum instead of two rows).  Odd and
+    even tile columns, images that are not multiples of 16 / 32, the split mapping (small image), tile-row
+    stripes, opaque Gaussians (general path) and the forward-only frame.  Mode 2 keeps one wave per 16x16
+    tile on the wide lists (TS_RASTER_NARROW_WAVES): same pixels again."""
+    from tinysplat_amd import frame
+    dev = torch.device(DEV)
+    keep_wide = frame.WIDE_TILES
+    cases = [(60000, 2, 800, 450, 2.0, None), (40000, 1, 336, 208, 4.0, None), (30000, 0, 333, 211, 6.0, None),
+             (50000, 1, 1000, 520, 3.0, (7, 19)), (3000, 3, 40, 24, 8.0, None)]
+    for n, sh, w, h, mult, rows in cases:
+        model, cam = scene_args(n, sh, w, h, seed=61 + sh, scale_mult=mult)
+        g = torch.Generator().manual_seed(62)
+        model.opacities = torch.empty(n, 1).uniform_(-5.0, 8.0, generator=g)
+        rows_px = h if rows is None else min(h, 16 * rows[1]) - 16 * rows[0]
+        wr, wd = torch.rand(rows_px, w, 3, generator=g).to(DEV), torch.rand(rows_px, w, generator=g).to(DEV)
+        from tinysplat_amd.rasterizer import camera_on_device
+        view, projview, origin = camera_on_device(cam, dev)
+        res, listed = [], []
+        try:
+            for wide in (0, 1, 2):
+                frame.WIDE_TILES = wide
+                md = model.to(DEV).requires_grad_(True)
+                img, xys, radii = frame.render_frame(md, view[:3, :], projview, origin, cam.f_x, cam.f_y, w, h,
+                                                     True, tile_rows=rows)
+                ((img[..., :3] * wr).sum() + (img[..., 3] * wd).sum()).backward()
+                b = frame.last_binning[0]
+                listed.append(int(b.tile_bins[:, 1].max()))
+                with torch.no_grad():
+                    view_img, _, _ = frame.render_view(md, view[:3, :], projview, origin, cam.f_x, cam.f_y, w, h,
+                                                       True, tile_rows=rows)
+                assert torch.equal(view_img, img.detach())
+                res.append([img.detach(), radii, xys.grad] + [p.grad for p in md.parameters()])
+        finally:
+            frame.WIDE_TILES = keep_wide
+        assert listed[1] < listed[0] and listed[2] == listed[1]           # fewer list entries
+        for other in (1, 2):
+            assert torch.equal(res[0][0], res[other][0]) and torch.equal(res[0][1], res[other][1])
+            for a, b in zip(res[0][2:], res[other][2:]):
+                if a.numel() == 0:
+                    continue
+                tol = 2e-6 * max(1.0, a.abs().max().item())
+                assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol, n, w, h, other)
+
+
 def test_frame_path_with_opaque_and_faint_gaussians_matches_oracle():
     """The adapter's fast path (one node, tight lists, split mapping at this tile count, general
     per-pixel code for opacities > 0.99) against the oracle frame incl. parameter gradients."""

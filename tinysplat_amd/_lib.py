@@ -11,7 +11,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TsCamera(ctypes.Structure):
@@ -22,6 +22,7 @@ class TsCamera(ctypes.Structure):
         ("tile_bounds_x", c_int32), ("tile_bounds_y", c_int32),
         ("tile_row0", c_int32), ("tile_rows", c_int32),
         ("glob_scale", c_float), ("clip_thresh", c_float),
+        ("wide_tiles", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
+    "ts_num_tiles": (c_int32, [_CAM]),
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) hist[j] = 0;
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+    const int ws = cam.wide_tiles ? 1 : 0;                         // list column = 16x16 column >> ws
+    const int tbx = (cam.tile_bounds_x + ws) >> ws;
     for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
         const int r = radii[i];
         if (r <= 0) continue;
@@ -235,8 +237,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
         for (int ty = b.miny; ty < b.maxy; ++ty) {
             int lo, hi;
             tight.row_range(ty, b.minx, b.maxx, lo, hi);
-            for (int tx = lo; tx < hi; ++tx) {
-                const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
+            if (hi <= lo) continue;
+            // list columns: 16x16 tiles lo..hi-1, or the wide tiles that contain them
+            for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) {
+                const int t = (ty - cam.tile_row0) * tbx + tx - t0;
                 if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
             }
         }
@@ -348,6 +352,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) cursor[j] = tile_start[t0 + j] + src[j];
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+    const int ws = cam.wide_tiles ? 1 : 0;                         // list column = 16x16 column >> ws
+    const int tbx = (cam.tile_bounds_x + ws) >> ws;
     for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
         const int r = radii[i];
         if (r <= 0) continue;
@@ -360,8 +366,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
         for (int ty = b.miny; ty < b.maxy; ++ty) {
             int lo, hi;
             tight.row_range(ty, b.minx, b.maxx, lo, hi);
-            for (int tx = lo; tx < hi; ++tx) {
-                const int t = (ty - cam.tile_row0) * cam.tile_bounds_x + tx - t0;
+            if (hi <= lo) continue;
+            for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) {
+                const int t = (ty - cam.tile_row0) * tbx + tx - t0;
                 if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
             }
         }
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
             c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2];
         }
         q1 = make_float4(conics[3 * i + 1], conics[3 * i + 2], c0, c1);
-        q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w));
+        q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w | (b.minx << 16)));
       }
     }
     splats[3 * (size_t)i] = q0;
@@ -740,6 +747,12 @@ inline int launch_status() { return (int)hipGetLastError(); }
 }  // namespace
 
 extern "C" {
+
+int32_t ts_num_tiles(const ts_camera* cam) {
+    if (!cam) return 0;
+    const int tbx = cam->wide_tiles ? (cam->tile_bounds_x + 1) / 2 : cam->tile_bounds_x;
+    return cam->tile_rows * tbx;
+}
 
 int64_t ts_scan_ws_ints(int32_t n) {
     return n <= 0 ? 1 : (int64_t)((n + kScanBlock - 1) / kScanBlock);
@@ -772,7 +785,7 @@ int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
 int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float* splats,
                  const ts_camera* cam, int32_t* bin_ws, void* stream) {
     if (n < 0 || !cam || !bin_ws) return TS_E_BADARG;
-    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    const int nt = ts_num_tiles(cam);
     if (nt <= 0) return 0;
     if (n > 0 && (!xys || !radii)) return TS_E_BADARG;
     const int chunks = bin_num_chunks(n);
@@ -817,7 +830,7 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!xys || !radii || !bin_ws || !bucket_ids) return TS_E_BADARG;
-    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    const int nt = ts_num_tiles(cam);
     if (nt <= 0) return 0;
     const int chunks = bin_num_chunks(n);
     const int chunk = (n + chunks - 1) / chunks;

@@ -23,9 +23,10 @@ namespace {
 inline bool bad(const ts_frame* f) {
     return !f || f->n < 0 || (f->channels != 3 && f->channels != 4) || f->num_bases < 1;
 }
-inline int num_tiles(const ts_frame* f) { return f->cam.tile_rows * f->cam.tile_bounds_x; }
+inline int num_tiles(const ts_frame* f) { return ts_num_tiles(&f->cam); }
 inline int raster_flags(const ts_frame* f) {
-    return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0);
+    return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
+           ((f->flags & TS_FRAME_NARROW_WAVES) ? TS_RASTER_NARROW_WAVES : 0);
 }
 }  // namespace
 
@@ -76,7 +77,7 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
 
 int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
-    TS_TRY(ts_raster_bwd(f->channels, (f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0, f->num_intersects,
+    TS_TRY(ts_raster_bwd(f->channels, raster_flags(f) & ~TS_RASTER_CLAMP_RGB, f->num_intersects,
                          &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background, f->final_Ts,
                          f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags, stream));
     return ts_reduce_partials(f->n, f->channels,

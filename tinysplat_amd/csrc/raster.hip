@@ -105,7 +105,7 @@ __device__ __forceinline__ int xcd_tile_group(int num_groups) {
 }
 
 struct Staged {          // what a lane derives from the Gaussian it gathered
-    int mask;            // bit k set: the alpha >= 1/255 level set may reach 8x8 block k of the tile
+    int mask;            // bit k set: the alpha >= 1/255 level set may reach 8x8 block k of the tile (bit NB: see below)
     float gx, gy, hA, B, hC, lo;   // conic and opacity in the log2 domain
 };
 
@@ -126,11 +126,20 @@ __device__ __forceinline__ bool mask_rect(unsigned long long m, int& xmin, int& 
     return true;
 }
 
-// gather + exact cull against the four 8x8 pixel blocks of the tile (block k: bx = k&1, by = k>>1).
+// Tile shapes.  NBX = 8x8 blocks per tile row: 2 -> the 16x16 tile of gsplat's lists (four blocks, four
+// pixels per lane); 4 -> a WIDE 32x16 tile (eight blocks, eight pixels per lane) made of two
+// horizontally adjacent 16x16 tiles whose lists were binned as one (ts_camera.wide_tiles).  A Gaussian
+// that reaches both halves is then listed, staged, reduced over the wave and written as a gradient row
+// ONCE instead of twice: on the random scenes the wide lists hold 0.73x the pairs, and the per-entry
+// cost (the cross-lane reduction of the backward pass above all) shrinks with them, while the number
+// of block bodies - the per-pixel work - is unchanged.  Block k sits at (bx, by) = (k % NBX, k / NBX).
+//
+// gather + exact cull against the NB 8x8 pixel blocks of the tile.
 // rects[k] = sample-position bounding rectangle of the pixels of block k that still matter (all of
 // the block at first; it shrinks as pixels saturate in the forward pass / covers only the pixels
 // whose lists have started in the backward pass), kept in LDS so that the rolled loop can index it.
 // blocks = bit mask of the blocks whose rectangle is non-empty.
+template <int NB>
 __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const float4 q1,
                                               const float4* __restrict__ rects, int blocks) {
     Staged s;
@@ -141,7 +150,7 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
     s.hC = 0.5f * kLog2e * Cc;
     s.lo = __log2f(op);
     s.mask = 0;
-    // bit 4 ("general"): the per-pixel code must test sigma >= 0 and apply the 0.999 clamp.  For a
+    // bit NB ("general"): the per-pixel code must test sigma >= 0 and apply the 0.999 clamp.  For a
     // positive-definite conic and opacity <= 0.99 neither can trigger (sigma >= 0 up to rounding,
     // alpha = opacity * exp(-sigma) <= opacity), and the kernels take a leaner wave-uniform path.
     const bool general = !(s.hA > 0.0f && s.hC > 0.0f && 4.0f * s.hA * s.hC > s.B * s.B && op <= 0.99f);
@@ -151,7 +160,7 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
             if (s.hA > 0.0f && s.hC > 0.0f) {
                 const float inv2A = 0.5f / s.hA, inv2C = 0.5f / s.hC;
 #pragma unroll 1
-                for (int k = 0; k < 4; ++k) {           // rolled: runs once per 64 entries, keeps VGPRs low
+                for (int k = 0; k < NB; ++k) {          // rolled: runs once per 64 entries, keeps VGPRs low
                     if (!(blocks & (1 << k))) continue;
                     const float4 r = rects[k];          // {x0, x1, y0, y1}, wave-uniform
                     if (ts::rect_may_contribute(s.hA, s.B, s.hC, inv2A, inv2C, tau, s.gx, s.gy, r.x, r.y, r.z,
@@ -161,7 +170,7 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
             } else {
                 s.mask = blocks;                        // not a PSD conic: no geometric cull
             }
-            if (s.mask != 0 && general) s.mask |= 16;
+            if (s.mask != 0 && general) s.mask |= (1 << NB);
         }
     }
     return s;
@@ -169,22 +178,34 @@ __device__ __forceinline__ Staged stage_splat(bool have, const float4 q0, const 
 
 // Writes rects[k] for the pixels selected by `sel[k]` (one bool per lane and block) and returns the
 // mask of non-empty blocks.  Lane 0 stores; callers fence before reading.
-__device__ __forceinline__ int update_rects(const bool sel[4], float X0, float Y0, float4* rects,
+template <int NBX>
+__device__ __forceinline__ int update_rects(const bool (&sel)[2 * NBX], float X0, float Y0, float4* rects,
                                             int lane) {
     int blocks = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2 * NBX; ++k) {
         const unsigned long long m = __ballot(sel[k]);
         int xmin, xmax, ymin, ymax;
         if (mask_rect(m, xmin, xmax, ymin, ymax)) {
             blocks |= (1 << k);
-            const float bx = X0 + (float)(8 * (k & 1)), by = Y0 + (float)(8 * (k >> 1));
+            const float bx = X0 + (float)(8 * (k % NBX)), by = Y0 + (float)(8 * (k / NBX));
             if (lane == 0)
                 rects[k] = make_float4(bx + (float)xmin, bx + (float)xmax, by + (float)ymin,
                                        by + (float)ymax);
         }
     }
     return blocks;
+}
+
+// Blocks of a wide tile a Gaussian may be composited into: gsplat lists a Gaussian in the 16x16 tiles
+// of its tile box only, so a half of the wide tile that lies outside the box [minx, minx + w) must not
+// see it even where its level set reaches in (record: bbox_w | bbox_minx << 16).  Bit NB is kept.
+// WL (16x16 waves reading WIDE lists): the wave's tile column tx must itself lie in the box.
+template <int NBX, bool WL>
+__device__ __forceinline__ int bbox_blocks(int wm, int tx) {
+    const int minx = wm >> 16, w = wm & 0xffff;
+    if (NBX == 2) return (!WL || (tx >= minx && tx < minx + w)) ? ~0 : 0;
+    return ((2 * tx >= minx) ? 0x33 : 0) | ((2 * tx + 1 < minx + w) ? 0xCC : 0) | (1 << (2 * NBX));
 }
 
 using mask64 = unsigned long long;
@@ -199,10 +220,10 @@ using mask64 = unsigned long long;
 // and for finished pixels, and makes the weights telescope (sum of vis = 1 - T_final exactly).
 // GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
 // positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
-template <int CH, bool GENERAL>
-__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[2],
-                                          const float (&fpy)[2], float (&T)[4], int (&fidx)[4],
-                                          float (&acc)[4][CH]) {
+template <int CH, bool GENERAL, int NBX>
+__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
+                                          const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
+                                          float (&acc)[2 * NBX][CH]) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
@@ -213,10 +234,10 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
-            const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k & 1], r0.y - fpy[k >> 1]);
+            const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k % NBX], r0.y - fpy[k / NBX]);
             float a = __builtin_amdgcn_exp2f(-sgl);
             bool ok = a >= ts::kAlphaMin;
             if (GENERAL) {
@@ -244,40 +265,47 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 // Same list, same arithmetic per pixel; used when a launch has fewer tiles than the GPU has SIMDs (a
 // tile-row stripe of a multi-GPU frame, a small image), where one wave per tile leaves the vector ALUs
 // without a second wave to switch to and the launch takes as long as the longest tile list.
-template <int CH, bool SPLIT>
+// WL (NBX == 2 only): the lists are those of wide tiles (ts_camera.wide_tiles) but every 16x16 tile
+// keeps a wave of its own, which walks the list of the wide tile it belongs to and drops the Gaussians
+// whose tile box does not contain it - binning and sorting at the wide tiles' price, compositing at the
+// register footprint of four pixels per lane.
+template <int CH, bool SPLIT, int NBX, bool WL>
 __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
     const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ final_Ts, int* __restrict__ final_index, const int clamp_rgb,
     unsigned char* __restrict__ clamp_mask) {
+    constexpr int NB = 2 * NBX;
     __shared__ float4 lds_all[kWaves][64 * 3];
-    __shared__ float4 rect_all[kWaves][4];
+    __shared__ float4 rect_all[kWaves][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int units = SPLIT ? 4 * num_tiles : num_tiles;
+    const int units = SPLIT ? NB * num_tiles : num_tiles;
     const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
     if (unit >= units) return;
-    const int tile = SPLIT ? unit >> 2 : unit;
-    const int only = SPLIT ? unit & 3 : -1;
+    const int tile = SPLIT ? unit / NB : unit;
+    const int only = SPLIT ? unit % NB : -1;
     float4* lds = lds_all[wave];
     float4* rects = rect_all[wave];
-    const int tbx = cam.tile_bounds_x;
+    const int tbx = NBX == 2 ? cam.tile_bounds_x : (cam.tile_bounds_x + 1) >> 1;     // tiles of this shape per row
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
-    const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
-    // sample positions of the lane's pixel in the left / right and the upper / lower blocks
-    const float fpx[2] = {(float)px0 + ts::kPixOff, (float)(px0 + 8) + ts::kPixOff};
+    const int px0 = tx * (8 * NBX) + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    // sample positions of the lane's pixel in the block columns / the upper and lower block row
+    float fpx[NBX];
+#pragma unroll
+    for (int c = 0; c < NBX; ++c) fpx[c] = (float)(px0 + 8 * c) + ts::kPixOff;
     const float fpy[2] = {(float)py0 + ts::kPixOff, (float)(py0 + 8) + ts::kPixOff};
-    const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
+    const float X0 = (float)(tx * (8 * NBX)) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
 
     // T > 0: transmittance of an unfinished pixel; T < 0: finished or outside, final value |T|
-    float T[4], acc[4][CH];
-    int fidx[4];
-    bool inside[4];
+    float T[NB], acc[NB][CH];
+    int fidx[NB];
+    bool inside[NB];
     int live = 0;                                   // blocks that still have unfinished pixels
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H) && (!SPLIT || k == only);
+    for (int k = 0; k < NB; ++k) {
+        inside[k] = (px0 + 8 * (k % NBX) < W) && (py0 + 8 * (k / NBX) < H) && (!SPLIT || k == only);
         T[k] = inside[k] ? 1.0f : -1.0f;
         fidx[k] = 0;
 #pragma unroll
@@ -285,7 +313,8 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         if (__any(inside[k])) live |= (1 << k);
     }
 
-    const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
+    const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
 
     // Software pipeline over 64-entry chunks: the id of chunk c+2 and the packed record of chunk
     // c+1 are in flight while chunk c is composited (two dependent gathers = ~2 us of latency
@@ -310,15 +339,16 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         if (i + 128 < range.y) id_next = ids_sorted[i + 128];
         {   // rectangle of the still-unfinished pixels of each block: saturated pixels need no more
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
-            bool sel[4];
+            bool sel[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sel[k] = T[k] > 0.0f;
-            live = update_rects(sel, X0, Y0, rects, lane);
+            for (int k = 0; k < NB; ++k) sel[k] = T[k] > 0.0f;
+            live = update_rects<NBX>(sel, X0, Y0, rects, lane);
             TS_WAVE_SYNC();
             if (live == 0) break;
         }
-        const Staged s = stage_splat(have, q0, q1, rects, live);
-        const bool keep = s.mask != 0;
+        Staged s = stage_splat<NB>(have, q0, q1, rects, live);
+        s.mask &= bbox_blocks<NBX, WL>(__float_as_int(q2.w), tx);
+        const bool keep = (s.mask & ((1 << NB) - 1)) != 0;
         const unsigned long long mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
@@ -328,12 +358,12 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
         TS_WAVE_SYNC();
-        // bit 4 of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
+        // bit NB of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
         // once per chunk so that the common case runs a loop without those tests
-        if (__ballot(keep && (s.mask & 16)) != 0ull)
-            fwd_chunk<CH, true>(lds, cnt, fpx, fpy, T, fidx, acc);
+        if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
+            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc);
         else
-            fwd_chunk<CH, false>(lds, cnt, fpx, fpy, T, fidx, acc);
+            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc);
         TS_WAVE_SYNC();
     }
 
@@ -342,9 +372,9 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     for (int c = 0; c < CH; ++c) bg[c] = background[c];
     const int row_off = cam.tile_row0 * 16;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NB; ++k) {
         if (!inside[k]) continue;
-        const size_t pix = (size_t)(py0 + 8 * (k >> 1) - row_off) * W + (px0 + 8 * (k & 1));
+        const size_t pix = (size_t)(py0 + 8 * (k / NBX) - row_off) * W + (px0 + 8 * (k % NBX));
         const float Tf = __builtin_fabsf(T[k]);
         if (final_Ts) {             // null in the forward-only (viewer) mode: nothing is kept for backward
             final_Ts[pix] = Tf;
@@ -436,10 +466,10 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
 //   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
 // Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
 // (ra = 1, fac = 0, v_sig = 0) and changes nothing.
-template <int CH, bool GENERAL>
-__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[2],
-                                          const float (&fpy)[2], float (&T)[4], float (&R)[4],
-                                          const float (&vo)[4][CH], const int (&fidx)[4],
+template <int CH, bool GENERAL, int NBX>
+__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
+                                          const float (&fpy)[2], float (&T)[2 * NBX], float (&R)[2 * NBX],
+                                          const float (&vo)[2 * NBX][CH], const int (&fidx)[2 * NBX],
                                           float (&acc)[6 + CH], long long num_isects,
                                           float* __restrict__ partials,
                                           unsigned char* __restrict__ row_flags, int lane) {
@@ -458,9 +488,9 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
 
         int any = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
-            const float dx = r0.x - fpx[k & 1], dy = r0.y - fpy[k >> 1];
+            const float dx = r0.x - fpx[k % NBX], dy = r0.y - fpy[k / NBX];
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, dx, dy);
             const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
             float a = araw;
@@ -513,7 +543,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
     }
 }
 
-template <int CH, bool SPLIT>
+template <int CH, bool SPLIT, int NBX, bool WL>
 __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
@@ -522,25 +552,29 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
     const unsigned char* __restrict__ clamp_mask,
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
+    constexpr int NB = 2 * NBX;
     __shared__ float4 lds_all[kWaves][64 * 4];
-    __shared__ float4 rect_all[kWaves][4];
+    __shared__ float4 rect_all[kWaves][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int units = SPLIT ? 4 * num_tiles : num_tiles;
+    const int units = SPLIT ? NB * num_tiles : num_tiles;
     const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
     if (unit >= units) return;
-    const int tile = SPLIT ? unit >> 2 : unit;
-    const int only = SPLIT ? unit & 3 : -1;       // SPLIT: this wave owns block `only`, row slot*4 + only
+    const int tile = SPLIT ? unit / NB : unit;
+    const int only = SPLIT ? unit % NB : -1;      // SPLIT: this wave owns block `only`, row slot*NB + only
     float4* rects = rect_all[wave];
-    const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
+    const int tbx = NBX == 2 ? cam.tile_bounds_x : (cam.tile_bounds_x + 1) >> 1;
+    const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
+    const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
     if (range.y <= range.x) return;
     float4* lds = lds_all[wave];
-    const int tbx = cam.tile_bounds_x;
-    const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
-    const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
-    // sample positions of the lane's pixel in the left / right and the upper / lower blocks
-    const float fpx[2] = {(float)px0 + ts::kPixOff, (float)(px0 + 8) + ts::kPixOff};
+    const int px0 = tx * (8 * NBX) + (lane & 7), py0 = ty * 16 + (lane >> 3);
+    // sample positions of the lane's pixel in the block columns / the upper and lower block row
+    float fpx[NBX];
+#pragma unroll
+    for (int c = 0; c < NBX; ++c) fpx[c] = (float)(px0 + 8 * c) + ts::kPixOff;
     const float fpy[2] = {(float)py0 + ts::kPixOff, (float)(py0 + 8) + ts::kPixOff};
-    const float X0 = (float)(tx * 16) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
+    const float X0 = (float)(tx * (8 * NBX)) + ts::kPixOff, Y0 = (float)(ty * 16) + ts::kPixOff;
     const int W = cam.img_width, H = cam.img_height;
     const int row_off = cam.tile_row0 * 16;
 
@@ -550,12 +584,12 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 
     // per pixel: T = transmittance behind the Gaussian being replayed; R = T_final*(v_alpha - bg.v_out)
     // - sum over the Gaussians already replayed of fac * (colour . v_out)   (see the inner loop)
-    float T[4], R[4], vo[4][CH];
-    int fidx[4], bmax[4];
+    float T[NB], R[NB], vo[NB][CH];
+    int fidx[NB], bmax[NB];
     int fmax = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
+    for (int k = 0; k < NB; ++k) {
+        const int px = px0 + 8 * (k % NBX), py = py0 + 8 * (k / NBX);
         const bool inside = (px < W) && (py < H) && (!SPLIT || k == only);
         fidx[k] = -1;
         T[k] = 1.0f;
@@ -581,7 +615,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     }
     const int last = min(range.y - 1, fmax);
 
-    // per-lane sums over its (up to) four pixels for the Gaussian being replayed, updated in place
+    // per-lane sums over its (up to) NB pixels for the Gaussian being replayed, updated in place
     // by the block bodies and zeroed after each row is written:
     // {S v, S v dx, S v dy, S v dx^2, S v dx dy, S v dy^2, v_c0, v_c1, ...}
     float acc[6 + CH];
@@ -609,35 +643,44 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
         if (i - 128 >= range.x) id_next = ids_sorted[i - 128];
         int blocks;
         {   // rectangle of the pixels whose forward list reaches into this chunk (fidx >= chunk low)
-            bool sel[4];
+            bool sel[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sel[k] = fidx[k] >= hi - 63;
-            blocks = update_rects(sel, X0, Y0, rects, lane);
+            for (int k = 0; k < NB; ++k) sel[k] = fidx[k] >= hi - 63;
+            blocks = update_rects<NBX>(sel, X0, Y0, rects, lane);
             TS_WAVE_SYNC();
         }
-        Staged s = stage_splat(have, q0, q1, rects, blocks);
+        Staged s = stage_splat<NB>(have, q0, q1, rects, blocks);
+        s.mask &= bbox_blocks<NBX, WL>(__float_as_int(q2.w), tx);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NB; ++k)
             if (i > bmax[k]) s.mask &= ~(1 << k);   // nothing in block k got this far in forward
-        const bool keep = s.mask != 0;
+        const bool keep = (s.mask & ((1 << NB) - 1)) != 0;
         const unsigned long long mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
             const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            int slot = __float_as_int(q2.z) + ty * __float_as_int(q2.w) + tx;
-            if (SPLIT) slot = 4 * slot + only;       // one partial row per (tile, Gaussian, block)
+            // row of this (tile, Gaussian): the slot gsplat's count reserves for the 16x16 tile (column
+            // tx16, row ty) of the Gaussian's tile box; a wide tile uses the slot of its left half, or of
+            // its right half where the box starts there (record: bbox_w | bbox_minx << 16)
+            // SPLIT: one row per (16x16 tile, Gaussian, block of that tile) - block `only` of a wide tile
+            // lies in its half (only % NBX) >> 1 and is block lb of that 16x16 tile
+            const int wm = __float_as_int(q2.w);
+            const int half = SPLIT ? ((only % NBX) >> 1) : 0;
+            const int tx16 = NBX == 2 ? tx : (SPLIT ? 2 * tx + half : max(2 * tx, wm >> 16));
+            int slot = __float_as_int(q2.z) + ty * (wm & 0xffff) + tx16;
+            if (SPLIT) slot = 4 * slot + (NBX == 2 ? only : ((only % NBX) & 1) + 2 * (only / NBX));
             lds[4 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
             lds[4 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
             lds[4 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(slot));
             lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
         TS_WAVE_SYNC();
-        if (__ballot(keep && (s.mask & 16)) != 0ull)
-            bwd_chunk<CH, true>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
-                                row_flags, lane);
+        if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
+            bwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
+                                     row_flags, lane);
         else
-            bwd_chunk<CH, false>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
-                                 row_flags, lane);
+            bwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
+                                      row_flags, lane);
         TS_WAVE_SYNC();
     }
 }
@@ -710,21 +753,30 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const i
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
                   void* stream) {
     if (!cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
-    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    const bool narrow = cam->wide_tiles != 0 && (flags & TS_RASTER_NARROW_WAVES) != 0;   // 16x16 waves, wide lists
+    const int nt = narrow ? cam->tile_rows * cam->tile_bounds_x : ts_num_tiles(cam);
     if (nt <= 0) return 0;
     if (!tile_bins || !background || !out_img || (!final_Ts != !final_index)) return TS_E_BADARG;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
-    const int units = split ? 4 * nt : nt;
+    const bool wide = cam->wide_tiles != 0 && !narrow;
+    const int units = split ? (wide ? 8 : 4) * nt : nt;
     const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-#define TS_LAUNCH_FWD(C, S)                                                                        \
-    hipLaunchKernelGGL((raster_fwd_kernel<C, S>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,       \
+#define TS_LAUNCH_FWD(C, S, X, L)                                                                  \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,           \
                        final_index, clamp, clamp ? clamp_mask : nullptr)
-    if (channels == 3) { if (split) TS_LAUNCH_FWD(3, true); else TS_LAUNCH_FWD(3, false); }
-    else { if (split) TS_LAUNCH_FWD(4, true); else TS_LAUNCH_FWD(4, false); }
+#define TS_LAUNCH_FWD_X(C, S)                                                                      \
+    do {                                                                                           \
+        if (wide) TS_LAUNCH_FWD(C, S, 4, false);                                                   \
+        else if (narrow) TS_LAUNCH_FWD(C, S, 2, true);                                             \
+        else TS_LAUNCH_FWD(C, S, 2, false);                                                        \
+    } while (0)
+    if (channels == 3) { if (split) TS_LAUNCH_FWD_X(3, true); else TS_LAUNCH_FWD_X(3, false); }
+    else { if (split) TS_LAUNCH_FWD_X(4, true); else TS_LAUNCH_FWD_X(4, false); }
+#undef TS_LAUNCH_FWD_X
 #undef TS_LAUNCH_FWD
     return launch_status();
 }
@@ -735,24 +787,33 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
                   const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
                   float* partials, uint8_t* row_flags, void* stream) {
     if (!cam || (channels != 3 && channels != 4) || num_intersects < 0) return TS_E_BADARG;
-    const int nt = cam->tile_rows * cam->tile_bounds_x;
+    const bool narrow = cam->wide_tiles != 0 && (flags & TS_RASTER_NARROW_WAVES) != 0;
+    const int nt = narrow ? cam->tile_rows * cam->tile_bounds_x : ts_num_tiles(cam);
     if (nt <= 0 || num_intersects == 0) return 0;
     if (!tile_bins || !gaussian_ids_sorted || !splats || !background || !final_Ts || !final_index ||
         !v_out_img || !partials || !row_flags)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    const bool wide = cam->wide_tiles != 0 && !narrow;
     hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * (split ? 4 : 1), s);
     if (e != hipSuccess) return (int)e;
-    const int units = split ? 4 * nt : nt;
+    const int units = split ? (wide ? 8 : 4) * nt : nt;
     const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
-#define TS_LAUNCH_BWD(C, S)                                                                        \
-    hipLaunchKernelGGL((raster_bwd_kernel<C, S>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,       \
+#define TS_LAUNCH_BWD(C, S, X, L)                                                                  \
+    hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp, background,  \
                        final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials, row_flags)
-    if (channels == 3) { if (split) TS_LAUNCH_BWD(3, true); else TS_LAUNCH_BWD(3, false); }
-    else { if (split) TS_LAUNCH_BWD(4, true); else TS_LAUNCH_BWD(4, false); }
+#define TS_LAUNCH_BWD_X(C, S)                                                                      \
+    do {                                                                                           \
+        if (wide) TS_LAUNCH_BWD(C, S, 4, false);                                                   \
+        else if (narrow) TS_LAUNCH_BWD(C, S, 2, true);                                             \
+        else TS_LAUNCH_BWD(C, S, 2, false);                                                        \
+    } while (0)
+    if (channels == 3) { if (split) TS_LAUNCH_BWD_X(3, true); else TS_LAUNCH_BWD_X(3, false); }
+    else { if (split) TS_LAUNCH_BWD_X(4, true); else TS_LAUNCH_BWD_X(4, false); }
+#undef TS_LAUNCH_BWD_X
 #undef TS_LAUNCH_BWD
     return launch_status();
 }

@@ -41,6 +41,21 @@ TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 # one wave per tile such launches cannot hide any latency.  0 disables.
 SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 
+# WIDE LISTS: the frame path bins, scatters and sorts on 32x16 tiles - two horizontally adjacent 16x16 tiles
+# as one list (ts_camera.wide_tiles; 0.73x the list entries on the random scenes, longer lists for the sort
+# networks) - and composites with ONE WAVE PER 16x16 TILE as before, each wave walking the list of the wide
+# tile it lies in and dropping the Gaussians whose tile box does not contain it (TS_RASTER_NARROW_WAVES).
+# Image, depth and every transmittance decision are bitwise those of 16x16 lists, gradients agree to
+# rounding (tests/test_gpu_parity.py::test_wide_tiles_change_no_pixel).  Measured on MI355X (mode 0 -> 2):
+# config 5 (5 M, 4K) 5.71 -> 5.01 ms, 5.03 -> 4.33 ms in Morton order (sort 0.94 -> 0.55, scatter 0.88 -> 0.70,
+# count 0.23 -> 0.13 ms; compositing +1 %); config 3 1.316 -> 1.305 ms (sort 79 -> 64 us, scatter 64 -> 48 us,
+# offsets 27 -> 19 us against raster_bwd 545 -> 566 us for the longer lists it stages).
+# Mode 1 also gives each wave the whole wide tile (eight pixels per lane: the "super-tile" mapping, one
+# butterfly reduction and one gradient row per Gaussian and wide tile): built, bit-identical, and slower -
+# raster_fwd 0.25 -> 0.39 ms, raster_bwd 0.55 -> 0.71 ms on config 3, because 150-170 VGPRs leave 3 waves per
+# SIMD instead of 4-5.  TS_WIDE_TILES = 0 | 1 | 2; the drop-in op keeps gsplat's 16x16 lists.
+WIDE_TILES = int(os.environ.get("TS_WIDE_TILES", "2"))
+
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
 
@@ -84,7 +99,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     opacities, colors_dc, colors_rest = _f32c(opacities), _f32c(colors_dc), _f32c(colors_rest)
     view34, projview, origin = _f32c(view34), _f32c(projview), _f32c(origin)
     w, h = int(width), int(height)
-    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
+    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows, wide_tiles=bool(WIDE_TILES))
     ch = 4 if with_depth else 3
     if with_depth:          # channel 3 is composited over background[0], as the reference's depth pass (:86)
         key = (background.data_ptr(), background._version, dev.index)
@@ -103,9 +118,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.cam, F.n, F.nb, F.ch, F.w, F.h, F.keep = cam, n, nb, ch, w, h, keep
     F.inputs = (means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin)
     F.bg = bg
-    num_tiles = cam.tile_rows * cam.tile_bounds_x
+    num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))            # lists of this launch (wide or 16x16 tiles)
     F.num_tiles = num_tiles
-    F.split = 0 < num_tiles <= SPLIT_BLOCKS_BELOW
+    F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
     _mark("fwd:inputs checked")
@@ -143,7 +158,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         host, event = _total_slot(dev)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
-        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0)
+        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if int(WIDE_TILES) == 2 else 0)
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -216,26 +231,26 @@ def _steps_prepare(lib, fr, s):
           fr.opacities, fr.cum_tiles_hit, fr.cam, fr.depths if fr.channels == 4 else None, fr.splats, s)
     tight = fr.splats if fr.flags & 1 else None
     _call("ts_bin_count", lib.ts_bin_count, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws, s)
-    _call("ts_tile_offsets", lib.ts_tile_offsets, fr.n, fr.cam.tile_rows * fr.cam.tile_bounds_x, fr.bin_ws,
+    _call("ts_tile_offsets", lib.ts_tile_offsets, fr.n, int(lib.ts_num_tiles(ctypes.byref(fr.cam))), fr.bin_ws,
           fr.tile_bins, s)
 
 
 def _steps_composite(lib, fr, s):
     tight = fr.splats if fr.flags & 1 else None
-    nt = fr.cam.tile_rows * fr.cam.tile_bounds_x
+    nt = int(lib.ts_num_tiles(ctypes.byref(fr.cam)))
     if fr.num_intersects > 0:
         _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
               fr.bucket_ids, s)
         _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
               fr.gaussian_ids_sorted, fr.bin_ws, s)
-    _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0), fr.cam, fr.tile_bins,
+    _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam, fr.tile_bins,
           fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.final_Ts, fr.final_index,
           fr.clamp_mask, s)
 
 
 def _steps_bwd_composite(lib, fr, s):
     split = 4 if fr.flags & 2 else 0
-    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split, fr.num_intersects, fr.cam, fr.tile_bins,
+    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split | (fr.flags & 8), fr.num_intersects, fr.cam, fr.tile_bins,
           fr.gaussian_ids_sorted, fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None,
           fr.clamp_mask, fr.partials, fr.row_flags, s)
     _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split, fr.num_tiles_hit,

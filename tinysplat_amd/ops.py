@@ -126,7 +126,8 @@ def _stream(dev: torch.device) -> int:
 
 
 def _camera(fx, fy, cx, cy, img_height, img_width, tile_bounds, glob_scale=1.0,
-            clip_thresh=CLIP_THRESH, tile_rows: Optional[Tuple[int, int]] = None) -> TsCamera:
+            clip_thresh=CLIP_THRESH, tile_rows: Optional[Tuple[int, int]] = None,
+            wide_tiles: bool = False) -> TsCamera:
     tbx, tby = int(tile_bounds[0]), int(tile_bounds[1])
     if tile_rows is None:
         row0, rows = 0, tby
@@ -135,7 +136,7 @@ def _camera(fx, fy, cx, cy, img_height, img_width, tile_bounds, glob_scale=1.0,
         if row0 < 0 or rows < 0 or row0 + rows > tby:
             raise ValueError(f"tile_rows {tile_rows} outside [0, {tby}]")
     return TsCamera(float(fx), float(fy), float(cx), float(cy), int(img_width), int(img_height),
-                    tbx, tby, row0, rows, float(glob_scale), float(clip_thresh))
+                    tbx, tby, row0, rows, float(glob_scale), float(clip_thresh), 1 if wide_tiles else 0, 0)
 
 
 def _tile_bounds(img_height: int, img_width: int) -> Tuple[int, int, int]:

@@ -602,7 +602,8 @@ def main():
                        "scale_mult": args.scale_mult,
                        "tile_lists": {0: "16x16 (gsplat's)", 1: "32x16 lists, 32x16 waves",
                                       2: "32x16 lists (pairs of 16x16 tiles), one wave per 16x16 tile"}.get(
-                                          int(_frame.WIDE_TILES), str(_frame.WIDE_TILES)),
+                                          _frame._list_mode(dev.index, tiles), "?")
+                                      + (" (auto)" if _frame.WIDE_TILES == "auto" else ""),
                        "gaussian_order": "Morton curve of the means (--spatial-sort)" if args.spatial_sort
                                          else "as generated (i.i.d.)",
                        **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "

@@ -32,6 +32,16 @@ class HmCamera(ctypes.Structure):
                 ("rows", ctypes.c_int), ("gs", ctypes.c_float), ("clip", ctypes.c_float)]
 
 
+@pytest.fixture(autouse=True)
+def _fresh_list_mode_history():
+    """frame.py picks its tile-list mode from the previous frame's pairs per tile: no carry-over between tests."""
+    import sys
+    fr = sys.modules.get("tinysplat_amd.frame")
+    if fr is not None:
+        fr._pairs_per_tile.clear()
+    yield
+
+
 @pytest.fixture(scope="session")
 def hostmath():
     """g++ build of tests/hostmath/hostmath.cpp: the kernels' math header compiled for the host."""

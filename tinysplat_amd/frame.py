@@ -53,8 +53,25 @@ SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 # Mode 1 also gives each wave the whole wide tile (eight pixels per lane: the "super-tile" mapping, one
 # butterfly reduction and one gradient row per Gaussian and wide tile): built, bit-identical, and slower -
 # raster_fwd 0.25 -> 0.39 ms, raster_bwd 0.55 -> 0.71 ms on config 3, because 150-170 VGPRs leave 3 waves per
-# SIMD instead of 4-5.  TS_WIDE_TILES = 0 | 1 | 2; the drop-in op keeps gsplat's 16x16 lists.
-WIDE_TILES = int(os.environ.get("TS_WIDE_TILES", "2"))
+# SIMD instead of 4-5.  The drop-in op keeps gsplat's 16x16 lists.
+# TS_WIDE_TILES = 0 | 1 | 2 | auto (default): mode 2 where the lists are long - the previous frame on the
+# device averaged >= WIDE_LISTS_FROM bounding-box pairs per 16x16 tile (config 5: 2 490; config 3: 766, where
+# the two modes are within 1 % of each other and mode 0 keeps the compositing kernels' own time lowest) -
+# mode 0 otherwise; a first frame goes by its tile count (4K-class frames start wide).  Modes 0 and 2 run the
+# same per-tile arithmetic on the same Gaussians in the same order, so switching never changes a result.
+_wt = os.environ.get("TS_WIDE_TILES", "auto")
+WIDE_TILES = _wt if _wt == "auto" else int(_wt)
+WIDE_LISTS_FROM = int(os.environ.get("TS_WIDE_LISTS_FROM", "1000"))
+_pairs_per_tile = {}    # device index -> bounding-box pairs per 16x16 tile of the most recent frame
+
+
+def _list_mode(dev_index: int, tiles16: int) -> int:
+    if WIDE_TILES != "auto":
+        return int(WIDE_TILES)
+    prev = _pairs_per_tile.get(dev_index)
+    if prev is None:
+        return 2 if tiles16 >= 20000 else 0
+    return 2 if prev >= WIDE_LISTS_FROM else 0
 
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
@@ -99,7 +116,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     opacities, colors_dc, colors_rest = _f32c(opacities), _f32c(colors_dc), _f32c(colors_rest)
     view34, projview, origin = _f32c(view34), _f32c(projview), _f32c(origin)
     w, h = int(width), int(height)
-    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows, wide_tiles=bool(WIDE_TILES))
+    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
+    mode = _list_mode(dev.index, cam.tile_rows * cam.tile_bounds_x)
+    cam.wide_tiles = 1 if mode else 0
     ch = 4 if with_depth else 3
     if with_depth:          # channel 3 is composited over background[0], as the reference's depth pass (:86)
         key = (background.data_ptr(), background._version, dev.index)
@@ -158,7 +177,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         host, event = _total_slot(dev)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
-        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if int(WIDE_TILES) == 2 else 0)
+        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0)
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -196,6 +215,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
                                     "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
         _mark("fwd:waited for count")
         F.total = total
+        _pairs_per_tile[dev.index] = total / max(1, cam.tile_rows * cam.tile_bounds_x)
         cap = (max(total, 1) + 63) & ~63
         F.bucket_ids = torch.empty((2 * cap,), **i32)             # bucket_ids | gaussian_ids_sorted
         F.ids = F.bucket_ids[cap:cap + total]

@@ -17,13 +17,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float 
     unsigned long long sm = threadIdx.x & 1 ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull;
     sm = __builtin_amdgcn_readfirstlane((unsigned)sm) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(sm >> 32)) << 32);
     for (int it = 0; it < iters; ++it) {
+        if (MODE == 5) asm volatile("s_mov_b64 vcc, %0" : : "s"(sm) : "vcc");       // one scalar move per 16 selects
 #define OP(i)                                                                                                   \
         if (MODE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));                    \
         else if (MODE == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(s0), "v"(c));              \
         else if (MODE == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));                           \
         else if (MODE == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));                           \
         else if (MODE == 4) asm volatile("v_add_f32 %0, 0x3f800347, %0" : "+v"(a[i]));                            \
-        else if (MODE == 5) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));                  \
+        else if (MODE == 5) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));              \
         else if (MODE == 6) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "s"(sm));          \
         else if (MODE == 7) asm volatile("v_cmp_le_f32 vcc, %0, %1" : : "v"(a[i]), "v"(m) : "vcc");               \
         else if (MODE == 8) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));                                        \

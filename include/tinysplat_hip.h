@@ -109,7 +109,13 @@ int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
  * num_bases == 1. */
 int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
                      const float* origin, const float* colors_dc, const float* colors_rest,
-                     float* colors, uint8_t* clamp_mask, void* stream);
+                     float* colors, uint8_t* clamp_mask, const int32_t* live, void* stream);
+/* live: NULL, or num_tiles_hit of a tile-row stripe - only Gaussians with live[i] != 0 are evaluated (each
+ * reads its own coefficient row) and the colours / masks of the others are left unwritten: the colour stage
+ * of one rank of a multi-GPU frame touches the 1/G of the Gaussians that its stripe lists.
+ * ts_sh_colors_bwd: clamp_mask may be NULL (all channels pass) when the mask was already applied by
+ * ts_reduce_partials(color_mask) - the multi-GPU order, where the 2-D gradients are summed over ranks
+ * between the two and a rank holds masks for its own stripe's Gaussians only. */
 int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
                      const float* origin, const uint8_t* clamp_mask, const float* v_colors,
                      float* v_colors_dc, float* v_colors_rest, void* stream);
@@ -209,9 +215,11 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
 int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
-                       float* v_colors, float* v_opacity, float* v_depth, void* stream);
+                       float* v_colors, float* v_opacity, float* v_depth, const uint8_t* color_mask,
+                       void* stream);
 /* v_depth: NULL, or (channels == 4) the gradient of channel 3 as its own array [n]; v_colors is then
- * [n,3] - the layout the RGB + depth frame hands to ts_sh_colors_bwd / ts_project_bwd. */
+ * [n,3] - the layout the RGB + depth frame hands to ts_sh_colors_bwd / ts_project_bwd.
+ * color_mask: NULL, or the colour stage's clamp mask: v_colors[i][c] = 0 where bit c is clear. */
 
 /* ============== whole-frame executor (the adapter's recipe, rasterize.py:26-62, in five calls) ======
  * The reference's GaussianRasterizer.__call__ enqueues ~30 small operations per frame from Python; on
@@ -234,6 +242,8 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_TIGHT 1
 #define TS_FRAME_SPLIT 2
 #define TS_FRAME_NARROW_WAVES 8        /* TS_RASTER_NARROW_WAVES for the compositing launches (cam.wide_tiles) */
+#define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
+                                          stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */
 typedef struct ts_frame {
     int32_t n, num_bases, sh_degree, channels, flags, reserved;
     ts_camera cam;

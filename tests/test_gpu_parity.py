@@ -517,6 +517,47 @@ def test_wide_tiles_change_no_pixel():
                 assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol, n, w, h, other)
 
 
+def test_stripe_sparse_stages_change_nothing():
+    """frame.STRIPE_SPARSE (TS_FRAME_STRIPE): on a tile-row stripe the colour stage evaluates only the
+    Gaussians the stripe lists and the clamp mask is applied in the row reduction instead of the colour
+    stage's backward: every output and gradient bitwise, one wave per tile and split mapping alike.
+    Colours above / below the clamp on purpose (dc ~ N(0, 1))."""
+    from tinysplat_amd import frame
+    from tinysplat_amd.rasterizer import camera_on_device
+    dev = torch.device(DEV)
+    for n, sh, w, h, rows, exact in ((80000, 2, 1920, 1080, (10, 50), True), (50000, 3, 1000, 520, (7, 19), True),
+                                     (20000, 0, 640, 360, (0, 3), True)):
+        model, cam = scene_args(n, sh, w, h, seed=71 + sh, scale_mult=2.5)
+        g = torch.Generator().manual_seed(72)
+        rows_px = min(h, 16 * rows[1]) - 16 * rows[0]
+        wr, wd = torch.rand(rows_px, w, 3, generator=g).to(DEV), torch.rand(rows_px, w, generator=g).to(DEV)
+        view, projview, origin = camera_on_device(cam, dev)
+        res = []
+        try:
+            for sparse in (False, True):
+                frame.STRIPE_SPARSE = sparse
+                md = model.to(DEV).requires_grad_(True)
+                img, xys, radii = frame.render_frame(md, view[:3, :], projview, origin, cam.f_x, cam.f_y, w, h,
+                                                     True, tile_rows=rows)
+                ((img[..., :3] * wr).sum() + (img[..., 3] * wd).sum()).backward()
+                with torch.no_grad():
+                    view_img, _, _ = frame.render_view(md, view[:3, :], projview, origin, cam.f_x, cam.f_y, w, h,
+                                                       True, tile_rows=rows)
+                assert torch.equal(view_img, img.detach())
+                res.append([img.detach(), radii, xys.grad] + [p.grad for p in md.parameters()])
+        finally:
+            frame.STRIPE_SPARSE = True
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert float(res[0][6].abs().max()) > 0            # colour gradients flow
+        for a, b in zip(res[0][2:], res[1][2:]):
+            if a.numel() == 0:
+                continue
+            if exact:
+                assert torch.equal(a, b), (n, w, h)
+            tol = 2e-6 * max(1.0, a.abs().max().item())
+            assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol, n, w, h)
+
+
 def test_frame_path_with_opaque_and_faint_gaussians_matches_oracle():
     """The adapter's fast path (one node, tight lists, split mapping at this tile count, general
     per-pixel code for opacities > 0.99) against the oracle frame incl. parameter gradients."""

@@ -64,7 +64,7 @@ SIGNATURES = {
     "ts_project_bwd": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sh_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
     "ts_sh_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
-    "ts_sh_colors_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_sh_colors_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sh_colors_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_scan_ws_ints": (c_int64, [c_int32]),
     "ts_scan_tiles": (c_int32, [c_int32, _P, _P, _P, _P]),
@@ -91,7 +91,7 @@ SIGNATURES = {
     "ts_ply_row_floats": (c_int32, [c_int32]),
     "ts_ply_pack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_ply_unpack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_frame_struct_bytes": (c_int32, []),
     "ts_frame_fwd_project": (c_int32, [_FRAME, _P]),
     "ts_frame_fwd_prepare": (c_int32, [_FRAME, _P]),

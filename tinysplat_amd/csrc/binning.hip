@@ -712,13 +712,15 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
     if (i >= n) return;
     const int r = radii[i];
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    bool listed = false;
     if (r > 0) {
         const float2 xy = reinterpret_cast<const float2*>(xys)[i];
         const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
                                             cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
         const int w = b.maxx - b.minx, h = b.maxy - b.miny;
         const int cnt = h > 0 ? w * h : 0;
-      if (cnt > 0) {       // cnt == 0: visible, but not in this stripe -> never listed, the record stays zero
+      if (cnt > 0) {       // cnt == 0: visible, but not in this stripe -> never listed, no record
+        listed = true;
         const int excl = cum_tiles_hit[i] - cnt;
         const int slot_base = excl - b.miny * w - b.minx;
         float op = opacity[i];
@@ -737,6 +739,10 @@ __global__ __launch_bounds__(kThreads) void pack_splats_kernel(
         q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w | (b.minx << 16)));
       }
     }
+    // a Gaussian that is not listed in this launch (culled, or outside the tile-row stripe) has no reader:
+    // bin_count / bin_scatter skip it on the same test, the compositing kernels see listed ids only and
+    // ts_reduce_partials reads the record of a Gaussian with num_tiles_hit > 0 only
+    if (!listed) return;
     splats[3 * (size_t)i] = q0;
     splats[3 * (size_t)i + 1] = q1;
     splats[3 * (size_t)i + 2] = q2;

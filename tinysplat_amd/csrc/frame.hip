@@ -52,7 +52,8 @@ int ts_frame_fwd_project(const ts_frame* f, void* stream) {
 int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
     if (bad(f)) return TS_E_BADARG;
     TS_TRY(ts_sh_colors_fwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->colors_dc,
-                            f->num_bases > 1 ? f->colors_rest : nullptr, f->colors, f->sh_mask, stream));
+                            f->num_bases > 1 ? f->colors_rest : nullptr, f->colors, f->sh_mask,
+                            (f->flags & TS_FRAME_STRIPE) ? f->num_tiles_hit : nullptr, stream));
     // channel 3 of an RGB + depth frame is the depth itself (rasterize.py:48-50), taken from `depths`
     TS_TRY(ts_pack_splats(f->n, f->channels, TS_RASTER_LOGIT_OPACITY, f->xys, f->radii, f->conics, f->colors,
                           f->opacities, f->cum_tiles_hit, &f->cam, f->channels == 4 ? f->depths : nullptr,
@@ -80,15 +81,18 @@ int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
     TS_TRY(ts_raster_bwd(f->channels, raster_flags(f) & ~TS_RASTER_CLAMP_RGB, f->num_intersects,
                          &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background, f->final_Ts,
                          f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags, stream));
+    const bool stripe = (f->flags & TS_FRAME_STRIPE) != 0;
     return ts_reduce_partials(f->n, f->channels,
                               TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0),
                               f->num_tiles_hit, f->cum_tiles_hit, f->partials, f->row_flags, f->splats, f->v_xy,
-                              f->v_conic, f->v_colors, f->v_opacity, f->channels == 4 ? f->v_depth : nullptr, stream);
+                              f->v_conic, f->v_colors, f->v_opacity, f->channels == 4 ? f->v_depth : nullptr,
+                              stripe ? f->sh_mask : nullptr, stream);
 }
 
 int ts_frame_bwd_params(const ts_frame* f, void* stream) {
     if (bad(f)) return TS_E_BADARG;
-    TS_TRY(ts_sh_colors_bwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->sh_mask, f->v_colors,
+    TS_TRY(ts_sh_colors_bwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin,
+                            (f->flags & TS_FRAME_STRIPE) ? nullptr : f->sh_mask, f->v_colors,
                             f->v_colors_dc, f->num_bases > 1 ? f->v_colors_rest : nullptr, stream));
     return ts_project_bwd(f->n, f->means, f->scales, f->quats, f->view34, f->projview, &f->cam, 3, f->radii,
                           f->v_xy, f->v_depth, f->v_conic, nullptr, f->v_means, f->v_scales, f->v_quats, stream);

@@ -287,6 +287,37 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
     colors[3 * i + 2] = fmaxf(c2, 0.0f);
 }
 
+// The same colour stage for a tile-row STRIPE of a multi-GPU frame: only the Gaussians that are listed in
+// the stripe (live[i] = num_tiles_hit[i] != 0, typically 1/G of them) are evaluated; each live lane reads
+// its own coefficient row (no LDS staging: a workgroup holds few live rows, and skipping the others is the
+// point - the dense kernel streams all 12 K bytes per Gaussian).  Colours and masks of the other
+// Gaussians are left unwritten: nothing reads them (ts_pack_splats and ts_reduce_partials touch only
+// listed Gaussians).
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
+    int n, int num_bases, const int* __restrict__ live, const float* __restrict__ means,
+    const float* __restrict__ origin, const float* __restrict__ dc, const float* __restrict__ rest,
+    float* __restrict__ colors, unsigned char* __restrict__ mask) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n || live[i] == 0) return;
+    float Y[KA];
+    ts::sh_basis(DEG, means[3 * i] - origin[0], means[3 * i + 1] - origin[1],
+                 means[3 * i + 2] - origin[2], Y);
+    float c0 = Y[0] * dc[3 * i], c1 = Y[0] * dc[3 * i + 1], c2 = Y[0] * dc[3 * i + 2];
+    const float* r = rest + (size_t)i * 3 * (num_bases - 1);
+#pragma unroll
+    for (int k = 1; k < KA; ++k) {      // same association order as the dense kernel: identical bits
+        c0 = c0 + Y[k] * r[3 * (k - 1)];
+        c1 = c1 + Y[k] * r[3 * (k - 1) + 1];
+        c2 = c2 + Y[k] * r[3 * (k - 1) + 2];
+    }
+    c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
+    if (mask) mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
+    colors[3 * i] = fmaxf(c0, 0.0f); colors[3 * i + 1] = fmaxf(c1, 0.0f);
+    colors[3 * i + 2] = fmaxf(c2, 0.0f);
+}
+
 template <int DEG>
 __global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
         float Y[KA];
         ts::sh_basis(DEG, means[3 * i] - origin[0], means[3 * i + 1] - origin[1],
                      means[3 * i + 2] - origin[2], Y);
-        const int m = mask[i];
+        const int m = mask ? mask[i] : 7;      // NULL: the clamp was applied upstream (ts_reduce_partials)
         const float v0 = (m & 1) ? v_colors[3 * i] : 0.0f, v1 = (m & 2) ? v_colors[3 * i + 1] : 0.0f,
                     v2 = (m & 4) ? v_colors[3 * i + 2] : 0.0f;
         v_dc[3 * i] = Y[0] * v0; v_dc[3 * i + 1] = Y[0] * v1; v_dc[3 * i + 2] = Y[0] * v2;
@@ -466,13 +497,28 @@ int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
 
 int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
                      const float* origin, const float* colors_dc, const float* colors_rest,
-                     float* colors, uint8_t* clamp_mask, void* stream) {
+                     float* colors, uint8_t* clamp_mask, const int32_t* live, void* stream) {
     const int chk = sh_check(n, degrees_to_use, num_bases);
     if (chk) return chk;
     if (n == 0) return 0;
     if (!means3d || !origin || !colors_dc || !colors || (num_bases > 1 && !colors_rest))
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
+    if (live) {
+        hipStream_t ss = (hipStream_t)stream;
+#define TS_SHC_SPARSE(D)                                                                           \
+        hipLaunchKernelGGL(sh_colors_fwd_sparse_kernel<D>, dim3(grid), dim3(kThreads), 0, ss, n,   \
+                           num_bases, live, means3d, origin, colors_dc, colors_rest, colors, clamp_mask)
+        switch (degrees_to_use) {
+            case 0: TS_SHC_SPARSE(0); break;
+            case 1: TS_SHC_SPARSE(1); break;
+            case 2: TS_SHC_SPARSE(2); break;
+            case 3: TS_SHC_SPARSE(3); break;
+            default: TS_SHC_SPARSE(4); break;
+        }
+#undef TS_SHC_SPARSE
+        return launch_status();
+    }
     const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
     const size_t lds = (size_t)kThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
@@ -501,8 +547,7 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     const int chk = sh_check(n, degrees_to_use, num_bases);
     if (chk) return chk;
     if (n == 0) return 0;
-    if (!means3d || !origin || !clamp_mask || !v_colors || !v_colors_dc ||
-        (num_bases > 1 && !v_colors_rest))
+    if (!means3d || !origin || !v_colors || !v_colors_dc || (num_bases > 1 && !v_colors_rest))
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
     const size_t lds = (size_t)kThreads * ((3 * (num_bases - 1)) | 1) * sizeof(float);

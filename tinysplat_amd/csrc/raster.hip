@@ -688,12 +688,15 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 // Row layout (raw sums over the pixels of one tile, see raster_bwd_kernel):
 //   [ S v_sigma, S v_sigma dx, S v_sigma dy, S v_sigma dx^2, S v_sigma dx dy, S v_sigma dy^2, c0..c3, -, - ]
 // with d = xy - pixel.  The conic / opacity factors are applied once per Gaussian here.
+// color_mask (may be NULL): clamp mask of the colour stage, applied here (bit c clear -> v_colors[c] = 0)
+// when the gradients are summed over ranks before the colour stage's backward runs.
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, int flags, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
     const float4* __restrict__ partials, const unsigned char* __restrict__ row_flags,
     const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_opacity, float* __restrict__ v_depth) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacity, float* __restrict__ v_depth,
+    const unsigned char* __restrict__ color_mask) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
@@ -728,6 +731,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
         vy = B * a0.y + C * a0.z;
         vop = op > 0.0f ? -a0.x / op : 0.0f;
         if (flags & TS_RASTER_LOGIT_OPACITY) vop *= op * (1.0f - op);   // through the sigmoid
+        if (color_mask) {
+            const int m = color_mask[i];
+            if (!(m & 1)) a1.z = 0.0f;
+            if (!(m & 2)) a1.w = 0.0f;
+            if (!(m & 4)) a2.x = 0.0f;
+        }
     }
     reinterpret_cast<float2*>(v_xy)[i] = make_float2(vx, vy);
     v_opacity[i] = vop;
@@ -821,7 +830,8 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
 int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
                        const int32_t* cum_tiles_hit, const float* partials,
                        const uint8_t* row_flags, const float* splats, float* v_xy, float* v_conic,
-                       float* v_colors, float* v_opacity, float* v_depth, void* stream) {
+                       float* v_colors, float* v_opacity, float* v_depth, const uint8_t* color_mask,
+                       void* stream) {
     if (n < 0 || (channels != 3 && channels != 4)) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!num_tiles_hit || !cum_tiles_hit || !row_flags || !splats || !v_xy || !v_conic || !v_colors || !v_opacity)
@@ -831,13 +841,11 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int grid = (n + 255) / 256;
     if (channels == 3)
-        hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags,
-                           num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth);
+        hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask);
     else
-        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags,
-                           num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth);
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask);
     return launch_status();
 }
 

@@ -89,6 +89,13 @@ _pinned_total = {}      # device index -> (pinned int32[1], event): the path's o
 _bg_cache = {}          # (storage address, version, channels) -> contiguous background with the depth channel
 
 
+# One stripe of a multi-GPU frame (tile_rows narrower than the frame, training frame): the colour stage
+# runs only for the Gaussians the stripe lists and the clamp mask is applied before the all-reduce
+# (TS_FRAME_STRIPE, csrc/frame.hip).  Same gradients, bit for bit, as the dense order
+# (tests/test_gpu_parity.py, tests/test_gpu_dist.py); a rank's colour stage at 8 stripes: 60 -> 24 us.
+# TS_STRIPE_SPARSE=0 for A/B timing.
+STRIPE_SPARSE = os.environ.get("TS_STRIPE_SPARSE", "1") != "0"
+
 # How the host waits for the intersection count (the one host read of a frame).  "event": synchronise on an
 # event recorded behind the copy; "spin": the pinned word is set to -1 before the copy is issued and the
 # host polls it - no driver call on the critical path (the count is >= 0, or < 0 only on int32 overflow,
@@ -186,7 +193,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         host, event = _total_slot(dev)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
-        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0)
+        # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
+        stripe = STRIPE_SPARSE and cam.tile_rows < cam.tile_bounds_y
+        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -268,7 +277,8 @@ def _steps_project(lib, fr, s):
 
 def _steps_prepare(lib, fr, s):
     _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
-          fr.colors_dc, fr.colors_rest if fr.num_bases > 1 else None, fr.colors, fr.sh_mask, s)
+          fr.colors_dc, fr.colors_rest if fr.num_bases > 1 else None, fr.colors, fr.sh_mask,
+          fr.num_tiles_hit if fr.flags & 16 else None, s)
     _call("ts_pack_splats", lib.ts_pack_splats, fr.n, fr.channels, 1, fr.xys, fr.radii, fr.conics, fr.colors,
           fr.opacities, fr.cum_tiles_hit, fr.cam, fr.depths if fr.channels == 4 else None, fr.splats, s)
     tight = fr.splats if fr.flags & 1 else None
@@ -297,12 +307,13 @@ def _steps_bwd_composite(lib, fr, s):
           fr.clamp_mask, fr.partials, fr.row_flags, s)
     _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split, fr.num_tiles_hit,
           fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, fr.v_xy, fr.v_conic, fr.v_colors,
-          fr.v_opacity, fr.v_depth if fr.channels == 4 else None, s)
+          fr.v_opacity, fr.v_depth if fr.channels == 4 else None, fr.sh_mask if fr.flags & 16 else None, s)
 
 
 def _steps_bwd_params(lib, fr, s):
     _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
-          fr.sh_mask, fr.v_colors, fr.v_colors_dc, fr.v_colors_rest if fr.num_bases > 1 else None, s)
+          None if fr.flags & 16 else fr.sh_mask, fr.v_colors, fr.v_colors_dc,
+          fr.v_colors_rest if fr.num_bases > 1 else None, s)
     _call("ts_project_bwd", lib.ts_project_bwd, fr.n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview,
           fr.cam, 3, fr.radii, fr.v_xy, fr.v_depth, fr.v_conic, None, fr.v_means, fr.v_scales, fr.v_quats, s)
 

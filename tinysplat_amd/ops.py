@@ -289,7 +289,7 @@ class _ShColors(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, n, int(degrees_to_use), nb, _ptr(means3d),
                   _ptr(origin), _ptr(colors_dc), _ptr(colors_rest) if nb > 1 else None, _ptr(colors),
-                  _ptr(mask), _stream(dev))
+                  _ptr(mask), None, _stream(dev))
         ctx.degree, ctx.nb = int(degrees_to_use), nb
         ctx.save_for_backward(means3d, origin, mask)
         return colors
@@ -503,7 +503,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          _ptr(v_out_alpha), None, _ptr(partials), _ptr(row_flags), s)
             _call("ts_reduce_partials", lib.ts_reduce_partials, n, ch, ctx.logit, _ptr(b.num_tiles_hit), _ptr(b.cum_tiles_hit),
                                               _ptr(partials), _ptr(row_flags), _ptr(splats), _ptr(v_xy), _ptr(v_conic),
-                                              _ptr(v_colors), _ptr(v_opacity), None, s)
+                                              _ptr(v_colors), _ptr(v_opacity), None, None, s)
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity.view(ctx.opacity_shape),
                 None, None, None, None, None)
 

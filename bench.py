@@ -437,7 +437,10 @@ def main():
                 r_, ws_ = rank, world
             out, (y0, y1), _ = render_stripe(model, cam, (w, h), dev, r_, ws_, with_depth=args.depth,
                                              collective=(world > 1 or args.force_dist))
-            loss = (out[:, :, :3] * w_rgb[y0:y1]).sum()
+            # D2's loss (rgb * w).sum(); a full-range slice of a 3-channel frame would only add a zero-fill and
+            # a copy of the whole image to the backward pass
+            rgb = out if out.shape[2] == 3 else out[:, :, :3]
+            loss = (rgb * w_rgb[y0:y1]).sum()
             if args.depth:
                 loss = loss + (out[:, :, 3] * w_d[y0:y1]).sum()
         loss.backward()

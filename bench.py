@@ -54,10 +54,8 @@ STAGE_OF = {
     "ts_sh_bwd": "sh_bwd", "ts_sh_colors_bwd": "sh_bwd",
     "ts_scan_tiles": "bin_sort", "ts_bin_count": "bin_sort", "ts_tile_offsets": "bin_sort",
     "ts_bin_scatter": "bin_sort", "ts_sort_tiles": "bin_sort", "ts_pack_splats": "bin_sort",
-    "ts_frame_prep": "bin_sort",
     "ts_raster_fwd": "raster_fwd",
     "ts_raster_bwd": "raster_bwd", "ts_reduce_partials": "raster_bwd",
-    "ts_grads_bwd": "param_bwd",
 }
 
 
@@ -74,7 +72,6 @@ def stage_alg_bytes(stage: str, n: int, i: int, p: int, t: int, k: int, ch: int 
         "raster_bwd": (24.0 + extra) * p + (76.0 + 2 * extra) * i + (36.0 + extra) * n,
         "sh_bwd": (24.0 + 12.0 * k) * n,
         "project_bwd": 144.0 * n,
-        "param_bwd": (24.0 + 12.0 * k) * n + 144.0 * n,      # SH bwd + project bwd in one launch
     }[stage]
 
 
@@ -255,8 +252,8 @@ def cpu_baseline_guarded(timeout_s: float = 240.0):
 KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel", "ts_raster_fwd"),
                    ("reduce_partials_kernel", "ts_reduce_partials"), ("sort_tiles", "ts_sort_tiles"),
                    ("bin_scatter_kernel", "ts_bin_scatter"), ("bin_count_kernel", "ts_bin_count"),
-                   ("sh_colors_fwd_kernel", "ts_sh_colors_fwd"), ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
-                   ("grads_bwd_kernel", "ts_grads_bwd"), ("frame_prep_kernel", "ts_frame_prep"),
+                   ("sh_colors_fwd_kernel", "ts_sh_colors_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_sh_colors_fwd"),
+                   ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
                    ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
                    ("pack_splats_kernel", "ts_pack_splats")]
 

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restri
 // one window per chunk (as long as the tile count fits the LDS) with 4096-Gaussian chunks is the
 // fastest split - larger chunks with several tile windows make the runs written into a bucket
 // longer but re-read every Gaussian once per window and lost 10-30 %.
-constexpr int kBinThreads = 512;
+#ifndef TS_BIN_THREADS
+#define TS_BIN_THREADS 1024
+#endif
+constexpr int kBinThreads = TS_BIN_THREADS;
 #ifndef TS_BIN_CHUNK
 #define TS_BIN_CHUNK 4096
 #endif
@@ -127,8 +130,13 @@ constexpr int kBinMaxChunks = 512;
 constexpr int kBinWindowMax = 36864;      // tiles per LDS window (144 KiB of the 160 KiB LDS)
 constexpr int kBinTargetBlocks = 1;       // chunks x windows aimed at (1 = no extra windows)
 
+// Chunk size: kBinChunkMin Gaussians for scenes of ~1 M and more (one workgroup per CU); smaller scenes get
+// smaller chunks, down to 1024, so that a 100 k-Gaussian frame still spreads over ~100 workgroups
+// (config 2: bin_count 30 -> 15 us, bin_scatter 33 -> 17 us).
 __host__ __device__ inline int bin_num_chunks(int n) {
-    int b = (n + kBinChunkMin - 1) / kBinChunkMin;
+    int per = n / 192;
+    per = per < 1024 ? 1024 : (per > kBinChunkMin ? kBinChunkMin : per);
+    int b = (n + per - 1) / per;
     if (b < 1) b = 1;
     if (b > kBinMaxChunks) b = kBinMaxChunks;
     return b;
@@ -168,11 +176,10 @@ constexpr float kTightEps = 0.02f;
 struct TightTest {
     bool cull_all, geometric;
     float gx, gy, hA, B, tau4A, D4, inv2A, dymax, dxext, dy_left;
-    __device__ __forceinline__ TightTest(const float4* __restrict__ splats, int i, float radius) {
+    __device__ __forceinline__ TightTest(bool tight, const float4 q0, const float4 q1, float radius) {
         cull_all = false; geometric = false;
         gx = gy = hA = B = tau4A = D4 = inv2A = dymax = dxext = dy_left = 0.0f;
-        if (!splats) return;
-        const float4 q0 = splats[3 * (size_t)i], q1 = splats[3 * (size_t)i + 1];
+        if (!tight) return;
         gx = q0.x; gy = q0.y;
         hA = 0.5f * ts::kLog2e * q0.w; B = ts::kLog2e * q1.x;
         const float hC = 0.5f * ts::kLog2e * q1.y;
@@ -212,6 +219,65 @@ struct TightTest {
     }
 };
 
+// Walks the Gaussians of a chunk and calls emit(t) for every list (tile of the lists' shape, index t
+// inside the launch) a Gaussian is entered in.  Count and scatter replay the same walk, so they agree.
+// A thread handles kBinThreads-strided Gaussians; the operands of kBinPre of them (radius, centre, the
+// two record words of the tight test) are loaded before the first one is processed, and a workgroup is
+// 1024 threads: with one workgroup per CU the walk is a chain of dependent loads and square roots per
+// Gaussian, and more waves / more loads in flight are what hide it.  Measured against 512 threads without
+// prefetch: bin_count 32.5 -> 25.7 us on config 3, 125 -> 111 us on config 5; bin_scatter 0.63 -> 0.49 ms
+// on config 5 (63 us either way on config 3, where the scattered 4-byte stores bind).
+#ifndef TS_BIN_PRE
+#define TS_BIN_PRE 2
+#endif
+constexpr int kBinPre = TS_BIN_PRE;
+template <typename Emit>
+__device__ __forceinline__ void walk_chunk(int g0, int g1, const float* __restrict__ xys,
+                                           const int* __restrict__ radii,
+                                           const float4* __restrict__ splats, const ts_camera& cam,
+                                           Emit emit) {
+    const int ws = cam.wide_tiles ? 1 : 0;                         // list column = 16x16 column >> ws
+    const int tbx = (cam.tile_bounds_x + ws) >> ws;
+    const bool tight_lists = splats != nullptr;
+    for (int base = g0 + threadIdx.x; base < g1; base += kBinPre * kBinThreads) {
+        int r[kBinPre];
+        float2 xy[kBinPre];
+        float4 q0[kBinPre], q1[kBinPre];
+#pragma unroll
+        for (int u = 0; u < kBinPre; ++u) {
+            const int i = base + u * kBinThreads;
+            r[u] = i < g1 ? radii[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kBinPre; ++u) {
+            const int i = base + u * kBinThreads;
+            xy[u] = make_float2(0.f, 0.f);
+            q0[u] = q1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r[u] > 0) {
+                xy[u] = reinterpret_cast<const float2*>(xys)[i];
+                if (tight_lists) { q0[u] = splats[3 * (size_t)i]; q1[u] = splats[3 * (size_t)i + 1]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBinPre; ++u) {
+            if (r[u] <= 0) continue;
+            const ts::TileBox b = ts::tile_bbox(xy[u].x, xy[u].y, (float)r[u], cam.tile_bounds_x,
+                                                cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
+            if (b.maxy <= b.miny || b.maxx <= b.minx) continue;  // not in this stripe (its record was never written)
+            const TightTest tight(tight_lists, q0[u], q1[u], (float)r[u]);
+            if (tight.cull_all) continue;
+            const int i = base + u * kBinThreads;
+            for (int ty = b.miny; ty < b.maxy; ++ty) {
+                int lo, hi;
+                tight.row_range(ty, b.minx, b.maxx, lo, hi);
+                if (hi <= lo) continue;
+                // list columns: 16x16 tiles lo..hi-1, or the wide tiles that contain them
+                for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) emit((ty - cam.tile_row0) * tbx + tx, i);
+            }
+        }
+    }
+}
+
 // grid = (chunks, windows); counts[b * T + t]
 __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
@@ -223,28 +289,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) hist[j] = 0;
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-    const int ws = cam.wide_tiles ? 1 : 0;                         // list column = 16x16 column >> ws
-    const int tbx = (cam.tile_bounds_x + ws) >> ws;
-    for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
-        const int r = radii[i];
-        if (r <= 0) continue;
-        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
-        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
-                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        if (b.maxy <= b.miny || b.maxx <= b.minx) continue;      // not in this stripe: skip the record load
-        const TightTest tight(splats, i, (float)r);
-        if (tight.cull_all) continue;
-        for (int ty = b.miny; ty < b.maxy; ++ty) {
-            int lo, hi;
-            tight.row_range(ty, b.minx, b.maxx, lo, hi);
-            if (hi <= lo) continue;
-            // list columns: 16x16 tiles lo..hi-1, or the wide tiles that contain them
-            for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) {
-                const int t = (ty - cam.tile_row0) * tbx + tx - t0;
-                if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
-            }
-        }
-    }
+    walk_chunk(g0, g1, xys, radii, splats, cam, [&](int t, int) {
+        t -= t0;
+        if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
+    });
     __syncthreads();
     int* dst = counts + (size_t)blockIdx.x * num_tiles + t0;
     for (int j = threadIdx.x; j < tw; j += kBinThreads) dst[j] = hist[j];
@@ -352,27 +400,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) cursor[j] = tile_start[t0 + j] + src[j];
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-    const int ws = cam.wide_tiles ? 1 : 0;                         // list column = 16x16 column >> ws
-    const int tbx = (cam.tile_bounds_x + ws) >> ws;
-    for (int i = g0 + threadIdx.x; i < g1; i += kBinThreads) {
-        const int r = radii[i];
-        if (r <= 0) continue;
-        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
-        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
-                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        if (b.maxy <= b.miny || b.maxx <= b.minx) continue;
-        const TightTest tight(splats, i, (float)r);
-        if (tight.cull_all) continue;
-        for (int ty = b.miny; ty < b.maxy; ++ty) {
-            int lo, hi;
-            tight.row_range(ty, b.minx, b.maxx, lo, hi);
-            if (hi <= lo) continue;
-            for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) {
-                const int t = (ty - cam.tile_row0) * tbx + tx - t0;
-                if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
-            }
-        }
-    }
+    walk_chunk(g0, g1, xys, radii, splats, cam, [&](int t, int i) {
+        t -= t0;
+        if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
+    });
 }
 
 // ---- per-tile bitonic sort ---------------------------------------------------------------------

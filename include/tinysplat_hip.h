@@ -161,7 +161,10 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
  * (bin_ws may be passed: its contents are dead once ts_bin_scatter has run). */
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
                   const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
-                  void* stream);
+                  int32_t* zeroed_counter, void* stream);
+/* zeroed_counter: NULL, or a device word known to be zero that the sort may use as its counter of oversized
+ * tiles (it is left non-zero).  ts_tile_offsets zeroes the LAST word of its workspace,
+ * bin_ws[ts_bin_ws_ints(n, num_tiles) - 1], for this purpose: passing it saves a 4-byte memset launch. */
 
 #define TS_RASTER_LOGIT_OPACITY 1 /* `opacity` holds logits: sigmoid (rasterize.py:86) is applied while */
                                   /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */

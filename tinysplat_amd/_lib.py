@@ -72,7 +72,7 @@ SIGNATURES = {
     "ts_bin_count": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P]),
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
-    "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
+    "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

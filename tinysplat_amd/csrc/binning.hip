@@ -82,27 +82,22 @@ __global__ __launch_bounds__(kThreads) void scan_local_kernel(int n, const int* 
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// single workgroup: in-place exclusive scan of m ints
-__global__ __launch_bounds__(kThreads) void scan_sums_kernel(int m, int* __restrict__ sums) {
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < m; base += kThreads) {
-        const int i = base + threadIdx.x;
-        const int v = (i < m) ? sums[i] : 0;
-        int total;
-        const int inc = block_inclusive_scan(v, &total);
-        const int c = carry;
-        if (i < m) sums[i] = c + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-}
-
+// adds to every element of block b the sum of the blocks before it, which the block reduces itself from
+// the <= n / 1024 block sums (a separate single-workgroup scan of those sums would be one more launch on
+// the critical path of the frame: ~5 us each on MI355X however small the kernel)
 __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restrict__ out,
-                                                            const int* __restrict__ block_excl) {
-    const int add = block_excl[blockIdx.x];
+                                                            const int* __restrict__ block_sums) {
+    __shared__ int red[kThreads / 64];
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kThreads) part += block_sums[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) add += red[w];
+    if (blockIdx.x == 0) return;
     const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
@@ -342,10 +337,11 @@ __global__ __launch_bounds__(kThreads) void column_group_scan_kernel(int num_til
 constexpr int kOffsetsThreads = 1024;
 __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_tiles,
                                                                        int* __restrict__ tile_total,
-                                                                       int* __restrict__ tile_bins) {
+                                                                       int* __restrict__ tile_bins,
+                                                                       int* __restrict__ spare) {
     constexpr int kPer = 8;
     __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) { carry = 0; *spare = 0; }     // the workspace's last word: ts_sort_tiles' tile counter
     __syncthreads();
     for (int base = 0; base < num_tiles; base += kOffsetsThreads * kPer) {
         const int t0 = base + threadIdx.x * kPer;
@@ -691,7 +687,8 @@ __device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
 // sample sort.
 __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     int num_tiles, const int* __restrict__ tile_bins, const float* __restrict__ depths,
-    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_list) {
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_count,
+    int* __restrict__ large_list) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (tile >= num_tiles) return;
@@ -699,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     const int n = range.y - range.x;
     if (n <= 0) return;
     if (n > kWaveSortMax) {                      // (kWaveSortMax, kSortCap]: sort_tiles_mid_kernel
-        if (n > kSortCap && lane == 0) large_list[1 + atomicAdd(&large_list[0], 1)] = tile;
+        if (n > kSortCap && lane == 0) large_list[atomicAdd(large_count, 1)] = tile;
         return;
     }
     const int* g = bucket_ids + range.x;
@@ -726,11 +723,11 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_mid_kernel(
 __global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
     const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted,
-    const int* __restrict__ large_list) {
+    const int* __restrict__ large_count, const int* __restrict__ large_list) {
     __shared__ unsigned long long lds_large[kLargeLdsU64];
-    const int count = large_list[0];
+    const int count = *large_count;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        const int2 range = reinterpret_cast<const int2*>(tile_bins)[large_list[1 + q]];
+        const int2 range = reinterpret_cast<const int2*>(tile_bins)[large_list[q]];
         __syncthreads();
         sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, range.y - range.x,
                          lds_large);
@@ -807,11 +804,8 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(kThreads), 0, s, n, num_tiles_hit,
                        cum_tiles_hit, scan_ws);
-    if (nb > 1) {
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kThreads), 0, s, nb, scan_ws);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, n, cum_tiles_hit,
-                           scan_ws);
-    }
+    if (nb > 1)
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, n, cum_tiles_hit, scan_ws);
     return launch_status();
 }
 
@@ -859,7 +853,7 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     hipLaunchKernelGGL(column_group_scan_kernel, dim3((num_tiles + kThreads - 1) / kThreads),
                        dim3(kThreads), 0, s, num_tiles, groups, group_sum, tile_total);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kOffsetsThreads), 0, s, num_tiles, tile_total,
-                       tile_bins);
+                       tile_bins, bin_ws + (ts_bin_ws_ints(n, num_tiles) - 1));
     hipLaunchKernelGGL(column_finish_kernel, grid2, dim3(kThreads), 0, s, num_tiles, chunks,
                        per_group, bin_ws, group_sum);
     return launch_status();
@@ -889,21 +883,27 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
 
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
                   const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
-                  void* stream) {
+                  int32_t* zeroed_counter, void* stream) {
     if (num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
     if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted || !sort_ws) return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
+    // counter + list of the tiles beyond the sorting network.  zeroed_counter: a word the caller knows to
+    // be zero (ts_tile_offsets leaves the last word of its workspace so) - saves a 4-byte memset launch
+    int32_t* counter = zeroed_counter ? zeroed_counter : sort_ws;
+    int32_t* list = zeroed_counter ? sort_ws : sort_ws + 1;
+    if (!zeroed_counter) {
+        hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(sort_tiles_small_kernel, dim3((num_tiles + kThreads / 64 - 1) / (kThreads / 64)),
                        dim3(kThreads), 0, s, (int)num_tiles, tile_bins, depths, bucket_ids,
-                       gaussian_ids_sorted, sort_ws);
+                       gaussian_ids_sorted, counter, list);
     hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
                        bucket_ids, gaussian_ids_sorted);
     const int grid = num_tiles < 768 ? num_tiles : 768;
     hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
-                       bucket_ids, gaussian_ids_sorted, sort_ws);
+                       bucket_ids, gaussian_ids_sorted, counter, list);
     return launch_status();
 }
 

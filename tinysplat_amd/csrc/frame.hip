@@ -70,7 +70,7 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
         const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
         TS_TRY(ts_bin_scatter(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, f->bucket_ids, stream));
         TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
-                             f->bin_ws, stream));
+                             f->bin_ws, f->bin_ws + (ts_bin_ws_ints(f->n, num_tiles(f)) - 1), stream));
     }
     return ts_raster_fwd(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
                          f->background, f->out_img, f->final_Ts, f->final_index, f->clamp_mask, stream);

@@ -294,7 +294,7 @@ def _steps_composite(lib, fr, s):
         _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
               fr.bucket_ids, s)
         _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
-              fr.gaussian_ids_sorted, fr.bin_ws, s)
+              fr.gaussian_ids_sorted, fr.bin_ws, fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
     _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam, fr.tile_bins,
           fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.final_Ts, fr.final_index,
           fr.clamp_mask, s)
@@ -351,8 +351,13 @@ class _RenderFrame(torch.autograd.Function):
         with torch.cuda.device(dev):
             _mark("bwd:device ctx")
             # v_xy | v_conic | v_colors | [v_depth] | v_opacity: ONE buffer, so that the multi-GPU path
-            # can all-reduce it in place
-            flat = torch.empty((n * (6 + ch),), **f32)
+            # can all-reduce it in place.  Without a collective v_xy and v_opacity are written straight into
+            # the tensors handed out (xys.grad, the opacity gradient): no copies behind the kernels.
+            single = ctx.group is None
+            flat = torch.empty((n * ((3 + ch) if single else (6 + ch)),), **f32)
+            if single:
+                v_xy = torch.empty((n, 2), **f32)
+                v_opac = torch.empty(tuple(ctx.opacity_shape), **f32)
             rows = max(F.total, 1) * (4 if F.split else 1)
             partials = torch.empty((rows, 12), **f32)
             row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
@@ -364,9 +369,14 @@ class _RenderFrame(torch.autograd.Function):
             v_rest = torch.empty(tuple(ctx.rest_shape), **f32)
             p = flat.data_ptr()
             fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
-            fr.v_xy, fr.v_conic, fr.v_colors = p, p + 8 * n, p + 20 * n
-            fr.v_depth = p + 32 * n if ch == 4 else None
-            fr.v_opacity = p + (20 + 4 * ch) * n
+            if single:
+                fr.v_xy, fr.v_conic, fr.v_colors = v_xy.data_ptr(), p, p + 12 * n
+                fr.v_depth = p + 24 * n if ch == 4 else None
+                fr.v_opacity = v_opac.data_ptr()
+            else:
+                fr.v_xy, fr.v_conic, fr.v_colors = p, p + 8 * n, p + 20 * n
+                fr.v_depth = p + 32 * n if ch == 4 else None
+                fr.v_opacity = p + (20 + 4 * ch) * n
             fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
             fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
             _mark("bwd:allocated")
@@ -382,16 +392,17 @@ class _RenderFrame(torch.autograd.Function):
             else:
                 _lib.check(lib.ts_frame_bwd_params(ctypes.byref(fr), s), "ts_frame_bwd_params")
         _mark("bwd:calls")
-        v_xy = flat[:2 * n].view(n, 2)
-        v_opac = flat[(5 + ch) * n:]
+        if not single:      # compact copies: views would pin the n * (6 + ch) buffer
+            v_xy = flat[:2 * n].view(n, 2).clone()
+            v_opac = flat[(5 + ch) * n:].view(ctx.opacity_shape).clone()
         # what extras['xys'].grad holds in the reference (model_gaussian.py:130-132).  `xys` carries no
         # autograd edge on this fused path (retain_grad() is not needed and would raise); the gradient
         # is a compact copy - not a view that pins the n*(6+ch) buffer - and accumulates like a
         # retained grad when a second backward reaches the same frame.
         xo = ctx.xys_out
-        xo.grad = v_xy.clone() if xo.grad is None else xo.grad + v_xy
+        xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
         _mark("bwd:exit")
-        return (v_means, v_scales, v_quats, v_opac.view(ctx.opacity_shape).clone(), v_dc, v_rest) + (None,) * 12
+        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 12
 
 
 @torch.no_grad()

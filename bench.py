@@ -436,8 +436,10 @@ def main():
                                              collective=(world > 1 or args.force_dist))
             # D2's loss (rgb * w).sum(); a full-range slice of a 3-channel frame would only add a zero-fill and
             # a copy of the whole image to the backward pass
-            rgb = out if out.shape[2] == 3 else out[:, :, :3]
-            loss = (rgb * w_rgb[y0:y1]).sum()
+            if out.shape[2] == 3:        # (rgb * w).sum() as one pass over the image (and one in backward)
+                loss = torch.dot(out.reshape(-1), w_rgb[y0:y1].reshape(-1))
+            else:
+                loss = (out[:, :, :3] * w_rgb[y0:y1]).sum()
             if args.depth:
                 loss = loss + (out[:, :, 3] * w_d[y0:y1]).sum()
         loss.backward()

@@ -125,10 +125,13 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
  * -> ts_sort_tiles -> ts_pack_splats -> ts_raster_fwd ; backward: ts_raster_bwd -> ts_reduce_partials */
 
 /* Inclusive int32 prefix sum of num_tiles_hit -> cum_tiles_hit[n]; the grand total (number of
- * tile/Gaussian intersections I) is cum_tiles_hit[n-1].  scan_ws: >= ts_scan_ws_ints(n) int32. */
+ * tile/Gaussian intersections I) is cum_tiles_hit[n-1].  scan_ws: >= ts_scan_ws_ints(n) int32.
+ * total_out: NULL, or a DEVICE-VISIBLE address (the device pointer of mapped pinned host memory, see
+ * hipHostGetDevicePointer) that receives the grand total with a system-scope store from the scan itself:
+ * the host can poll it there instead of queueing a 4-byte copy behind the scan. */
 int64_t ts_scan_ws_ints(int32_t n);
 int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hit,
-                  int32_t* scan_ws, void* stream);
+                  int32_t* scan_ws, int32_t* total_out, void* stream);
 
 /* Tile bucketing without global atomics.  The Gaussians are cut into B = ts_bin_chunks(n) contiguous
  * chunks; bin_ws (>= ts_bin_ws_ints(n, num_tiles) int32, num_tiles = tile_rows * tile_bounds_x) holds

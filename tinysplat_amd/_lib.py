@@ -67,7 +67,7 @@ SIGNATURES = {
     "ts_sh_colors_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sh_colors_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_scan_ws_ints": (c_int64, [c_int32]),
-    "ts_scan_tiles": (c_int32, [c_int32, _P, _P, _P, _P]),
+    "ts_scan_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P]),
     "ts_bin_ws_ints": (c_int64, [c_int32, c_int32]),
     "ts_bin_count": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P]),
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),

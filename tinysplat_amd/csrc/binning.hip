@@ -61,9 +61,13 @@ __device__ __forceinline__ int block_inclusive_scan(int v, int* total) {
     return inc + add;
 }
 
+// total_out (may be null): device-visible address - pinned host memory - that receives out[n-1], the
+// grand total, from the thread that produces it (system-scope store): the host reads it there without
+// a copy operation behind the scan
 __global__ __launch_bounds__(kThreads) void scan_local_kernel(int n, const int* __restrict__ in,
                                                               int* __restrict__ out,
-                                                              int* __restrict__ block_sums) {
+                                                              int* __restrict__ block_sums,
+                                                              int* __restrict__ total_out) {
     const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
     int v[kScanItems];
     int sum = 0;
@@ -78,7 +82,11 @@ __global__ __launch_bounds__(kThreads) void scan_local_kernel(int n, const int* 
     const int excl = inc - sum;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
-        if (base + k < n) out[base + k] = v[k] + excl;
+        if (base + k < n) {
+            out[base + k] = v[k] + excl;
+            if (total_out && gridDim.x == 1 && base + k == n - 1)
+                __hip_atomic_store(total_out, v[k] + excl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(kThreads) void scan_local_kernel(int n, const int* 
 // the <= n / 1024 block sums (a separate single-workgroup scan of those sums would be one more launch on
 // the critical path of the frame: ~5 us each on MI355X however small the kernel)
 __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restrict__ out,
-                                                            const int* __restrict__ block_sums) {
+                                                            const int* __restrict__ block_sums,
+                                                            int* __restrict__ total_out) {
     __shared__ int red[kThreads / 64];
     int part = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += kThreads) part += block_sums[j];
@@ -97,11 +106,15 @@ __global__ __launch_bounds__(kThreads) void scan_add_kernel(int n, int* __restri
     int add = 0;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w) add += red[w];
-    if (blockIdx.x == 0) return;
     const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
-        if (base + k < n) out[base + k] += add;
+        if (base + k < n) {
+            const int v = out[base + k] + add;
+            if (blockIdx.x != 0) out[base + k] = v;
+            if (total_out && base + k == n - 1)
+                __hip_atomic_store(total_out, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 }
 
 // ---- tile bucketing without global atomics --------------------------------------------------
@@ -796,16 +809,17 @@ int64_t ts_scan_ws_ints(int32_t n) {
 }
 
 int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hit,
-                  int32_t* scan_ws, void* stream) {
+                  int32_t* scan_ws, int32_t* total_out, void* stream) {
     if (n < 0) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!num_tiles_hit || !cum_tiles_hit || !scan_ws) return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(kThreads), 0, s, n, num_tiles_hit,
-                       cum_tiles_hit, scan_ws);
+                       cum_tiles_hit, scan_ws, total_out);
     if (nb > 1)
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, n, cum_tiles_hit, scan_ws);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, n, cum_tiles_hit, scan_ws,
+                           total_out);
     return launch_status();
 }
 

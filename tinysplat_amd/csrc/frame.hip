@@ -24,6 +24,20 @@ inline bool bad(const ts_frame* f) {
     return !f || f->n < 0 || (f->channels != 3 && f->channels != 4) || f->num_bases < 1;
 }
 inline int num_tiles(const ts_frame* f) { return ts_num_tiles(&f->cam); }
+// device address of a pinned host word, or null (the last answer is kept: a host uses one word per device)
+inline int32_t* mapped_pointer(int32_t* host) {
+    static int32_t* last_host = nullptr;
+    static int32_t* last_dev = nullptr;
+    if (host == last_host) return last_dev;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = nullptr;
+    }
+    last_host = host;
+    last_dev = static_cast<int32_t*>(dev);
+    return last_dev;
+}
 inline int raster_flags(const ts_frame* f) {
     return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
            ((f->flags & TS_FRAME_NARROW_WAVES) ? TS_RASTER_NARROW_WAVES : 0);
@@ -40,8 +54,11 @@ int ts_frame_fwd_project(const ts_frame* f, void* stream) {
     // cov3d is not produced (the adapter discards it, rasterize.py:32)
     TS_TRY(ts_project_fwd(f->n, f->means, f->scales, f->quats, f->view34, f->projview, &f->cam, 3, f->xys,
                           f->depths, f->radii, f->conics, f->num_tiles_hit, nullptr, stream));
-    TS_TRY(ts_scan_tiles(f->n, f->num_tiles_hit, f->cum_tiles_hit, f->scan_ws, stream));
-    if (f->n > 0 && f->total_host) {
+    // the count goes to the caller's pinned word from the scan kernel itself when that memory is mapped
+    // into the device's address space (hipHostMalloc'd memory is); otherwise by a 4-byte copy
+    int32_t* total_dev = f->total_host ? mapped_pointer(f->total_host) : nullptr;
+    TS_TRY(ts_scan_tiles(f->n, f->num_tiles_hit, f->cum_tiles_hit, f->scan_ws, total_dev, stream));
+    if (f->n > 0 && f->total_host && !total_dev) {
         const hipError_t e = hipMemcpyAsync(f->total_host, f->cum_tiles_hit + (f->n - 1), sizeof(int32_t),
                                             hipMemcpyDeviceToHost, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;

@@ -272,7 +272,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
 def _steps_project(lib, fr, s):
     _call("ts_project_fwd", lib.ts_project_fwd, fr.n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview,
           fr.cam, 3, fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, None, s)
-    _call("ts_scan_tiles", lib.ts_scan_tiles, fr.n, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws, s)
+    _call("ts_scan_tiles", lib.ts_scan_tiles, fr.n, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws, None, s)
 
 
 def _steps_prepare(lib, fr, s):

@@ -400,7 +400,7 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
     with torch.cuda.device(dev):
         cum = torch.empty((n,), **i32)
         ws = torch.empty((int(lib.ts_scan_ws_ints(n)),), **i32)
-        _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth_c), _ptr(cum), _ptr(ws), s)
+        _call("ts_scan_tiles", lib.ts_scan_tiles, n, _ptr(nth_c), _ptr(cum), _ptr(ws), None, s)
         pending = _IntersectionCount(cum, dev)       # D2H copy of cum[n-1] starts now ...
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)

@@ -96,6 +96,8 @@ _bg_cache = {}          # (storage address, version, channels) -> contiguous bac
 # TS_STRIPE_SPARSE=0 for A/B timing.
 STRIPE_SPARSE = os.environ.get("TS_STRIPE_SPARSE", "1") != "0"
 
+DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
+
 # How the host waits for the intersection count (the one host read of a frame).  "event": synchronise on an
 # event recorded behind the copy; "spin": the pinned word is set to -1 before the copy is issued and the
 # host polls it - no driver call on the critical path (the count is >= 0, or < 0 only on int32 overflow,
@@ -353,7 +355,7 @@ class _RenderFrame(torch.autograd.Function):
             # v_xy | v_conic | v_colors | [v_depth] | v_opacity: ONE buffer, so that the multi-GPU path
             # can all-reduce it in place.  Without a collective v_xy and v_opacity are written straight into
             # the tensors handed out (xys.grad, the opacity gradient): no copies behind the kernels.
-            single = ctx.group is None
+            single = ctx.group is None and DIRECT_GRADS
             flat = torch.empty((n * ((3 + ch) if single else (6 + ch)),), **f32)
             if single:
                 v_xy = torch.empty((n, 2), **f32)

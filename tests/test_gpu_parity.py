@@ -423,8 +423,13 @@ def test_one_node_frame_is_bitwise_the_fused_op_recipe():
     finally:
         frame.SPLIT_BLOCKS_BELOW = keep
     assert len(res[0]) == len(res[1]) == 11
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(*res)):
+        if frame.WIDE_TILES == 1 and k >= 4 and a.numel():
+            # TS_WIDE_TILES=1 (the optional 32x16 compositing waves) sums a Gaussian's two halves in one
+            # wave reduction: same pixels, gradients equal to rounding
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+        else:
+            assert torch.equal(a, b)
 
 
 def test_tight_binning_drops_only_pairs_that_contribute_nothing():

@@ -51,6 +51,7 @@ VALU_FP32_PEAK_TFLOPS = 157.3
 STAGE_OF = {
     "ts_project_fwd": "project_fwd", "ts_project_bwd": "project_bwd",
     "ts_sh_fwd": "sh_fwd", "ts_sh_colors_fwd": "sh_fwd",
+    "ts_colors_pack_fwd": "sh_fwd",          # colour stage + record packing in one launch (frame path)
     "ts_sh_bwd": "sh_bwd", "ts_sh_colors_bwd": "sh_bwd",
     "ts_scan_tiles": "bin_sort", "ts_bin_count": "bin_sort", "ts_tile_offsets": "bin_sort",
     "ts_bin_scatter": "bin_sort", "ts_sort_tiles": "bin_sort", "ts_pack_splats": "bin_sort",
@@ -252,7 +253,7 @@ def cpu_baseline_guarded(timeout_s: float = 240.0):
 KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel", "ts_raster_fwd"),
                    ("reduce_partials_kernel", "ts_reduce_partials"), ("sort_tiles", "ts_sort_tiles"),
                    ("bin_scatter_kernel", "ts_bin_scatter"), ("bin_count_kernel", "ts_bin_count"),
-                   ("sh_colors_fwd_kernel", "ts_sh_colors_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_sh_colors_fwd"),
+                   ("sh_colors_fwd_kernel", "ts_colors_pack_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_colors_pack_fwd"),
                    ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
                    ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
                    ("pack_splats_kernel", "ts_pack_splats")]

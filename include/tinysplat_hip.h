@@ -119,6 +119,15 @@ int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
 int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
                      const float* origin, const uint8_t* clamp_mask, const float* v_colors,
                      float* v_colors_dc, float* v_colors_rest, void* stream);
+/* ts_sh_colors_fwd + ts_pack_splats in one launch for the RGB / RGB + depth frame: the colour stage
+ * writes the packed record of every listed Gaussian itself (arguments as for ts_pack_splats; the colours
+ * stay in registers, no colors[n,3] array exists).  channels == 4 takes channel 3 from depths[]. */
+int ts_colors_pack_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                       const float* origin, const float* colors_dc, const float* colors_rest,
+                       uint8_t* clamp_mask, const int32_t* live, int32_t channels, int32_t flags,
+                       const float* xys, const int32_t* radii, const float* conics, const float* opacity,
+                       const int32_t* cum_tiles_hit, const ts_camera* cam_host, const float* depths,
+                       float* splats, void* stream);
 
 /* ========================= rasterize_gaussians (rasterize.py:44,50) =========================== */
 /* Stage order: ts_scan_tiles -> (read total) -> ts_bin_count -> ts_tile_offsets -> ts_bin_scatter
@@ -236,7 +245,7 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
  *   ts_frame_fwd_project    project_fwd, scan_tiles, then an async copy of the intersection count
  *                           cum_tiles_hit[n-1] into total_host (pinned host memory) - the caller
  *                           records an event behind this call and waits for it only before step 3
- *   ts_frame_fwd_prepare    sh_colors_fwd, pack_splats, bin_count, tile_offsets   (do not need the count)
+ *   ts_frame_fwd_prepare    colors_pack_fwd (= sh_colors_fwd + pack_splats), bin_count, tile_offsets   (do not need the count)
  *   ts_frame_fwd_composite  bin_scatter, sort_tiles, raster_fwd   (needs bucket_ids / gaussian_ids_sorted
  *                           sized by the count; num_intersects must be set)
  *   ts_frame_bwd_composite  raster_bwd, reduce_partials -> the flat 2-D gradients v_xy | v_conic |

@@ -74,6 +74,8 @@ SIGNATURES = {
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),
+    "ts_colors_pack_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
+                                     _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"
+#include "pack.h"
 #include "splat_math.h"
 
 namespace {
@@ -747,49 +748,20 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
     }
 }
 
-__global__ __launch_bounds__(kThreads) void pack_splats_kernel(
-    int n, int channels, int flags, const float* __restrict__ xys, const int* __restrict__ radii,
-    const float* __restrict__ conics, const float* __restrict__ colors,
-    const float* __restrict__ opacity, const int* __restrict__ cum_tiles_hit, const ts_camera cam,
-    const float* __restrict__ depths, float4* __restrict__ splats) {
+__global__ __launch_bounds__(kThreads) void pack_splats_kernel(int n, const ts::PackArgs a,
+                                                              const float* __restrict__ colors) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
-    const int r = radii[i];
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-    bool listed = false;
-    if (r > 0) {
-        const float2 xy = reinterpret_cast<const float2*>(xys)[i];
-        const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x,
-                                            cam.tile_bounds_y, cam.tile_row0, cam.tile_rows);
-        const int w = b.maxx - b.minx, h = b.maxy - b.miny;
-        const int cnt = h > 0 ? w * h : 0;
-      if (cnt > 0) {       // cnt == 0: visible, but not in this stripe -> never listed, no record
-        listed = true;
-        const int excl = cum_tiles_hit[i] - cnt;
-        const int slot_base = excl - b.miny * w - b.minx;
-        float op = opacity[i];
-        if (flags & TS_RASTER_LOGIT_OPACITY) op = 1.0f / (1.0f + expf(-op));   // sigmoid, rasterize.py:86
-        q0 = make_float4(xy.x, xy.y, op, conics[3 * i]);
-        float c0, c1, c2, c3 = 0.0f;
-        if (channels == 4 && depths == nullptr) {
-            const float4 c = reinterpret_cast<const float4*>(colors)[i];
-            c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
-        } else if (channels == 4) {      // RGB + depth in one pass: colors is [n,3], channel 3 = depths (rasterize.py:48-50)
-            c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2]; c3 = depths[i];
-        } else {
-            c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2];
-        }
-        q1 = make_float4(conics[3 * i + 1], conics[3 * i + 2], c0, c1);
-        q2 = make_float4(c2, c3, __int_as_float(slot_base), __int_as_float(w | (b.minx << 16)));
-      }
+    if (a.radii[i] <= 0) return;
+    float c0, c1, c2, c3 = 0.0f;
+    if (a.channels == 4 && a.depths == nullptr) {
+        const float4 c = reinterpret_cast<const float4*>(colors)[i];
+        c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+    } else {             // [n,3] colours; channel 3 of an RGB + depth frame = depths (rasterize.py:48-50)
+        c0 = colors[3 * i]; c1 = colors[3 * i + 1]; c2 = colors[3 * i + 2];
+        if (a.channels == 4) c3 = a.depths[i];
     }
-    // a Gaussian that is not listed in this launch (culled, or outside the tile-row stripe) has no reader:
-    // bin_count / bin_scatter skip it on the same test, the compositing kernels see listed ids only and
-    // ts_reduce_partials reads the record of a Gaussian with num_tiles_hit > 0 only
-    if (!listed) return;
-    splats[3 * (size_t)i] = q0;
-    splats[3 * (size_t)i + 1] = q1;
-    splats[3 * (size_t)i + 2] = q2;
+    ts::pack_one(a, i, c0, c1, c2, c3);
 }
 
 inline int launch_status() { return (int)hipGetLastError(); }
@@ -929,9 +901,12 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
     if (n == 0) return 0;
     if (!xys || !radii || !conics || !colors || !opacity || !cum_tiles_hit || !splats)
         return TS_E_BADARG;
+    ts::PackArgs a;
+    a.channels = channels; a.flags = (int)flags; a.xys = xys; a.radii = radii; a.conics = conics;
+    a.opacity = opacity; a.cum_tiles_hit = cum_tiles_hit; a.depths = depths;
+    a.splats = reinterpret_cast<float4*>(splats); a.cam = *cam;
     hipLaunchKernelGGL(pack_splats_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       (hipStream_t)stream, n, channels, (int)flags, xys, radii, conics, colors, opacity,
-                       cum_tiles_hit, *cam, depths, reinterpret_cast<float4*>(splats));
+                       (hipStream_t)stream, n, a, colors);
     return launch_status();
 }
 

@@ -68,13 +68,13 @@ int ts_frame_fwd_project(const ts_frame* f, void* stream) {
 
 int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
     if (bad(f)) return TS_E_BADARG;
-    TS_TRY(ts_sh_colors_fwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->colors_dc,
-                            f->num_bases > 1 ? f->colors_rest : nullptr, f->colors, f->sh_mask,
-                            (f->flags & TS_FRAME_STRIPE) ? f->num_tiles_hit : nullptr, stream));
-    // channel 3 of an RGB + depth frame is the depth itself (rasterize.py:48-50), taken from `depths`
-    TS_TRY(ts_pack_splats(f->n, f->channels, TS_RASTER_LOGIT_OPACITY, f->xys, f->radii, f->conics, f->colors,
-                          f->opacities, f->cum_tiles_hit, &f->cam, f->channels == 4 ? f->depths : nullptr,
-                          f->splats, stream));
+    // colour stage and record packing in one launch; channel 3 of an RGB + depth frame is the depth itself
+    // (rasterize.py:48-50), taken from `depths`
+    TS_TRY(ts_colors_pack_fwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin, f->colors_dc,
+                              f->num_bases > 1 ? f->colors_rest : nullptr, f->sh_mask,
+                              (f->flags & TS_FRAME_STRIPE) ? f->num_tiles_hit : nullptr, f->channels,
+                              TS_RASTER_LOGIT_OPACITY, f->xys, f->radii, f->conics, f->opacities, f->cum_tiles_hit,
+                              &f->cam, f->channels == 4 ? f->depths : nullptr, f->splats, stream));
     const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
     TS_TRY(ts_bin_count(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, stream));
     TS_TRY(ts_tile_offsets(f->n, num_tiles(f), f->bin_ws, f->tile_bins, stream));

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"
+#include "pack.h"
 #include "splat_math.h"
 
 namespace {
@@ -224,7 +225,7 @@ template <int DEG>
 __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const float* __restrict__ dc, const float* __restrict__ rest, float* __restrict__ colors,
-    unsigned char* __restrict__ mask) {
+    unsigned char* __restrict__ mask, const ts::PackArgs pk) {
     constexpr int KA = (DEG + 1) * (DEG + 1);
     constexpr int RS = 3 * (KA - 1);                // active floats of a `rest` row
     constexpr int RSP = RS | 1;
@@ -283,8 +284,9 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
     }
     c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
     if (mask) mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
-    colors[3 * i] = fmaxf(c0, 0.0f); colors[3 * i + 1] = fmaxf(c1, 0.0f);
-    colors[3 * i + 2] = fmaxf(c2, 0.0f);
+    c0 = fmaxf(c0, 0.0f); c1 = fmaxf(c1, 0.0f); c2 = fmaxf(c2, 0.0f);
+    if (colors) { colors[3 * i] = c0; colors[3 * i + 1] = c1; colors[3 * i + 2] = c2; }
+    if (pk.splats) ts::pack_one(pk, i, c0, c1, c2, pk.channels == 4 ? pk.depths[i] : 0.0f);
 }
 
 // The same colour stage for a tile-row STRIPE of a multi-GPU frame: only the Gaussians that are listed in
@@ -297,7 +299,7 @@ template <int DEG>
 __global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
     int n, int num_bases, const int* __restrict__ live, const float* __restrict__ means,
     const float* __restrict__ origin, const float* __restrict__ dc, const float* __restrict__ rest,
-    float* __restrict__ colors, unsigned char* __restrict__ mask) {
+    float* __restrict__ colors, unsigned char* __restrict__ mask, const ts::PackArgs pk) {
     constexpr int KA = (DEG + 1) * (DEG + 1);
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n || live[i] == 0) return;
@@ -314,8 +316,9 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
     }
     c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
     if (mask) mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
-    colors[3 * i] = fmaxf(c0, 0.0f); colors[3 * i + 1] = fmaxf(c1, 0.0f);
-    colors[3 * i + 2] = fmaxf(c2, 0.0f);
+    c0 = fmaxf(c0, 0.0f); c1 = fmaxf(c1, 0.0f); c2 = fmaxf(c2, 0.0f);
+    if (colors) { colors[3 * i] = c0; colors[3 * i + 1] = c1; colors[3 * i + 2] = c2; }
+    if (pk.splats) ts::pack_one(pk, i, c0, c1, c2, pk.channels == 4 ? pk.depths[i] : 0.0f);
 }
 
 template <int DEG>
@@ -495,20 +498,21 @@ int ts_sh_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float*
     return launch_status();
 }
 
-int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
-                     const float* origin, const float* colors_dc, const float* colors_rest,
-                     float* colors, uint8_t* clamp_mask, const int32_t* live, void* stream) {
+static int launch_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                             const float* origin, const float* colors_dc, const float* colors_rest,
+                             float* colors, uint8_t* clamp_mask, const int32_t* live, const ts::PackArgs& pk,
+                             void* stream) {
     const int chk = sh_check(n, degrees_to_use, num_bases);
     if (chk) return chk;
     if (n == 0) return 0;
-    if (!means3d || !origin || !colors_dc || !colors || (num_bases > 1 && !colors_rest))
+    if (!means3d || !origin || !colors_dc || (!colors && !pk.splats) || (num_bases > 1 && !colors_rest))
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
+    hipStream_t s = (hipStream_t)stream;
     if (live) {
-        hipStream_t ss = (hipStream_t)stream;
 #define TS_SHC_SPARSE(D)                                                                           \
-        hipLaunchKernelGGL(sh_colors_fwd_sparse_kernel<D>, dim3(grid), dim3(kThreads), 0, ss, n,   \
-                           num_bases, live, means3d, origin, colors_dc, colors_rest, colors, clamp_mask)
+        hipLaunchKernelGGL(sh_colors_fwd_sparse_kernel<D>, dim3(grid), dim3(kThreads), 0, s, n,    \
+                           num_bases, live, means3d, origin, colors_dc, colors_rest, colors, clamp_mask, pk)
         switch (degrees_to_use) {
             case 0: TS_SHC_SPARSE(0); break;
             case 1: TS_SHC_SPARSE(1); break;
@@ -521,14 +525,13 @@ int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     }
     const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
     const size_t lds = (size_t)kThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
 #define TS_SHC_FWD(D)                                                                             \
     do {                                                                                          \
         if (lds > 48 * 1024)                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_fwd_kernel<D>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n,         \
-                           num_bases, means3d, origin, colors_dc, colors_rest, colors, clamp_mask); \
+                           num_bases, means3d, origin, colors_dc, colors_rest, colors, clamp_mask, pk); \
     } while (0)
     switch (degrees_to_use) {
         case 0: TS_SHC_FWD(0); break;
@@ -539,6 +542,34 @@ int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     }
 #undef TS_SHC_FWD
     return launch_status();
+}
+
+int ts_sh_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const float* colors_dc, const float* colors_rest,
+                     float* colors, uint8_t* clamp_mask, const int32_t* live, void* stream) {
+    ts::PackArgs none;
+    none.splats = nullptr;
+    if (!colors) return TS_E_BADARG;
+    return launch_colors_fwd(n, degrees_to_use, num_bases, means3d, origin, colors_dc, colors_rest, colors,
+                             clamp_mask, live, none, stream);
+}
+
+int ts_colors_pack_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                       const float* origin, const float* colors_dc, const float* colors_rest,
+                       uint8_t* clamp_mask, const int32_t* live, int32_t channels, int32_t flags,
+                       const float* xys, const int32_t* radii, const float* conics, const float* opacity,
+                       const int32_t* cum_tiles_hit, const ts_camera* cam, const float* depths,
+                       float* splats, void* stream) {
+    if (n < 0 || !cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
+    if (n > 0 && (!xys || !radii || !conics || !opacity || !cum_tiles_hit || !splats ||
+                  (channels == 4 && !depths)))
+        return TS_E_BADARG;
+    ts::PackArgs pk;
+    pk.channels = channels; pk.flags = (int)flags; pk.xys = xys; pk.radii = radii; pk.conics = conics;
+    pk.opacity = opacity; pk.cum_tiles_hit = cum_tiles_hit; pk.depths = depths;
+    pk.splats = reinterpret_cast<float4*>(splats); pk.cam = *cam;
+    return launch_colors_fwd(n, degrees_to_use, num_bases, means3d, origin, colors_dc, colors_rest, nullptr,
+                             clamp_mask, live, pk, stream);
 }
 
 int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,

@@ -278,11 +278,10 @@ def _steps_project(lib, fr, s):
 
 
 def _steps_prepare(lib, fr, s):
-    _call("ts_sh_colors_fwd", lib.ts_sh_colors_fwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
-          fr.colors_dc, fr.colors_rest if fr.num_bases > 1 else None, fr.colors, fr.sh_mask,
-          fr.num_tiles_hit if fr.flags & 16 else None, s)
-    _call("ts_pack_splats", lib.ts_pack_splats, fr.n, fr.channels, 1, fr.xys, fr.radii, fr.conics, fr.colors,
-          fr.opacities, fr.cum_tiles_hit, fr.cam, fr.depths if fr.channels == 4 else None, fr.splats, s)
+    _call("ts_colors_pack_fwd", lib.ts_colors_pack_fwd, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
+          fr.colors_dc, fr.colors_rest if fr.num_bases > 1 else None, fr.sh_mask,
+          fr.num_tiles_hit if fr.flags & 16 else None, fr.channels, 1, fr.xys, fr.radii, fr.conics, fr.opacities,
+          fr.cum_tiles_hit, fr.cam, fr.depths if fr.channels == 4 else None, fr.splats, s)
     tight = fr.splats if fr.flags & 1 else None
     _call("ts_bin_count", lib.ts_bin_count, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws, s)
     _call("ts_tile_offsets", lib.ts_tile_offsets, fr.n, int(lib.ts_num_tiles(ctypes.byref(fr.cam))), fr.bin_ws,

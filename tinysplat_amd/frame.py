@@ -98,11 +98,12 @@ STRIPE_SPARSE = os.environ.get("TS_STRIPE_SPARSE", "1") != "0"
 
 DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
 
-# How the host waits for the intersection count (the one host read of a frame).  "event": synchronise on an
-# event recorded behind the copy; "spin": the pinned word is set to -1 before the copy is issued and the
-# host polls it - no driver call on the critical path (the count is >= 0, or < 0 only on int32 overflow,
-# which the event path catches the same way: see below).  Measured: config 2 (100 k Gaussians, host-bound)
-# 0.400 -> 0.378 ms/frame, config 3 unchanged.
+# How the host waits for the intersection count (the one host read of a frame; the scan kernel stores it
+# into the pinned word itself, csrc/frame.hip).  "event": synchronise on an event recorded behind the scan;
+# "spin": a sentinel (-2^31) is stored in the word before the scan is issued and the host polls the word -
+# no driver call on the critical path (a count is >= 0, or negative only on int32 overflow, which is
+# reported either way).  Measured: config 2 (100 k Gaussians, host-bound) 0.400 -> 0.378 ms/frame, config 3
+# unchanged.  One word per device: frames of a device are issued by one host thread, one after the other.
 COUNT_WAIT = os.environ.get("TS_COUNT_WAIT", "spin")
 _SPIN_LIMIT = 50_000_000
 

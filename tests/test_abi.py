@@ -55,6 +55,14 @@ def test_argument_errors_are_reported_without_a_gpu():
     cam = _lib.TsCamera(1, 1, 0, 0, 16, 16, 1, 1, 0, 1, 1.0, 0.01)
     assert lib.ts_pack_splats(4, 5, 0, *([None] * 6), cam, None, None, None) == -1
     assert lib.ts_raster_fwd(2, 0, cam, *([None] * 9)) == -1
+    # ABI 3: tile-list shape helper, fused colour stage + packing, stripe-order arguments
+    assert lib.ts_num_tiles(None) == 0 and lib.ts_num_tiles(cam) == 1
+    wide = _lib.TsCamera(1, 1, 0, 0, 80, 32, 5, 2, 0, 2, 1.0, 0.01, 1, 0)
+    assert lib.ts_num_tiles(wide) == 2 * 3                  # 5 columns of 16x16 tiles -> 3 wide columns
+    assert lib.ts_colors_pack_fwd(4, 0, 1, *([None] * 6), 5, 0, *([None] * 5), cam, None, None, None) == -1
+    assert lib.ts_colors_pack_fwd(4, 0, 1, *([None] * 6), 3, 0, *([None] * 5), cam, None, None, None) == -1
+    assert lib.ts_colors_pack_fwd(4, 2, 4, *([None] * 6), 3, 0, *([None] * 5), None, None, None, None) == -1
+    assert lib.ts_sort_tiles(-1, *([None] * 7)) == -1
 
 
 def test_ops_refuse_cpu_tensors_and_product_never_imports_the_oracle():

@@ -56,6 +56,10 @@ namespace {
 #define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0)
 #endif
 
+#ifndef TS_REDUCE_AHEAD
+#define TS_REDUCE_AHEAD 4                // rows of a Gaussian requested together by reduce_partials
+#endif
+
 #ifndef TS_RASTER_WAVES
 #define TS_RASTER_WAVES 4
 #endif
@@ -702,25 +706,53 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     const int cnt = num_tiles_hit[i];
     const long long end = cum_tiles_hit[i];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    auto add_row = [&](long long s) {
-        const float4 p0 = partials[3 * s], p1 = partials[3 * s + 1], p2 = partials[3 * s + 2];
-        a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
-        a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
-        a2.x += p2.x; a2.y += p2.y;
-    };
     if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
         const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
         for (long long s = end - cnt; s < end; ++s) {
             const unsigned int f = flags4[s];
             if (f == 0u) continue;
+            float4 p0[4], p1[4], p2[4];            // the slot's flagged rows requested together, added in order
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (f & (0xffu << (8 * k))) add_row(4 * s + k);
+            for (int k = 0; k < 4; ++k) {
+                if (f & (0xffu << (8 * k))) {
+                    p0[k] = partials[3 * (4 * s + k)]; p1[k] = partials[3 * (4 * s + k) + 1];
+                    p2[k] = partials[3 * (4 * s + k) + 2];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (f & (0xffu << (8 * k))) {
+                    a0.x += p0[k].x; a0.y += p0[k].y; a0.z += p0[k].z; a0.w += p0[k].w;
+                    a1.x += p1[k].x; a1.y += p1[k].y; a1.z += p1[k].z; a1.w += p1[k].w;
+                    a2.x += p2[k].x; a2.y += p2[k].y;
+                }
+            }
         }
     } else {
-        for (long long s = end - cnt; s < end; ++s) {
-            if (!row_flags[s]) continue;          // never written this pass (stale contents)
-            add_row(s);
+        // four slots per step: their flags, then the rows of the flagged ones, are all requested before the
+        // first addition, which happens in slot order as before (same sums, bit for bit) - a lane's walk is
+        // otherwise a chain of dependent flag -> row -> flag loads
+        constexpr int kAhead = TS_REDUCE_AHEAD;
+        for (long long s0 = end - cnt; s0 < end; s0 += kAhead) {
+            bool f[kAhead];
+            float4 p0[kAhead], p1[kAhead], p2[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) f[u] = (s0 + u < end) && row_flags[s0 + u] != 0;   // 0: never written (stale)
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (f[u]) {
+                    p0[u] = partials[3 * (s0 + u)]; p1[u] = partials[3 * (s0 + u) + 1];
+                    p2[u] = partials[3 * (s0 + u) + 2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (f[u]) {
+                    a0.x += p0[u].x; a0.y += p0[u].y; a0.z += p0[u].z; a0.w += p0[u].w;
+                    a1.x += p1[u].x; a1.y += p1[u].y; a1.z += p1[u].z; a1.w += p1[u].w;
+                    a2.x += p2[u].x; a2.y += p2[u].y;
+                }
+            }
         }
     }
     float vx = 0.f, vy = 0.f, vop = 0.f;

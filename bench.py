@@ -591,7 +591,7 @@ def main():
                       "Gaussians*pixels/s of a full training step (render RGB+depth, loss, backward, Adam)",
             "value": value, "unit": "Gaussians*pixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd "
                                    f"({'RGB+depth' if args.depth else 'RGB'}), BASELINE configs[2]"

@@ -52,3 +52,40 @@ def test_view_renderer_follows_the_reference_request_handler():
     # a second pose re-uses the pinned buffer and really moves the camera
     img2 = vr.render([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]).copy()
     assert np.abs(img2 - vr.render(pos, quat)).max() > 1.0
+
+
+def test_two_host_threads_render_on_one_device():
+    """A viewer thread beside the training loop (the reference runs its viewer server next to train.py):
+    the frame path shares one pinned count word per device, guarded by a lock - frames issued from two
+    threads must not pick up each other's intersection counts (a wrong count would mis-size the list
+    buffers).  Each thread re-renders its own scene and must see the same image every time."""
+    import threading
+
+    from tinysplat_amd import frame
+    from tinysplat_amd.rasterizer import camera_on_device
+    dev = torch.device(DEV)
+    res = {}
+
+    def work(tag, n, w, h):
+        model, cam = scene_args(n, 1, w, h, seed=tag)
+        md = model.to(dev)
+        view, projview, origin = camera_on_device(cam, dev)
+        ref = None
+        for it in range(60):
+            with torch.no_grad():
+                img, _, _ = frame.render_view(md, view[:3, :], projview, origin, cam.f_x, cam.f_y, w, h, True)
+            if ref is None:
+                ref = img.clone()
+            elif not torch.equal(ref, img):
+                res[tag] = f"frame {it} differs"
+                return
+        res[tag] = "ok"
+
+    threads = [threading.Thread(target=work, args=(1, 30000, 640, 360)),
+               threading.Thread(target=work, args=(2, 90000, 800, 450))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert res == {1: "ok", 2: "ok"}, res

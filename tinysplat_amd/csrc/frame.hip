@@ -26,8 +26,8 @@ inline bool bad(const ts_frame* f) {
 inline int num_tiles(const ts_frame* f) { return ts_num_tiles(&f->cam); }
 // device address of a pinned host word, or null (the last answer is kept: a host uses one word per device)
 inline int32_t* mapped_pointer(int32_t* host) {
-    static int32_t* last_host = nullptr;
-    static int32_t* last_dev = nullptr;
+    static thread_local int32_t* last_host = nullptr;
+    static thread_local int32_t* last_dev = nullptr;
     if (host == last_host) return last_dev;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {

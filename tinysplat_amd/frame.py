@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -103,7 +104,7 @@ DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (
 # "spin": a sentinel (-2^31) is stored in the word before the scan is issued and the host polls the word -
 # no driver call on the critical path (a count is >= 0, or negative only on int32 overflow, which is
 # reported either way).  Measured: config 2 (100 k Gaussians, host-bound) 0.400 -> 0.378 ms/frame, config 3
-# unchanged.  One word per device: frames of a device are issued by one host thread, one after the other.
+# unchanged.  One word per device, guarded by a lock from the sentinel store to the read of the count.
 COUNT_WAIT = os.environ.get("TS_COUNT_WAIT", "spin")
 _SPIN_LIMIT = 50_000_000
 
@@ -111,7 +112,9 @@ _SPIN_LIMIT = 50_000_000
 def _total_slot(dev: torch.device):
     slot = _pinned_total.get(dev.index)
     if slot is None:
-        slot = (torch.zeros((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        # the lock makes the word safe to share when two host threads render on one device (a viewer
+        # thread beside the training loop): it is held from the sentinel store to the read of the count
+        slot = (torch.zeros((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), threading.Lock())
         _pinned_total[dev.index] = slot
     return slot
 
@@ -193,7 +196,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         F.nth = view(6, torch.int32, n, (n,))
         F.cum = view(7, torch.int32, n, (n,))
         F.tile_bins = view(10, torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
-        host, event = _total_slot(dev)
+        host, event, count_lock = _total_slot(dev)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
         # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
@@ -214,39 +217,43 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         _mark("fwd:allocated + struct")
         timed = kernel_timer.enabled
         spin = COUNT_WAIT == "spin" and n > 0
-        if spin:
-            word = ctypes.c_int32.from_address(host.data_ptr())
-            word.value = -(1 << 31)                      # sentinel: no int32 prefix sum ends here (overflow wraps past it)
-        if timed:
-            _steps_project(lib, fr, s)
-            if n > 0:
-                host.copy_(F.cum[-1:], non_blocking=True)
-        else:
-            _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
-        _mark("fwd:call project")
-        event.record(torch.cuda.current_stream(dev))
-        # the kernels that do not need the count run while it travels to the host
-        if timed:
-            _steps_prepare(lib, fr, s)
-        else:
-            _lib.check(lib.ts_frame_fwd_prepare(ctypes.byref(fr), s), "ts_frame_fwd_prepare")
-        _mark("fwd:call prepare")
-        total = 0
-        if n > 0:
-            if spin:                                              # the one host wait of the path
-                k = 0
-                while word.value == -(1 << 31):
-                    k += 1
-                    if k > _SPIN_LIMIT:
-                        event.synchronize()
-                        break
-                total = int(word.value)
+        count_lock.acquire()
+        try:
+            if spin:
+                word = ctypes.c_int32.from_address(host.data_ptr())
+                word.value = -(1 << 31)                  # sentinel: no int32 prefix sum ends here (overflow wraps past it)
+            if timed:
+                _steps_project(lib, fr, s)
+                if n > 0:
+                    host.copy_(F.cum[-1:], non_blocking=True)
             else:
-                event.synchronize()
-                total = int(host[0])
-            if total < 0:
-                raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
-                                    "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
+                _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
+            _mark("fwd:call project")
+            event.record(torch.cuda.current_stream(dev))
+            # the kernels that do not need the count run while it travels to the host
+            if timed:
+                _steps_prepare(lib, fr, s)
+            else:
+                _lib.check(lib.ts_frame_fwd_prepare(ctypes.byref(fr), s), "ts_frame_fwd_prepare")
+            _mark("fwd:call prepare")
+            total = 0
+            if n > 0:
+                if spin:                                          # the one host wait of the path
+                    k = 0
+                    while word.value == -(1 << 31):
+                        k += 1
+                        if k > _SPIN_LIMIT:
+                            event.synchronize()
+                            break
+                    total = int(word.value)
+                else:
+                    event.synchronize()
+                    total = int(host[0])
+        finally:
+            count_lock.release()
+        if total < 0:
+            raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
+                                "int32 prefix sum (gsplat's cum_tiles_hit is int32 as well)")
         _mark("fwd:waited for count")
         F.total = total
         _pairs_per_tile[dev.index] = total / max(1, cam.tile_rows * cam.tile_bounds_x)

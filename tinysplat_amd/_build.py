@@ -56,8 +56,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     # developer knob for ablation runs (tools/time_raster.py): extra -D flags, implies a rebuild
     extra_env = os.environ.get("TS_EXTRA_HIPCC_FLAGS", "").split()
-    headers = [CSRC / "splat_math.h", CSRC.parent.parent / "include" / "tinysplat_hip.h",
-               Path(__file__)]          # the flags live in this file
+    headers = [*sorted(CSRC.glob("*.h")), CSRC.parent.parent / "include" / "tinysplat_hip.h",
+               Path(__file__)]          # every header of csrc/ (splat_math.h, pack.h, ...); the flags live in this file
     objs = []
     relink = False
     for src, extra in SOURCES:

@@ -17,7 +17,10 @@ the exponent sigma = 0.5 (A dx^2 + C dy^2) + B dx dy in float32, and for a needl
 terms are ~10^3..10^4 and cancel, so any float32 implementation (gsplat's, the oracle run in float32,
 this one) is off by a few eps32 * |terms| there; the oracle reports that bound per pixel (`cond`) and
 which pixels have a discrete decision within its reach (`margin_f32`: no weight in the loss).  For
-ordinary Gaussians the bound is below 1e-6 and the check is the plain 1e-5.  Gradients: within
+ordinary Gaussians the bound is below 1e-6 and the check is the plain 1e-5.  Needle cases also get the
+image's sensitivity to a 1-ulp difference in exp(log-scales) added (measured per case, see run_case):
+the adapter's exp is evaluated by different libraries in the reference, the oracle and this build.
+Gradients: within
 max(2e-5, 0.5 eps32 max|terms|) * max(1, |ref|_inf) per tensor, no outliers; means / scales / quats of needle
 scenes against the oracle run end to end in float64, allowing 4 x what the float32 projection VJP loses
 on exact inputs (gsplat's formula -X G X with a near-singular conic; measured per case on the host).
@@ -158,10 +161,25 @@ def run_case(case):
     vis = f["radii"] > 0
     c_max = max(1.0, float(f["colors"][vis].detach().abs().max()) if vis.any() else 0.0, max(case["background"]))
     d_max = max(1.0, float(f["depths"][vis].detach().abs().max()) if vis.any() else 0.0)
+    # Needles make the PROJECTION ill-conditioned too: the adapter hands gsplat exp(log-scales), and a 1-ulp
+    # difference in that exp - torch's CPU exp (the oracle), torch's GPU exp (what the reference would feed
+    # gsplat) and the expf folded into ts_project_fwd differ in ~7 % of the elements - moves a needle's conic
+    # by up to 3e-4 relative.  What that does to the image is measured per case: the oracle frame is
+    # rendered once more with the log-scales nudged by +-1 ulp (alternating signs) and four times the
+    # per-pixel difference is added to the tolerance.  Ordinary scenes: the difference is ~1e-7.
+    jitter = {"rgb": 0.0, "depth": 0.0}
+    if case.get("aniso") == "needles":
+        nudged, _ = build(case)
+        sign = torch.where(torch.arange(nudged.scales.numel()).reshape(nudged.scales.shape) % 2 == 0, 1.0, -1.0)
+        nudged.scales = nudged.scales + sign * 1.2e-7
+        f2 = oracle_frame(nudged, cam, (w, h), depth=True, raster_dtype=torch.float64)
+        if torch.equal(f2["radii"], f["radii"]):
+            jitter = {"rgb": 4.0 * (f2["rgb"] - f["rgb"].detach()).abs().max(dim=2).values,
+                      "depth": 4.0 * (f2["depth"] - f["depth"].detach()).abs()}
     for got, want, base, scale, nm in ((rgb, f["rgb"], 1e-5, c_max, "rgb"),
                                        (extras["depth"], f["depth"], 1e-4, d_max, "depth")):
         err = (got.detach().cpu().double() - want.detach().double()).abs()
-        tol = base + scale * aux["cond"]
+        tol = base + scale * aux["cond"] + jitter[nm]
         if err.dim() == 3:
             tol = tol[..., None]
         over = (err > tol) & (stable[..., None] if err.dim() == 3 else stable)

@@ -18,10 +18,12 @@ terms are ~10^3..10^4 and cancel, so any float32 implementation (gsplat's, the o
 this one) is off by a few eps32 * |terms| there; the oracle reports that bound per pixel (`cond`) and
 which pixels have a discrete decision within its reach (`margin_f32`: no weight in the loss).  For
 ordinary Gaussians the bound is below 1e-6 and the check is the plain 1e-5.  Needle cases also get the
-image's sensitivity to a 1-ulp difference in exp(log-scales) added (measured per case, see run_case):
+image's (and every gradient's) sensitivity to a 1-ulp difference in exp(log-scales) added (measured per
+case, see run_case):
 the adapter's exp is evaluated by different libraries in the reference, the oracle and this build.
 Gradients: within
-max(2e-5, 0.5 eps32 max|terms|) * max(1, |ref|_inf) per tensor, no outliers; means / scales / quats of needle
+max(2e-5, 0.5 eps32 max|terms|) * max(1, |ref|_inf) per tensor (1e-4 on needle scenes: float32
+accumulation of moments whose terms are ~1e5 times their sum), no outliers; means / scales / quats of needle
 scenes against the oracle run end to end in float64, allowing 4 x what the float32 projection VJP loses
 on exact inputs (gsplat's formula -X G X with a near-singular conic; measured per case on the host).
 
@@ -132,7 +134,15 @@ def vjp_float32_floor(model, cam, dims, f64, r64):
     e_s = float((v_s.double() * torch.exp(r64.scales.detach()) - g_s).abs().max()) / max(1.0, float(g_s.abs().max()))
     g_m = r64.means.grad
     e_m = float((v_m.double() - g_m).abs().max()) / max(1.0, float(g_m.abs().max()))
-    return {"means": max(e_m, e_s), "scales": e_s, "quats": e_s}       # quats share the scales' path (v_M)
+    # the host function differentiates w.r.t. the normalised quaternion it is handed; the model holds the raw
+    # one: g_raw = (g - q_hat (q_hat . g)) / |q|
+    q = r64.quats.detach()
+    qn = q / q.norm(dim=1, keepdim=True)
+    g_n = v_q.double()
+    g_raw = (g_n - qn * (qn * g_n).sum(dim=1, keepdim=True)) / q.norm(dim=1, keepdim=True)
+    g_q = r64.quats.grad
+    e_q = float((g_raw - g_q).abs().max()) / max(1.0, float(g_q.abs().max()))
+    return {"means": max(e_m, e_s), "scales": e_s, "quats": max(e_q, e_s)}
 
 
 def run_case(case):
@@ -168,14 +178,23 @@ def run_case(case):
     # rendered once more with the log-scales nudged by +-1 ulp (alternating signs) and four times the
     # per-pixel difference is added to the tolerance.  Ordinary scenes: the difference is ~1e-7.
     jitter = {"rgb": 0.0, "depth": 0.0}
+    grad_jitter = {}                             # tensor name -> the same measurement for its gradient (relative)
     if case.get("aniso") == "needles":
         nudged, _ = build(case)
         sign = torch.where(torch.arange(nudged.scales.numel()).reshape(nudged.scales.shape) % 2 == 0, 1.0, -1.0)
         nudged.scales = nudged.scales + sign * 1.2e-7
+        nudged.requires_grad_(True)
         f2 = oracle_frame(nudged, cam, (w, h), depth=True, raster_dtype=torch.float64)
         if torch.equal(f2["radii"], f["radii"]):
-            jitter = {"rgb": 4.0 * (f2["rgb"] - f["rgb"].detach()).abs().max(dim=2).values,
-                      "depth": 4.0 * (f2["depth"] - f["depth"].detach()).abs()}
+            jitter = {"rgb": 4.0 * (f2["rgb"] - f["rgb"]).detach().abs().max(dim=2).values,
+                      "depth": 4.0 * (f2["depth"] - f["depth"]).detach().abs()}
+            loss2 = (f2["rgb"] * w_rgb).sum() + (f2["depth"] * w_d).sum()
+            if loss2.requires_grad and loss.requires_grad:
+                loss2.backward()
+                for nm in ("means", "scales", "quats", "opacities", "colors_dc", "colors_rest"):
+                    g1, g2 = getattr(ref, nm).grad, getattr(nudged, nm).grad
+                    if g1 is not None and g2 is not None and g1.numel():
+                        grad_jitter[nm] = float((g2 - g1).abs().max()) / max(1.0, float(g1.abs().max()))
     for got, want, base, scale, nm in ((rgb, f["rgb"], 1e-5, c_max, "rgb"),
                                        (extras["depth"], f["depth"], 1e-4, d_max, "depth")):
         err = (got.detach().cpu().double() - want.detach().double()).abs()
@@ -188,6 +207,11 @@ def run_case(case):
     live = stable & (aux["mag_max"] > 0)
     mag = float(aux["mag_max"][live].max()) if live.any() else 0.0
     rel = max(2e-5, 0.25 * O.F32_SIGMA_ULPS * 5.96e-8 * mag)     # sums over pixels average the per-pixel bound down
+    if case.get("aniso") == "needles":
+        # a needle's moments S v dx^2, S v dx dy, ... run over thousands of pixels with terms ~1e5 times the
+        # net sum: float32 accumulation (gsplat's atomicAdd as much as the rows here) leaves ~sqrt(N) eps of
+        # the terms, measured up to 4e-5 of the largest gradient entry with every other source excluded
+        rel = max(rel, 1e-4)
     names = ("means", "scales", "quats", "opacities", "colors_dc", "colors_rest")
     # Needles also make the PROJECTION backward ill-conditioned: the conic is the inverse of a near-singular
     # 2x2 covariance, and gsplat's VJP  v_cov2d = -X G X  (X = conic, G = v_conic; the same formula here)
@@ -214,10 +238,11 @@ def run_case(case):
         if b.grad is None:
             assert a.grad is None or a.grad.numel() == 0 or float(a.grad.abs().max()) == 0.0, nm
             continue
+        allow = max(rel, 4.0 * grad_jitter.get(nm, 0.0))
         if exact is not None and nm in floor:
-            check_grad(nm, a.grad, getattr(exact, nm).grad, rel=max(rel, 4.0 * floor[nm]))
+            check_grad(nm, a.grad, getattr(exact, nm).grad, rel=max(allow, 4.0 * floor[nm]))
         else:
-            check_grad(nm, a.grad, b.grad, rel=rel)
+            check_grad(nm, a.grad, b.grad, rel=allow)
     if f["xys"].grad is not None:
         check_grad("xys.grad", extras["xys"].grad, f["xys"].grad, rel=rel)
     return dict(visible=int(vis.sum()), stable=round(float(stable.float().mean()), 4), mag_max=round(mag, 1),

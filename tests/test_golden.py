@@ -163,3 +163,47 @@ def test_viewer_pose_handling_matches_reference():
     for p, q, v in zip(z["positions"], z["quats"], z["view_matrices"]):
         cam.update_view_matrix(np.asarray(p, dtype=np.float32), np.asarray(q, dtype=np.float32))
         assert np.array_equal(cam.view_matrix.numpy(), v)
+
+
+def test_scene_funnel_proj_matrix_rescale_and_sh_helpers_match_reference():
+    """SURVEY 8(a) rows A6 / A7 / A10 against tests/golden/scene_funnel.npz, captured from the reference's own
+    Scene / Camera / utils (tests/golden/make_scene_fixtures.py): Scene.render hands (camera, dims,
+    model.active_sh_degree) to the rasterizer (scene.py:222-223), update_proj_matrix at a second fov with
+    non-default and default near / far (scene.py:112-121), Camera.rescale incl. its fov-angle quirk
+    (scene.py:123-128), RGB2SH / SH2RGB (utils.py:7-13) - all bit for bit."""
+    from tinysplat_amd import RGB2SH, SH2RGB, Scene
+    from tinysplat_amd.synthetic import PinholeCamera
+    z = np.load(GOLD / "scene_funnel.npz")
+    cam = PinholeCamera.look_at_origin_plus_z(160, 96, fov_x_deg=float(np.degrees(2 * np.arctan(128 / 300.0))))
+    fx, fy, near, far = (float(v) for v in z["proj_fov"])
+    cam.update_proj_matrix(fx, fy, near, far)
+    assert np.array_equal(cam.proj_matrix.numpy(), z["proj_matrix_2"])
+    cam.update_proj_matrix(fx, fy)
+    assert np.array_equal(cam.proj_matrix.numpy(), z["proj_matrix_2_defaults"])
+    cam.rescale(float(z["rescale_factor"]))
+    assert [cam.width, cam.height] == list(z["rescaled_wh"])
+    assert np.array_equal(np.array([cam.fov_x, cam.fov_y]), z["rescaled_fov"])
+    assert np.array_equal(cam.proj_matrix.numpy(), z["rescaled_proj_matrix"])
+
+    calls = []
+
+    class Model:
+        active_sh_degree = 2
+
+    def recorder(*a, **kw):
+        calls.append((a, kw))
+        return "rgb", {"extras": 1}
+
+    sc = Scene([cam], Model(), recorder)
+    assert sc.render(cam, (64, 48)) == ("rgb", {"extras": 1}) and sc.render(cam) == ("rgb", {"extras": 1})
+    assert all(kw == {} and len(a) == 3 and a[0] is cam for a, kw in calls)
+    assert list(calls[0][0][1]) == list(z["render_dims"][0]) and (calls[1][0][1] is None) == bool(z["render_dims_none"])
+    assert [calls[0][0][2], calls[1][0][2]] == list(z["render_sh_degree"])
+    sc.rescale(2.0)
+    assert [cam.width, cam.height] == list(z["scene_rescaled_wh"])
+    assert sc.get_random_camera(1) is cam
+
+    rgb = torch.from_numpy(z["rgb"])
+    assert torch.equal(RGB2SH(rgb), torch.from_numpy(z["rgb2sh"]))
+    assert torch.equal(SH2RGB(rgb), torch.from_numpy(z["sh2rgb"]))
+    assert torch.equal(SH2RGB(RGB2SH(rgb)), torch.from_numpy(z["sh2rgb_of_rgb2sh"]))

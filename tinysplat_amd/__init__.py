@@ -6,6 +6,8 @@ model_gaussian.py:14) plus the render adapter.  ``tinysplat_amd.sh`` mirrors ``g
 from .ops import (deg_from_sh, num_sh_bases, project_gaussians, rasterize_gaussians,
                   spherical_harmonics)
 from .rasterizer import GaussianRasterizer
+from .scene import Scene
+from .synthetic import RGB2SH, SH2RGB
 
 __all__ = ["project_gaussians", "rasterize_gaussians", "spherical_harmonics", "num_sh_bases",
-           "deg_from_sh", "GaussianRasterizer"]
+           "deg_from_sh", "GaussianRasterizer", "Scene", "RGB2SH", "SH2RGB"]

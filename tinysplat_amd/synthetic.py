@@ -65,8 +65,10 @@ class PinholeCamera:
         proj[2, 2] = (zfar + znear) / (zfar - znear)
         proj[2, 3] = -1.0 * zfar * znear / (zfar - znear)
         proj[3, 2] = 1
-        return cls(torch.as_tensor(view, dtype=torch.float32),
-                   torch.as_tensor(proj, dtype=torch.float32), f_x, f_y, width, height)
+        cam = cls(torch.as_tensor(view, dtype=torch.float32),
+                  torch.as_tensor(proj, dtype=torch.float32), f_x, f_y, width, height)
+        cam.fov_x, cam.fov_y = fov_x, fov_y
+        return cam
 
 
 def _update_view_matrix(self, position, quat) -> None:
@@ -81,6 +83,47 @@ def _update_view_matrix(self, position, quat) -> None:
 
 
 PinholeCamera.update_view_matrix = _update_view_matrix
+
+
+def _update_proj_matrix(self, fov_x: float, fov_y: float, znear: float = 0.001, zfar: float = 1000) -> None:
+    """scene.py:112-121: the projection matrix from the two field-of-view angles (radians), built in
+    float64 numpy and stored float32; also records fov_x / fov_y on the camera as the reference does."""
+    self.fov_x = fov_x
+    self.fov_y = fov_y
+    proj = np.zeros((4, 4))
+    proj[0, 0] = 1. / np.tan(fov_x / 2)
+    proj[1, 1] = 1. / np.tan(fov_y / 2)
+    proj[2, 2] = (zfar + znear) / (zfar - znear)
+    proj[2, 3] = -1. * zfar * znear / (zfar - znear)
+    proj[3, 2] = 1
+    self.proj_matrix = torch.as_tensor(proj, dtype=torch.float32)
+
+
+def _rescale(self, factor: float) -> None:
+    """scene.py:123-128, quirk included: width / height are truncated products, and the fov ANGLES (not
+    their tangents) are multiplied by the factor before the matrix is rebuilt with the default near / far.
+    f_x / f_y are left as they were, as in the reference."""
+    self.width = int(self.width * factor)
+    self.height = int(self.height * factor)
+    self.fov_x = self.fov_x * factor
+    self.fov_y = self.fov_y * factor
+    self.update_proj_matrix(self.fov_x, self.fov_y)
+
+
+PinholeCamera.update_proj_matrix = _update_proj_matrix
+PinholeCamera.rescale = _rescale
+
+
+def RGB2SH(rgb):
+    """utils.py:7-9: colour -> DC spherical-harmonics coefficient."""
+    C0 = 0.28209479177387814
+    return (rgb - 0.5) / C0
+
+
+def SH2RGB(sh):
+    """utils.py:11-13."""
+    C0 = 0.28209479177387814
+    return sh * C0 + 0.5
 
 
 class SplatModel:

@@ -17,7 +17,7 @@ from torch import Tensor
 
 from . import _lib
 from .ops import _call, _f32c, _need_hip, _ptr, _stream
-from .rasterizer import GaussianRasterizer
+from .scene import Scene
 
 # learning-rate defaults of scripts/train.py:187-193, in the order of SplatModel.parameters()
 DEFAULT_LRS = {"means": 0.00016, "colors_dc": 0.0025, "colors_rest": 0.000125, "scales": 0.005,
@@ -164,10 +164,12 @@ class TrainStep:
     """render -> loss -> backward -> Adam, one call per iteration (train.py:45-106 minus policy)."""
 
     def __init__(self, model, device, lambda_dssim: float = 0.2, lambda_depth: float = 0.2,
-                 lrs: Optional[Dict[str, float]] = None):
+                 lrs: Optional[Dict[str, float]] = None, scene: Optional[Scene] = None):
         self.model, self.device = model, torch.device(device)
         self.lambda_dssim, self.lambda_depth = lambda_dssim, lambda_depth
-        self.rasterizer = GaussianRasterizer(model, None, device=self.device)
+        # the reference's loop renders through scene.render(camera) (train.py:55 -> scene.py:222-223)
+        self.scene = scene if scene is not None else Scene([], model, device=self.device)
+        self.rasterizer = self.scene.rasterizer
         model.requires_grad_(True)
         self.optimizer = Adam({n: getattr(model, n) for n in PARAM_ORDER}, lrs)
 
@@ -175,7 +177,7 @@ class TrainStep:
                  densifier=None, step: Optional[int] = None):
         """``densifier`` (densify.Densifier) + ``step`` add train.py:99-102 after the Adam update:
         gradient accumulation and, on the policy's steps, clone / split / prune."""
-        rgb, extras = self.rasterizer(camera, None, self.model.active_sh_degree)
+        rgb, extras = self.scene.render(camera)
         frame = getattr(rgb, "_base", None)
         if (frame is not None and frame.dim() == 3 and frame.shape[2] == 4 and frame.is_contiguous()
                 and extras["depth"]._base is frame):
@@ -241,8 +243,9 @@ def fit(model, cameras, targets, device, max_iter: int, depth_targets=None,
     densification (:99-102).  Dataset loading, the opacity / density regularisers of the surface
     extension (:71-90), metrics and checkpoints stay with the caller (``on_step(step, out)``)."""
     dev = torch.device(device)
-    step_fn = TrainStep(model, dev, lambda_dssim, lambda_depth, lrs)
-    pick = CameraSampler(len(cameras), rng)
+    scene = Scene(cameras, model, device=dev, rng=rng)
+    step_fn = TrainStep(model, dev, lambda_dssim, lambda_depth, lrs, scene=scene)
+    pick = scene._sampler
     out = None
     for step in range(1, int(max_iter) + 1):
         if step % sh_increment_interval == 0 and model.active_sh_degree < max_sh_degree:

@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .rasterizer import GaussianRasterizer
+from .scene import Scene
 
 
 class ViewRenderer:
@@ -27,7 +27,8 @@ class ViewRenderer:
         self.device = torch.device(device)
         self.model = model
         self.camera = copy.copy(camera)
-        self.rasterizer = GaussianRasterizer(model, [self.camera], device=self.device)
+        self.scene = Scene([self.camera], model, device=self.device)      # viewer.py:61-62, :92
+        self.rasterizer = self.scene.rasterizer
         self._pinned = {}
 
     def _host_buffer(self, shape, dtype):
@@ -52,7 +53,7 @@ class ViewRenderer:
                                        np.asarray(quat, dtype=np.float32))                 # :84-87
         with torch.no_grad():                                                               # :90
             self.model.background = torch.zeros(3, device=self.device)                     # :91
-            img, _extras = self.rasterizer(self.camera, None, self.model.active_sh_degree)  # :92
+            img, _extras = self.scene.render(self.camera)                                   # :92
             img = img * 255                                                                 # :94
             if as_uint8:
                 img = img.clamp_(0, 255).round_().to(torch.uint8)

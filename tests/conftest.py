@@ -60,6 +60,14 @@ def fptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """TS_PARITY_REPORT_ONLY=1 turns helpers.check_grad into a recorder (survey runs): such a session must
+    never count as a green test run."""
+    if os.environ.get("TS_PARITY_REPORT_ONLY") == "1" and session.exitstatus == 0:
+        session.exitstatus = 1
+        print("\nTS_PARITY_REPORT_ONLY=1: gradient checks were recorded, not asserted - session marked FAILED")
+
+
 def pytest_terminal_summary(terminalreporter):
     """Worst measured error per compared gradient tensor (helpers.check_grad)."""
     try:
@@ -68,9 +76,10 @@ def pytest_terminal_summary(terminalreporter):
         return
     if not PARITY_LOG:
         return
-    lines = ["test | tensor | max abs err | |ref|_inf | tolerance | err/tol | fraction over"]
-    for test, what, worst, mag, tol, frac in PARITY_LOG:
-        lines.append(f"{test} | {what} | {worst:.3e} | {mag:.3e} | {tol:.3e} | {worst / tol if tol else 0:.3f} | {frac:.2e}")
+    lines = ["test | tensor | max abs err | |ref|_inf | tolerance | err/tol | fraction over | fraction within 1e-5 abs"]
+    for test, what, worst, mag, tol, frac, within in PARITY_LOG:
+        lines.append(f"{test} | {what} | {worst:.3e} | {mag:.3e} | {tol:.3e} | {worst / tol if tol else 0:.3f} | "
+                     f"{frac:.2e} | {within:.6f}")
     terminalreporter.write_sep("-", "measured gradient errors (helpers.check_grad)")
     for ln in lines:
         terminalreporter.write_line(ln)

@@ -3,7 +3,7 @@
 configs[1] - 100 k Gaussians, SH 3, 1920x1080, fwd+bwd on one MI355X "vs gsplat numerics": the
 adapter's one-node frame (rasterize.py:26-62) against the same recipe run with the float32 oracle
 on the host (one frame, ~1 min of CPU): radii / num_tiles_hit / tile_bins / gaussian_ids_sorted
-bit-exact, rgb <= 1e-5 and depth <= 1e-4 at threshold-stable pixels with no outliers, the six
+bit-exact, rgb <= 1e-5 and depth <= 1e-5 max(1, |depth|) at threshold-stable pixels with no outliers, the six
 parameter gradients and xys.grad within the scaled tolerance, worst errors reported.
 
 configs[4] - 5 M Gaussians, 3840x2160, RGB + depth: far beyond the oracle, so size-independent
@@ -62,7 +62,7 @@ def test_config2_full_size_vs_oracle():
     assert torch.equal(b.gaussian_ids_sorted.cpu(), f["aux"]["gaussian_ids_sorted"])
     # rendered values at threshold-stable pixels: no outliers
     assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb")
-    assert_close_masked(extras["depth"], f["depth"], 1e-4, stable, what="depth")     # depth values reach 10
+    assert_close_masked(extras["depth"], f["depth"], 1e-5, stable, what="depth", scale_by_value=True)     # depth values reach 10
     # gradients: the six parameters and xys.grad (model_gaussian.py:130-132)
     assert extras["xys"].grad is not None
     for a, b_, nm in [(md.means, m32.means, "means"), (md.scales, m32.scales, "scales"),

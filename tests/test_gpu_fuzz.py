@@ -1,7 +1,7 @@
 """The first cases of tools/fuzz_frame.py as tests: randomised whole-frame scenes (sizes down to one
 Gaussian and images smaller than a tile, SH degrees 0-3, footprints from sub-pixel to tile-covering,
 opaque / faint opacity laws, Gaussians behind the near plane, duplicated Gaussians with equal depths)
-on the HIP path against the oracle frame - radii exact, RGB 1e-5, depth 1e-4 at stable pixels, every
+on the HIP path against the oracle frame - radii exact, RGB 1e-5, depth 1e-5 max(1, |depth|) at stable pixels, every
 gradient within 2e-5 * max(1, |ref|_inf) without outliers."""
 import sys
 from pathlib import Path

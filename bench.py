@@ -107,6 +107,25 @@ def measure_read_bandwidth(dev, gib: float = 2.0, reps: int = 10) -> float:
     return best
 
 
+GATHER_CAL_RECORDS = 4_000_000       # table of 48-byte records (192 MB: beyond the L2s, inside the Infinity Cache)
+GATHER_CAL_GATHERS = 8_000_000       # random record reads of the calibration launch
+
+
+def run_gather_calibration(dev) -> None:
+    """One launch of ts_bench_gather48 on a known record count (the PMC passes read its FETCH_SIZE)."""
+    from tinysplat_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    table = torch.ones((GATHER_CAL_RECORDS, 12), dtype=torch.float32, device=dev)
+    ids = torch.randint(0, GATHER_CAL_RECORDS, (GATHER_CAL_GATHERS,), generator=g, dtype=torch.int32).to(dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):
+        _lib.check(lib.ts_bench_gather48(table.data_ptr(), ids.data_ptr(), GATHER_CAL_GATHERS, sink.data_ptr(), s),
+                   "ts_bench_gather48")
+    torch.cuda.synchronize()
+
+
 # --------------------------------------------------------------------------------------------------
 # CPU baseline (SURVEY.md 8(d) D6): the oracle on the host cores, beside the GPU number
 # --------------------------------------------------------------------------------------------------
@@ -256,7 +275,7 @@ KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel",
                    ("sh_colors_fwd_kernel", "ts_colors_pack_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_colors_pack_fwd"),
                    ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
                    ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
-                   ("pack_splats_kernel", "ts_pack_splats")]
+                   ("pack_splats_kernel", "ts_pack_splats"), ("gather48_kernel", "gather48_calibration")]
 
 
 def collect_pmc(workload_argv, timeout_s: float = 150.0):
@@ -274,7 +293,8 @@ def collect_pmc(workload_argv, timeout_s: float = 150.0):
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
                    sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1",
-                   "--profile-steps", "1", "--no-cpu-baseline", "--no-pmc", "--no-bandwidth"] + workload_argv
+                   "--profile-steps", "1", "--no-cpu-baseline", "--no-pmc", "--no-bandwidth",
+                   "--gather-calibration"] + workload_argv
             env = dict(os.environ, TMPDIR="/tmp")
             for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k_, None)
@@ -354,6 +374,9 @@ def main():
                     help="BASELINE.json config shortcut: 2 = 100k/1080p, 3 = 1M/1080p (default), "
                          "5 = 5M/4K with depth")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--gather-calibration", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-rgbd-figure", action="store_true",
+                    help="do not time the RGB + depth frame (the reference's full adapter call) beside the RGB headline")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
@@ -467,6 +490,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    if args.gather_calibration and rank == 0:
+        run_gather_calibration(dev)
+
+    # second figure: the reference's whole adapter call renders RGB AND depth (rasterize.py:47-51); the headline
+    # workload (D5) is RGB only, so the like-for-like frame is timed beside it
+    rgbd = None
+    if (world == 1 and not args.depth and not args.forward_only and not args.train_step and args.emulate_ranks <= 1
+            and not args.force_dist and not args.no_rgbd_figure):
+        def step_rgbd():
+            for p_ in model.parameters():
+                p_.grad = None
+            rgb, extras = adapter(cam, (w, h), sh)
+            ((rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()).backward()
+        for _ in range(3):
+            step_rgbd()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k_rgbd = max(5, min(args.steps, 20))
+        for _ in range(k_rgbd):
+            step_rgbd()
+        torch.cuda.synchronize()
+        dt_rgbd = (time.perf_counter() - t1) / k_rgbd
+        rgbd = {"workload": "the same scene through the adapter call with its depth output (rasterize.py:26-62): RGB + "
+                            "depth composited in one 4-channel pass, both differentiated",
+                "ms_per_step": dt_rgbd * 1e3, "value": n * w * h / dt_rgbd, "steps": k_rgbd}
+        for _ in range(2):          # back to the headline workload's binning statistics
+            step()
+
     # scene statistics + per-entry timing (after the timed region)
     ops.kernel_timer.start()
     for _ in range(max(1, args.profile_steps)):
@@ -506,7 +557,10 @@ def main():
         dom_ms = stage_ms[dom_stage]
         dom_entry = max(stage_entries[dom_stage], key=lambda e: per_step[e])
         p_local = p if (world == 1 and args.emulate_ranks <= 1) else binning.cam.tile_rows * 16 * w
-        a_bytes = stage_alg_bytes(dom_stage, n, isects, p_local, tiles, k, ch)
+        # D5 priced with the pairs a launch actually processes (the tight lists); the figure with gsplat's
+        # bounding-box pair count - pairs that are never scattered, sorted or composited - is kept beside it
+        a_bytes = stage_alg_bytes(dom_stage, n, isects_listed, p_local, tiles, k, ch)
+        a_bytes_bbox = stage_alg_bytes(dom_stage, n, isects, p_local, tiles, k, ch)
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
         full_tiles = (w + 15) // 16 * ((h + 15) // 16)
         frame_bytes = frame_alg_bytes(n, isects_total, p, full_tiles, k, args.depth)
@@ -533,9 +587,21 @@ def main():
                 except Exception:
                     pmc = None
 
+        # FETCH_SIZE correction.  Wide coalesced reads: x2 (gfx950 tallies 128-B requests as 64 B,
+        # MI355X_MICROARCH.md HBM section).  Gathers of 48-byte records are not covered by that calibration, so
+        # the PMC passes also run ts_bench_gather48 on a known count: a 16-byte-aligned 48-byte record lies in
+        # 1.25 128-byte lines on average (160 B fetched per record when every gather misses the L2s).  The raw
+        # FETCH_SIZE per record decides the factor applied to the gather-dominated kernels: ~80 B -> the same
+        # half-tally (x2), ~160 B -> x1.
+        GATHER_ENTRIES = ("ts_raster_fwd", "ts_raster_bwd", "ts_reduce_partials")
+        cal = (pmc or {}).get("gather48_calibration")
+        gather_factor, gather_raw = 2.0, None
+        if cal and "fetch_kib" in cal:
+            gather_raw = cal["fetch_kib"] * 1024.0 / GATHER_CAL_GATHERS
+            gather_factor = 2.0 if gather_raw < 120.0 else 1.0
+
         def traffic_of(entries):
-            """HBM bytes per step of the entries: (2 x FETCH_SIZE + WRITE_SIZE) KiB - gfx950 tallies
-            128-B read requests as 64 B (MI355X_MICROARCH.md, HBM section)."""
+            """HBM bytes per step of the entries: (factor x FETCH_SIZE + WRITE_SIZE) KiB."""
             if not pmc:
                 return None
             tot = 0.0
@@ -544,24 +610,31 @@ def main():
                 if not c or "fetch_kib" not in c or "write_kib" not in c:
                     return None
                 launches = per_entry[e][0] / max(1, args.profile_steps)
-                tot += (2.0 * c["fetch_kib"] + c["write_kib"]) * 1024.0 * launches
+                f_ = gather_factor if e in GATHER_ENTRIES else 2.0
+                tot += (f_ * c["fetch_kib"] + c["write_kib"]) * 1024.0 * launches
             return tot
 
         _log(f"timed: {ms:.3f} ms/step")
         bw_meas = None if args.no_bandwidth else measure_read_bandwidth(dev)
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "frac_gsplat_pairs": a_bytes_bbox / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "alg_bytes_per_launch": a_bytes, "alg_bytes_per_launch_gsplat_pairs": a_bytes_bbox,
+               "pairs_priced": isects_listed, "pairs_gsplat_lists": isects,
+               "traffic": traffic_of(stage_entries[dom_stage]), "traffic_source": pmc_src,
+               "fetch_correction": {"streaming": 2.0, "gather_kernels": gather_factor,
+                                    "gather48_raw_fetch_bytes_per_record": gather_raw,
+                                    "gather48_expected_bytes_per_record": 160.0,
+                                    "gather_kernels_list": list(GATHER_ENTRIES)},
+               "peak_read_measured": bw_meas,
+               "frac_of_measured": None if bw_meas is None else achieved / bw_meas}
         roofline = {"bound": "hbm", "stage": dom_stage, "kernel": dom_entry,
-                    "entries": sorted(stage_entries[dom_stage]),
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(stage_entries[dom_stage]),
-                    "traffic_source": pmc_src, "alg_bytes_per_launch": a_bytes, "kernel_ms": dom_ms,
-                    "kernel_ms_dominant_entry": per_step[dom_entry],
-                    "peak_read_measured": bw_meas,
-                    "frac_of_measured": None if bw_meas is None else achieved / bw_meas}
-        frame_gbs = frame_bytes / (ms * 1e-3) / 1e9
-        frame_roofline = {"alg_bytes": frame_bytes, "achieved": frame_gbs, "peak": HBM_PEAK_GBS,
+                    "entries": sorted(stage_entries[dom_stage]), "kernel_ms": dom_ms,
+                    "kernel_ms_dominant_entry": per_step[dom_entry], **hbm}
+        frame_gbs = frame_bytes_listed / (ms * 1e-3) / 1e9
+        frame_roofline = {"alg_bytes": frame_bytes_listed, "achieved": frame_gbs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS,
-                          "alg_bytes_listed": frame_bytes_listed,
-                          "frac_listed": frame_bytes_listed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "alg_bytes_gsplat_pairs": frame_bytes,
+                          "frac_gsplat_pairs": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "peak_read_measured": bw_meas,
                           "frac_of_measured": None if bw_meas is None else frame_gbs / bw_meas}
         # D4 secondary figure: the compositing kernels against the vector ALUs
@@ -585,6 +658,19 @@ def main():
                             "tflops_if_all_fma": 2.0 * lane_ops / t_s / 1e12,
                             "peak_tflops_packed": VALU_FP32_PEAK_TFLOPS})
             valu[e] = ent
+        # the BINDING resource of the dominant kernel: the two compositing kernels issue vector-ALU instructions
+        # ~90 % of their time (PMC: SQ_INSTS_VALU against the 4-cycle wave64 issue rate) and
+        # sit far below the HBM roofline of their stage, so the line names "valu" and keeps the HBM figures under
+        # roofline.hbm.  Without the PMC pass (or for an HBM-bound dominant kernel) the HBM figures stay on top.
+        v_dom = valu.get(dom_entry)
+        if v_dom and "frac" in v_dom and v_dom["frac"] > hbm["frac"]:
+            roofline = {"bound": "valu", "stage": dom_stage, "kernel": dom_entry,
+                        "entries": sorted(stage_entries[dom_stage]), "kernel_ms": dom_ms,
+                        "kernel_ms_dominant_entry": per_step[dom_entry],
+                        "achieved": v_dom["lane_ops_per_s"] / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12,
+                        "unit": "T lane-ops/s (wave64 VALU instructions x 64; peak = one instruction per 4 cycles per SIMD)",
+                        "frac": v_dom["frac"], "valu_insts_per_listed_pair": v_dom["valu_insts_per_listed_pair"],
+                        "traffic": hbm["traffic"], "hbm": hbm}
         out = {
             "metric": "Gaussians*pixels/s forward only (no_grad, RGB+depth)" if args.forward_only else
                       "Gaussians*pixels/s fwd+bwd" if not args.train_step else
@@ -618,6 +704,8 @@ def main():
             "stages_ms": {k_: round(v, 4) for k_, v in sorted(stage_ms.items())},
             "entries_ms": {k_: round(v, 4) for k_, v in sorted(per_step.items())},
         }
+        if rgbd is not None:
+            out["frame_rgbd"] = rgbd
         if pmc:
             out["pmc_per_dispatch"] = {e: {k_: round(v, 1) for k_, v in c.items()} for e, c in sorted(pmc.items())}
         if world == 1 and not args.no_cpu_baseline:

@@ -391,6 +391,9 @@ int ts_ply_unpack_rows(int32_t n, int32_t k_rest, const float* rows, float* mean
 /* Streaming read of n_floats float32 (16-byte loads, grid-stride): the read-bandwidth microbenchmark
  * that SURVEY.md 8(d) D1 asks the roofline to be quoted against as well.  sink: >= 1 float. */
 int ts_bench_stream_read(const float* src, int64_t n_floats, float* sink, void* stream);
+/* Gather of m 48-byte records records[ids[j]] (three 16-byte loads per lane, the compositing kernels' access
+ * pattern) on a known record count: calibrates rocprofv3's FETCH_SIZE for gathers.  sink: >= 1 float. */
+int ts_bench_gather48(const float* records, const int32_t* ids, int64_t m, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_bench_stream_read": (c_int32, [_P, c_int64, _P, _P]),
+    "ts_bench_gather48": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ts_photometric_ws_floats": (c_int64, [c_int32, c_int32]),
     "ts_photometric_loss": (c_int32, [c_int32, c_int32, _P, _P, c_float, c_float, _P, _P, _P]),
     "ts_photometric_loss_rgbd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),

@@ -393,6 +393,22 @@ __global__ __launch_bounds__(kThreads) void stream_read_kernel(const float4* __r
     if (t == 123456.789f) sink[0] = t;          // practically never true: keeps the loads alive
 }
 
+// Measurement utility (bench.py): the access pattern of the compositing kernels' record gather - lane j reads the
+// 48-byte record ids[j] with three 16-byte loads - on a KNOWN number of records, so that rocprofv3's FETCH_SIZE
+// can be calibrated for this pattern (MI355X_MICROARCH.md, HBM section: only wide coalesced reads are calibrated).
+__global__ __launch_bounds__(kThreads) void gather48_kernel(const float4* __restrict__ records,
+                                                            const int* __restrict__ ids, size_t m,
+                                                            float* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t j = (size_t)blockIdx.x * kThreads + threadIdx.x; j < m; j += stride) {
+        const size_t g = (size_t)ids[j];
+        const float4 q0 = records[3 * g], q1 = records[3 * g + 1], q2 = records[3 * g + 2];
+        a.x += q0.x + q1.x + q2.x; a.y += q0.y + q1.y + q2.y; a.z += q0.z + q1.z + q2.z; a.w += q0.w + q1.w + q2.w;
+    }
+    if ((a.x + a.y) + (a.z + a.w) == 123456.789f) sink[0] = a.x;
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -600,6 +616,13 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
         default: TS_SHC_BWD(4); break;
     }
 #undef TS_SHC_BWD
+    return launch_status();
+}
+
+int ts_bench_gather48(const float* records, const int32_t* ids, int64_t m, float* sink, void* stream) {
+    if (!records || !ids || !sink || m < 1) return TS_E_BADARG;
+    hipLaunchKernelGGL(gather48_kernel, dim3(256 * 8), dim3(kThreads), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(records), ids, (size_t)m, sink);
     return launch_status();
 }
 

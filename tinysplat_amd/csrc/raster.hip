@@ -440,47 +440,8 @@ __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
     return x;
 }
 
-// The same reduction with gfx950's lane-swap instructions doing the two cross-row levels FIRST, while the
-// number of values is largest: v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows
-// of a register PAIR in one issue, so "merge two values over partner lanes" is swap + add (2 issues)
-// instead of two selects + a DPP add (3) - and the swaps clobber both operands, which is free here because
-// the accumulators are dead (zeroed) after a flush.  The in-row levels that remain see 3, 2 and 1
-// registers.  On return lane l holds the wave sum of value
-//     (l & 4) ? 8 + (l >> 5) : 4 * ((l >> 3) & 1) + 2 * ((l >> 4) & 1) + (l >> 5)
-// (the same in the four lanes of a quad).  10 values: 5+5 (xor 32) + 2+2+3 (xor 16) + 3+1 (xor 8) + 3 (xor 4,
-// row_half_mirror: any pairing of the two half-rows will do, the quad levels sum the rest) + 2 = 26 issues,
-// no ds_bpermute.
-#ifndef TS_FLUSH_SWAP
-#define TS_FLUSH_SWAP 0
-#endif
-typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float swap32_merge(float a, float b) {      // lanes 0..31: a over l ^ 32; lanes 32..63: b
-    const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float swap16_merge(float a, float b) {      // even rows: a over l ^ 16; odd rows: b
-    const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-template <bool HAVE9>
-__device__ __forceinline__ float wave_sum10_swap(const float v[10], int lane) {
-    const bool b2 = lane & 4, b3 = lane & 8;
-    const float m0 = swap32_merge(v[0], v[1]), m1 = swap32_merge(v[2], v[3]);
-    const float m2 = swap32_merge(v[4], v[5]), m3 = swap32_merge(v[6], v[7]);
-    // without a tenth value both half-waves end up holding value 8
-    const float m4 = HAVE9 ? swap32_merge(v[8], v[9]) : v[8] + __shfl_xor(v[8], 32, 64);
-    const float n0 = swap16_merge(m0, m1), n1 = swap16_merge(m2, m3);
-    const float n2 = swap16_merge(m4, m4);                              // both operands alike: plain l ^ 16 sum
-    float x = merge2<0x128>(n0, n1, b3);                                // row_ror:8
-    const float t = dpp_add_t<0x128, 0xF>(n2);
-    x = merge2<0x141>(x, t, b2);                                        // row_half_mirror: lane i <-> 7 - i
-    x = dpp_add_t<0x4E, 0xF>(x);                                        // quad_perm [2,3,0,1]
-    return dpp_add_t<0xB1, 0xF>(x);                                     // quad_perm [1,0,3,2]
-}
-
 // Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
-// (butterfly: lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag; swap form:
-// the first lane of ten quads stores, lane 1 sets the flag).
+// (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag).
 template <int CH>
 __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
@@ -492,18 +453,11 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         float v10[10];
 #pragma unroll
         for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
-        r = TS_FLUSH_SWAP ? wave_sum10_swap<(CH == 4)>(v10, lane) : wave_sum10<(CH == 4)>(v10, lane);
-    }
-    const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
-    (void)num_isects;
-    if (TS_FLUSH_SWAP) {
-        const int w = (lane & 4) ? 8 + (lane >> 5) : 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + (lane >> 5);
-        const bool writer = (lane & 3) == 0 && ((lane & 4) == 0 || (lane & 0x18) == 0);
-        if (writer && w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
-        if (lane == 1) row_flags[slot] = 1;                    // this row now holds data
-        return;
+        r = wave_sum10<(CH == 4)>(v10, lane);
     }
     const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
+    const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
+    (void)num_isects;
     if (w >= 0) {
         if (w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
         else if (w == 10) row_flags[slot] = 1;                 // this row now holds data

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 3
+#define TS_ABI_VERSION 4
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -291,6 +291,52 @@ int ts_frame_fwd_prepare(const ts_frame* f, void* stream);
 int ts_frame_fwd_composite(const ts_frame* f, void* stream);
 int ts_frame_bwd_composite(const ts_frame* f, void* stream);
 int ts_frame_bwd_params(const ts_frame* f, void* stream);
+
+/* ============== Gaussian-sharded multi-GPU frame (csrc/shard.hip) =====================
+ * One rank per GPU owns a contiguous range of Gaussians and one stripe of tile rows.  Per frame it projects and
+ * colours its own Gaussians (ts_project_fwd / ts_colors_pack_fwd with the FULL-frame camera), routes a 64-byte
+ * export record of each visible one to the rank(s) whose stripe its tile box reaches, and composites the
+ * records it receives; backward returns one 48-byte gradient row per record to the owner.  The exchange itself
+ * (two all_to_all calls) is the caller's: these entries produce and consume its buffers.
+ *
+ * Export record (TS_EXPORT_RECORD_FLOATS floats): {x, y, opacity, conic.xx | conic.xy, conic.yy, c0, c1 |
+ * c2, c3, depth, radius (int) | global id (int), -, -, -}: the first ten floats are those of the packed
+ * compositing record (ts_pack_splats).
+ * Gradient row (TS_PARTIAL_ROW_FLOATS floats): {v_x, v_y, v_conic.xx, v_conic.xy | v_conic.yy, v_c0, v_c1, v_c2 |
+ * v_c3 (depth channel), v_opacity (w.r.t. the sigmoid's output), -, -}. */
+#define TS_MAX_RANKS 16
+#define TS_EXPORT_RECORD_FLOATS 16
+typedef struct ts_stripes {   /* rank d renders tile rows [row[d], row[d+1]) */
+    int32_t num;
+    int32_t row[TS_MAX_RANKS + 1];
+} ts_stripes;
+/* route_ws: >= ts_route_ws_ints(n, num_ranks) int32; written by ts_route_count, read by ts_route_pack and
+ * ts_route_accumulate of the same frame.  counts (device, num_ranks int32) <- records per destination. */
+int64_t ts_route_ws_ints(int32_t n, int32_t num_ranks);
+int ts_route_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
+                   const ts_stripes* stripes_host, int32_t* route_ws, int32_t* counts, void* stream);
+/* records[sum(counts), 16]: grouped by destination (ascending), ascending Gaussian index inside a group;
+ * splats = the owner's packed records (colours, sigmoid opacity), gid_base = global index of Gaussian 0. */
+int ts_route_pack(int32_t n, int32_t gid_base, const float* xys, const int32_t* radii, const float* depths,
+                  const float* splats, const ts_camera* cam_host, const ts_stripes* stripes_host,
+                  const int32_t* route_ws, float* records, void* stream);
+/* importing rank, m received records: the arrays binning takes (num_tiles_hit for cam's stripe) ... */
+int ts_import_records(int32_t m, const float* records, const ts_camera* cam_host, float* xys, float* depths,
+                      int32_t* radii, int32_t* num_tiles_hit, void* stream);
+/* ... and, after ts_scan_tiles, the 48-byte compositing records */
+int ts_import_pack(int32_t m, const float* records, const int32_t* cum_tiles_hit, const ts_camera* cam_host,
+                   float* splats, void* stream);
+/* ts_reduce_partials writing one gradient row per (imported) Gaussian instead of the five arrays */
+int ts_reduce_partials_rows(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
+                            const int32_t* cum_tiles_hit, const float* partials, const uint8_t* row_flags,
+                            const float* splats, float* grad_rows, void* stream);
+/* owner: grad_rows[sum(counts), 12] in the order of ts_route_pack's records -> dense 2-D gradients of the owned
+ * Gaussians (rows of a Gaussian summed in ascending stripe order; clamp mask of the colour stage and the
+ * sigmoid's derivative applied: v_opacity is w.r.t. the logits).  v_depth may be NULL (channels == 3). */
+int ts_route_accumulate(int32_t n, int32_t channels, const float* xys, const int32_t* radii, const float* splats,
+                        const uint8_t* color_mask, const ts_camera* cam_host, const ts_stripes* stripes_host,
+                        const int32_t* route_ws, const float* grad_rows, float* v_xy, float* v_conic,
+                        float* v_colors, float* v_depth, float* v_opacity, void* stream);
 
 /* ============ training-step ops around the path (scripts/train.py:58-63,97) ===== */
 

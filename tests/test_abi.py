@@ -36,7 +36,7 @@ def test_binding_covers_the_header_and_version_matches():
     from tinysplat_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.ts_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 4
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + reserved (ABI 3)

@@ -22,6 +22,7 @@ SOURCES = [
     ("densify.hip", ["-ffp-contract=off"]),
     ("formats.hip", []),
     ("frame.hip", []),
+    ("shard.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

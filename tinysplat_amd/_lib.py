@@ -11,7 +11,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TsCamera(ctypes.Structure):
@@ -57,6 +57,16 @@ class TsFrame(ctypes.Structure):
 
 _FRAME = POINTER(TsFrame)
 
+MAX_RANKS = 16
+
+
+class TsStripes(ctypes.Structure):
+    """struct ts_stripes: rank d renders tile rows [row[d], row[d+1])."""
+    _fields_ = [("num", c_int32), ("row", c_int32 * (MAX_RANKS + 1))]
+
+
+_STRIPES = POINTER(TsStripes)
+
 # name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
 SIGNATURES = {
     "ts_abi_version": (c_int32, []),
@@ -95,6 +105,13 @@ SIGNATURES = {
     "ts_ply_pack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_ply_unpack_rows": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_route_ws_ints": (c_int64, [c_int32, c_int32]),
+    "ts_route_count": (c_int32, [c_int32, _P, _P, _CAM, _STRIPES, _P, _P, _P]),
+    "ts_route_pack": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _CAM, _STRIPES, _P, _P, _P]),
+    "ts_import_records": (c_int32, [c_int32, _P, _CAM, _P, _P, _P, _P, _P]),
+    "ts_import_pack": (c_int32, [c_int32, _P, _P, _CAM, _P, _P]),
+    "ts_reduce_partials_rows": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_route_accumulate": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _CAM, _STRIPES, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_frame_struct_bytes": (c_int32, []),
     "ts_frame_fwd_project": (c_int32, [_FRAME, _P]),
     "ts_frame_fwd_prepare": (c_int32, [_FRAME, _P]),

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     const float4* __restrict__ partials, const unsigned char* __restrict__ row_flags,
     const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_opacity, float* __restrict__ v_depth,
-    const unsigned char* __restrict__ color_mask) {
+    const unsigned char* __restrict__ color_mask, float4* __restrict__ grad_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
@@ -769,6 +769,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             if (!(m & 2)) a1.w = 0.0f;
             if (!(m & 4)) a2.x = 0.0f;
         }
+    }
+    if (grad_rows) {        // Gaussian-sharded frame (shard.hip): one 48-byte row per imported record
+        grad_rows[3 * (size_t)i] = make_float4(vx, vy, 0.5f * a0.w, a1.x);
+        grad_rows[3 * (size_t)i + 1] = make_float4(0.5f * a1.y, a1.z, a1.w, a2.x);
+        grad_rows[3 * (size_t)i + 2] = make_float4(CH == 4 ? a2.y : 0.0f, vop, 0.0f, 0.0f);
+        return;
     }
     reinterpret_cast<float2*>(v_xy)[i] = make_float2(vx, vy);
     v_opacity[i] = vop;
@@ -874,10 +880,34 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
     const int grid = (n + 255) / 256;
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask,
+                           (float4*)nullptr);
     else
         hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
-                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask);
+                           cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask,
+                           (float4*)nullptr);
+    return launch_status();
+}
+
+int ts_reduce_partials_rows(int32_t n, int32_t channels, int32_t flags, const int32_t* num_tiles_hit,
+                            const int32_t* cum_tiles_hit, const float* partials, const uint8_t* row_flags,
+                            const float* splats, float* grad_rows, void* stream) {
+    if (n < 0 || (channels != 3 && channels != 4)) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!num_tiles_hit || !cum_tiles_hit || !row_flags || !splats || !grad_rows) return TS_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const float4* pr = reinterpret_cast<const float4*>(partials);
+    const float4* sp = reinterpret_cast<const float4*>(splats);
+    float4* gr = reinterpret_cast<float4*>(grad_rows);
+    const int grid = (n + 255) / 256;
+    if (channels == 3)
+        hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
+                           cum_tiles_hit, pr, row_flags, sp, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, gr);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
+                           cum_tiles_hit, pr, row_flags, sp, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, gr);
     return launch_status();
 }
 

@@ -1,0 +1,484 @@
+"""Gaussian-sharded multi-GPU frame (the reference is single-device, rasterize.py:17).
+
+One process per GPU.  Rank r OWNS a contiguous range of the Gaussians - their six parameter tensors, and
+whatever the caller keeps per Gaussian (Adam moments, the densification accumulator) - and RENDERS one
+stripe of tile rows.  A frame on rank r:
+
+  owner stage    project + colour stage over the OWNED Gaussians only (N / G), with the full-frame camera;
+                 ``ts_route_count / ts_route_pack`` group a 64-byte export record of every visible Gaussian
+                 by the rank(s) whose stripe its tile box reaches
+  exchange       all_to_all of the records (RCCL over xGMI with backend "nccl"): a rank receives what its
+                 stripe lists - ~N / G records plus the Gaussians straddling a stripe boundary
+  stripe stage   ``ts_import_records`` -> scan -> ``ts_import_pack`` -> bin / sort / composite the stripe with
+                 the very kernels a single GPU runs (tight lists, wide lists, split blocks as frame.py)
+  backward       composite back to front, one 48-byte gradient row per imported record
+                 (``ts_reduce_partials_rows``), reverse all_to_all, ``ts_route_accumulate`` sums a Gaussian's
+                 rows in ascending stripe order, then the colour stage's and the projection's backward run on
+                 the owned Gaussians: every rank ends with the gradients of ITS parameters.
+
+Nothing is replicated and no stage of a rank is O(N): per-Gaussian work is N / G, per-record work ~1.15 N / G,
+compositing 1 / G of the pixels, and 64 + 48 bytes per (Gaussian, stripe) pair cross the links - at 1 M
+Gaussians on 8 ranks ~13 MB per rank and frame, against the dense (36 + 4 ch) N-byte all-reduce (40 MB on every
+rank) plus ~0.25 ms of replicated per-Gaussian stages of the replicated-parameter design (sharding.py, kept).
+
+The stripes tile the single-GPU image bit for bit (records reach a rank ordered by global Gaussian index, so
+equal depths tie-break as on one GPU); gradients agree to rounding (a Gaussian's rows are summed per stripe,
+then over stripes).  ``Exchange`` abstracts the two collectives so that the same frame code runs under
+torch.distributed (``DistExchange``) and against recorded remote records (``ReplayExchange``: bench.py's
+single-GPU estimate of one rank's step); ``simulate_frame`` runs the stages of ALL ranks one after the other in
+one process on one GPU (full-size functional checks and the per-stage table of a rank on 1-GPU boxes).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import _lib
+from . import frame as _frame
+from ._lib import TsStripes
+from .ops import _call, _camera, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
+from .rasterizer import camera_on_device
+from .sharding import stripe_rows
+from .synthetic import SplatModel
+
+RECORD_FLOATS = 16       # TS_EXPORT_RECORD_FLOATS
+ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS
+
+
+# --------------------------------------------------------------------------------------------------
+# layout: who owns which Gaussians, who renders which tile rows
+# --------------------------------------------------------------------------------------------------
+def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced index range of rank's Gaussians (the first n % world ranks own one more)."""
+    q, r = divmod(int(n_total), int(world))
+    i0 = rank * q + min(rank, r)
+    return i0, i0 + q + (1 if rank < r else 0)
+
+
+class ShardLayout:
+    """Static description of a sharded frame: ownership ranges and tile-row stripes of all ranks."""
+
+    def __init__(self, n_total: int, world: int, rank: int, dims: Tuple[int, int],
+                 stripes: Optional[Sequence[int]] = None):
+        if not (1 <= world <= _lib.MAX_RANKS) or not (0 <= rank < world):
+            raise ValueError(f"world size must be 1..{_lib.MAX_RANKS} and 0 <= rank < world")
+        self.n_total, self.world, self.rank, self.dims = int(n_total), int(world), int(rank), (int(dims[0]), int(dims[1]))
+        self.bounds = [shard_range(n_total, world, k)[0] for k in range(world)] + [int(n_total)]
+        tby = _tile_bounds(self.dims[1], self.dims[0])[1]
+        if stripes is None:
+            stripes = [stripe_rows(tby, world, k)[0] for k in range(world)] + [tby]
+        stripes = [int(v) for v in stripes]
+        if len(stripes) != world + 1 or any(a > b for a, b in zip(stripes, stripes[1:])) or stripes[0] < 0 \
+                or stripes[-1] > tby:
+            raise ValueError("stripes must be world + 1 ascending tile rows inside the frame")
+        self.stripes = stripes
+        st = TsStripes()
+        st.num = world
+        for k, v in enumerate(stripes):
+            st.row[k] = v
+        self.c_stripes = st
+
+    @property
+    def owned(self) -> Tuple[int, int]:
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+    @property
+    def tile_rows(self) -> Tuple[int, int]:
+        return self.stripes[self.rank], self.stripes[self.rank + 1]
+
+    def for_rank(self, rank: int) -> "ShardLayout":
+        return ShardLayout(self.n_total, self.world, rank, self.dims, self.stripes)
+
+
+def shard_model(model, world: int, rank: int) -> SplatModel:
+    """Rank's rows of the six parameter tensors as a model of its own (fresh leaf tensors)."""
+    i0, i1 = shard_range(model.means.shape[0], world, rank)
+    ps = [p.detach()[i0:i1].clone() for p in model.parameters()]
+    return SplatModel(*ps, active_sh_degree=model.active_sh_degree, background=model.background)
+
+
+# --------------------------------------------------------------------------------------------------
+# the two collectives of a frame
+# --------------------------------------------------------------------------------------------------
+class Exchange:
+    """counts(): device int32[world] records per destination -> (send_counts, recv_counts) as Python lists.
+    rows(): send[sum(send_counts), F] grouped by destination -> recv[sum(recv_counts), F] grouped by source.
+    ``backward=True`` marks the gradient return (same shapes with the roles of the counts swapped)."""
+
+    def counts(self, counts_dev: Tensor) -> Tuple[List[int], List[int]]:
+        raise NotImplementedError
+
+    def rows(self, send: Tensor, send_counts: List[int], recv_counts: List[int], backward: bool = False) -> Tensor:
+        raise NotImplementedError
+
+
+class DistExchange(Exchange):
+    """torch.distributed: ``all_to_all_single`` with split sizes (RCCL over xGMI for backend "nccl").  gloo
+    (functional tests with all ranks on one GPU) moves CUDA tensors through the host."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.via_host = dist.get_backend(group) == "gloo"
+
+    def counts(self, counts_dev):
+        if self.via_host:
+            mine = counts_dev.cpu()
+            got = torch.empty_like(mine)
+            dist.all_to_all_single(got, mine, group=self.group)
+            return mine.tolist(), got.tolist()
+        got = torch.empty_like(counts_dev)
+        dist.all_to_all_single(got, counts_dev, group=self.group)
+        both = torch.stack([counts_dev, got]).cpu()              # the frame's host read of the record counts
+        return both[0].tolist(), both[1].tolist()
+
+    def rows(self, send, send_counts, recv_counts, backward=False):
+        m = int(sum(recv_counts))
+        if self.via_host:
+            src = send.cpu()
+            got = torch.empty((m, send.shape[1]), dtype=send.dtype)
+            dist.all_to_all_single(got, src, output_split_sizes=list(recv_counts),
+                                   input_split_sizes=list(send_counts), group=self.group)
+            return got.to(send.device)
+        got = send.new_empty((m, send.shape[1]))
+        dist.all_to_all_single(got, send, output_split_sizes=list(recv_counts),
+                               input_split_sizes=list(send_counts), group=self.group)
+        return got
+
+
+class ReplayExchange(Exchange):
+    """bench.py --emulate-ranks: one rank's step on one GPU.  The records the other ranks would send were
+    produced once (``remote_records``); every frame the rank's own group is copied into its place, and in
+    backward only the rows of the rank's own records come back (the others would travel to their owners).
+    No byte crosses a link: what is timed is the rank's compute, NOT a multi-GPU measurement."""
+
+    def __init__(self, rank: int, recv_counts: List[int], recv_template: Tensor):
+        self.rank, self.recv_counts, self.template = rank, list(recv_counts), recv_template
+        self.recv_off = [0]
+        for c in self.recv_counts:
+            self.recv_off.append(self.recv_off[-1] + c)
+        self.send_counts = None
+
+    def counts(self, counts_dev):
+        self.send_counts = counts_dev.cpu().tolist()
+        if self.send_counts[self.rank] != self.recv_counts[self.rank]:
+            raise RuntimeError("the replayed records do not belong to this scene / camera")
+        return self.send_counts, self.recv_counts
+
+    def rows(self, send, send_counts, recv_counts, backward=False):
+        so = sum(send_counts[:self.rank])
+        ro = sum(recv_counts[:self.rank])
+        k = send_counts[self.rank]
+        if backward:        # send = gradient rows of the imported records; own rows return, the rest is remote
+            got = send.new_zeros((sum(recv_counts), send.shape[1]))
+            got[ro:ro + k] = send[so:so + k]
+            return got
+        got = self.template.clone()
+        got[ro:ro + k] = send[so:so + k]
+        return got
+
+
+# --------------------------------------------------------------------------------------------------
+# the frame
+# --------------------------------------------------------------------------------------------------
+class _Owner:
+    __slots__ = ("n", "nb", "ch", "cam", "xys", "depths", "radii", "conics", "nth", "splats", "sh_mask",
+                 "route_ws", "send_counts", "recv_counts", "inputs")
+
+
+class _Stripe:
+    __slots__ = ("m", "cam", "split", "mode", "xys", "depths", "radii", "nth", "cum", "splats", "tile_bins",
+                 "ids", "bucket", "total", "final_Ts", "final_index", "clamp_mask", "bg", "num_tiles")
+
+
+def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, scales, quats, opacities,
+                 colors_dc, colors_rest, view34, projview, origin, fx, fy, sh_degree, ch, keep: bool):
+    w, h = layout.dims
+    n = means.shape[0]
+    nb = colors_rest.shape[1] + 1
+    if sh_degree < 0 or sh_degree > deg_from_sh(nb):
+        raise ValueError("sh_degree exceeds the stored coefficients")
+    O = _Owner()
+    O.n, O.nb, O.ch = n, nb, ch
+    O.cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    m = max(n, 1)
+    O.xys, O.depths = torch.empty((m, 2), **f32)[:n], torch.empty((m,), **f32)[:n]
+    O.radii, O.nth = torch.empty((m,), **i32)[:n], torch.empty((m,), **i32)[:n]
+    O.conics = torch.empty((m, 3), **f32)[:n]
+    O.splats = torch.empty((m, 12), **f32)
+    O.sh_mask = torch.empty((m,), dtype=torch.uint8, device=dev) if keep else None
+    O.route_ws = torch.empty((int(lib.ts_route_ws_ints(n, layout.world)),), **i32)
+    counts = torch.empty((layout.world,), **i32)
+    p = lambda t: None if t is None else t.data_ptr()
+    _call("ts_project_fwd", lib.ts_project_fwd, n, p(means), p(scales), p(quats), p(view34), p(projview), O.cam, 3,
+          p(O.xys), p(O.depths), p(O.radii), p(O.conics), p(O.nth), None, s)
+    # colour stage + packed records of the owned Gaussians (slot fields are rewritten by the importing rank)
+    _call("ts_colors_pack_fwd", lib.ts_colors_pack_fwd, n, int(sh_degree), nb, p(means), p(origin), p(colors_dc),
+          p(colors_rest) if nb > 1 else None, p(O.sh_mask), None, ch, 1, p(O.xys), p(O.radii), p(O.conics),
+          p(opacities), p(O.nth), O.cam, p(O.depths) if ch == 4 else None, p(O.splats), s)
+    _call("ts_route_count", lib.ts_route_count, n, p(O.xys), p(O.radii), O.cam, layout.c_stripes, p(O.route_ws),
+          p(counts), s)
+    O.send_counts, O.recv_counts = exchange.counts(counts)
+    send = torch.empty((max(sum(O.send_counts), 1), RECORD_FLOATS), **f32)[:sum(O.send_counts)]
+    _call("ts_route_pack", lib.ts_route_pack, n, layout.owned[0], p(O.xys), p(O.radii), p(O.depths), p(O.splats),
+          O.cam, layout.c_stripes, p(O.route_ws), p(send), s)
+    return O, send
+
+
+def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background: Tensor, fx, fy, ch, keep: bool):
+    w, h = layout.dims
+    S = _Stripe()
+    m = records.shape[0]
+    S.m = m
+    cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=layout.tile_rows)
+    S.mode = _frame._list_mode(dev.index, cam.tile_rows * cam.tile_bounds_x)
+    cam.wide_tiles = 1 if S.mode else 0
+    S.cam = cam
+    S.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
+    num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
+    S.num_tiles = num_tiles
+    rows = _stripe_rows(cam)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    mm = max(m, 1)
+    S.xys, S.depths = torch.empty((mm, 2), **f32), torch.empty((mm,), **f32)
+    S.radii, S.nth, S.cum = torch.empty((mm,), **i32), torch.empty((mm,), **i32), torch.empty((mm,), **i32)
+    S.splats = torch.empty((mm, 12), **f32)
+    scan_ws = torch.empty((int(lib.ts_scan_ws_ints(m)),), **i32)
+    bin_ws = torch.empty((int(lib.ts_bin_ws_ints(m, num_tiles)),), **i32)
+    S.tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
+    out_img = torch.empty((rows, w, ch), **f32)
+    if keep:
+        S.final_Ts = torch.empty((rows, w), **f32)
+        S.final_index = torch.empty((rows, w), **i32)
+        S.clamp_mask = torch.empty((rows, w), dtype=torch.uint8, device=dev)
+    else:
+        S.final_Ts = S.final_index = S.clamp_mask = None
+    if ch == 4:            # channel 3 is composited over background[0], as the reference's depth pass (:86)
+        S.bg = _f32c(torch.cat([background, background[:1]]))
+    else:
+        S.bg = _f32c(background)
+    p = lambda t: None if t is None else t.data_ptr()
+    host, event, lock = _frame._total_slot(dev)
+    tight = p(S.splats) if _frame.TIGHT_BINNING else None
+    with lock:
+        if m > 0:
+            _call("ts_import_records", lib.ts_import_records, m, p(records), cam, p(S.xys), p(S.depths), p(S.radii),
+                  p(S.nth), s)
+            _call("ts_scan_tiles", lib.ts_scan_tiles, m, p(S.nth), p(S.cum), p(scan_ws), None, s)
+            host.copy_(S.cum[m - 1:m], non_blocking=True)
+            event.record(torch.cuda.current_stream(dev))
+            _call("ts_import_pack", lib.ts_import_pack, m, p(records), p(S.cum), cam, p(S.splats), s)
+        _call("ts_bin_count", lib.ts_bin_count, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, p(bin_ws), p(S.tile_bins), s)
+        total = 0
+        if m > 0:
+            event.synchronize()                          # the stripe's intersection count (sizes the lists)
+            total = int(host[0])
+    if total < 0:
+        raise OverflowError("more than 2^31-1 tile intersections in one stripe")
+    S.total = total
+    _frame._pairs_per_tile[dev.index] = total / max(1, cam.tile_rows * cam.tile_bounds_x)
+    cap = (max(total, 1) + 63) & ~63
+    S.bucket = torch.empty((2 * cap,), **i32)
+    S.ids = S.bucket[cap:cap + total]
+    if total > 0:
+        _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket), s)
+        _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, p(S.tile_bins), p(S.depths), p(S.bucket),
+              S.bucket.data_ptr() + 4 * cap, p(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
+    flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+    _call("ts_raster_fwd", lib.ts_raster_fwd, ch, flags, cam, p(S.tile_bins), S.bucket.data_ptr() + 4 * cap,
+          p(S.splats), p(S.bg), p(out_img), p(S.final_Ts), p(S.final_index), p(S.clamp_mask), s)
+    return S, out_img
+
+
+def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
+    """Compositing backward of the stripe -> one gradient row per imported record [m, 12]."""
+    f32 = dict(dtype=torch.float32, device=dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    m = S.m
+    cap = S.bucket.numel() // 2
+    rows_n = max(S.total, 1) * (4 if S.split else 1)
+    partials = torch.empty((rows_n, 12), **f32)
+    row_flags = torch.empty((rows_n,), dtype=torch.uint8, device=dev)
+    grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
+    rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+    _call("ts_raster_bwd", lib.ts_raster_bwd, ch, rflags, S.total, S.cam, p(S.tile_bins),
+          S.bucket.data_ptr() + 4 * cap, p(S.splats), p(S.bg), p(S.final_Ts), p(S.final_index), p(v_img),
+          None, p(S.clamp_mask), p(partials), p(row_flags), s)
+    _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, 4 if S.split else 0, p(S.nth),
+          p(S.cum), p(partials), p(row_flags), p(S.splats), p(grad_rows), s)
+    return grad_rows
+
+
+def _owner_backward(lib, s, dev, layout: ShardLayout, O: _Owner, back: Tensor, sh_degree: int, opacity_shape,
+                    rest_shape):
+    """Rows returned by the destinations -> gradients of the six OWNED parameter tensors and v_xy."""
+    means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin = O.inputs
+    f32 = dict(dtype=torch.float32, device=dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    n, ch = O.n, O.ch
+    nn = max(n, 1)
+    v_xy = torch.empty((nn, 2), **f32)[:n]
+    v_conic = torch.empty((nn, 3), **f32)[:n]
+    v_colors = torch.empty((nn, 3), **f32)[:n]
+    v_depth = torch.empty((nn,), **f32)[:n] if ch == 4 else None
+    v_opac = torch.empty((nn,) + tuple(opacity_shape[1:]), **f32)[:n]
+    _call("ts_route_accumulate", lib.ts_route_accumulate, n, ch, p(O.xys), p(O.radii), p(O.splats),
+          p(O.sh_mask), O.cam, layout.c_stripes, p(O.route_ws), p(back), p(v_xy), p(v_conic), p(v_colors),
+          p(v_depth), p(v_opac), s)
+    v_means = torch.empty((nn, 3), **f32)[:n]
+    v_scales = torch.empty((nn, 3), **f32)[:n]
+    v_quats = torch.empty((nn, 4), **f32)[:n]
+    v_dc = torch.empty((nn, 3), **f32)[:n]
+    v_rest = torch.empty((nn,) + tuple(rest_shape[1:]), **f32)[:n]
+    _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, n, sh_degree, O.nb, p(means), p(origin), None,
+          p(v_colors), p(v_dc), p(v_rest) if O.nb > 1 else None, s)
+    _call("ts_project_bwd", lib.ts_project_bwd, n, p(means), p(scales), p(quats), p(view34), p(projview),
+          O.cam, 3, p(O.radii), p(v_xy), p(v_depth), p(v_conic), None, p(v_means), p(v_scales), p(v_quats), s)
+    return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest), v_xy
+
+
+def _inputs(model, view, projview, origin):
+    return tuple(_f32c(t) for t in (model.means, model.scales, model.quats, model.opacities, model.colors_dc,
+                                    model.colors_rest, view[:3, :], projview, origin))
+
+
+class _ShardedFrame(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin,
+                background, fx, fy, sh_degree, with_depth, layout, exchange):
+        dev = _need_hip(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background)
+        inputs = tuple(_f32c(t) for t in (means, scales, quats, opacities, colors_dc, colors_rest, view34,
+                                          projview, origin))
+        if means.shape[0] != layout.owned[1] - layout.owned[0]:
+            raise ValueError("the model shard does not hold the rows this rank owns")
+        ch = 4 if with_depth else 3
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            s = _stream(dev)
+            O, send = _owner_stage(lib, s, dev, layout, exchange, *inputs, fx, fy, int(sh_degree), ch, keep=True)
+            records = exchange.rows(send, O.send_counts, O.recv_counts)
+            S, out = _stripe_stage(lib, s, dev, layout, records, background, fx, fy, ch, keep=True)
+        O.inputs = inputs
+        ctx.owner, ctx.stripe, ctx.layout, ctx.exchange = O, S, layout, exchange
+        ctx.opacity_shape, ctx.rest_shape, ctx.sh_degree = opacities.shape, colors_rest.shape, int(sh_degree)
+        xys, radii = O.xys, O.radii
+        ctx.xys_out = xys
+        ctx.mark_non_differentiable(xys, radii)
+        return out, xys, radii
+
+    @staticmethod
+    def backward(ctx, v_img, _v_xys, _v_radii):
+        O, S, layout, exchange = ctx.owner, ctx.stripe, ctx.layout, ctx.exchange
+        dev = O.xys.device
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            s = _stream(dev)
+            grad_rows = _stripe_backward(lib, s, dev, S, O.ch, _f32c(v_img))
+            back = exchange.rows(grad_rows, O.recv_counts, O.send_counts, backward=True)
+            grads, v_xy = _owner_backward(lib, s, dev, layout, O, back, ctx.sh_degree, ctx.opacity_shape,
+                                          ctx.rest_shape)
+        xo = ctx.xys_out                       # what extras['xys'].grad holds in the reference, for the OWNED rows
+        xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
+        return grads + (None,) * 10
+
+
+def render_sharded(model_shard, camera, device, layout: ShardLayout, exchange: Exchange, with_depth: bool = False):
+    """This rank's stripe of the reference frame (rasterize.py:26-62) from the Gaussians ALL ranks own.
+    ``model_shard`` holds the rows ``layout.owned`` of the model.  -> (out[rows, W, 3 or 4] with RGB clamped to
+    <= 1 and, with ``with_depth``, the depth map as channel 3; (row_begin_px, row_end_px); xys[n_owned, 2] whose
+    ``.grad`` receives the owned Gaussians' 2-D position gradients in backward)."""
+    view, projview, origin = camera_on_device(camera, device)
+    out, xys, _ = _ShardedFrame.apply(model_shard.means, model_shard.scales, model_shard.quats,
+                                      model_shard.opacities, model_shard.colors_dc, model_shard.colors_rest,
+                                      view[:3, :], projview, origin, model_shard.background, camera.f_x, camera.f_y,
+                                      model_shard.active_sh_degree, with_depth, layout, exchange)
+    y0 = 16 * layout.tile_rows[0]
+    return out, (y0, y0 + out.shape[0]), xys
+
+
+class _LocalCounts(Exchange):
+    """counts() only: the owner stage of one rank run on its own (export_records, simulate_frame)."""
+
+    def counts(self, counts_dev):
+        c = counts_dev.cpu().tolist()
+        return c, c
+
+
+@torch.no_grad()
+def export_records(model_shard, camera, device, layout: ShardLayout, with_depth: bool = False):
+    """Owner stage only: the records this rank would send, grouped by destination -> (records, send_counts).
+    (bench.py's --emulate-ranks records the other ranks' traffic with it.)"""
+    dev = torch.device(device)
+    view, projview, origin = camera_on_device(camera, dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        O, send = _owner_stage(lib, _stream(dev), dev, layout, _LocalCounts(), *_inputs(model_shard, view, projview, origin),
+                               camera.f_x, camera.f_y, int(model_shard.active_sh_degree), 4 if with_depth else 3,
+                               keep=False)
+    return send, O.send_counts
+
+
+@torch.no_grad()
+def simulate_frame(model, camera, dims, device, world: int, v_img_of, with_depth: bool = False,
+                   stripes: Optional[Sequence[int]] = None):
+    """The sharded frame of ALL ``world`` ranks executed one rank after the other in THIS process on one GPU,
+    with the two exchanges done by slicing each other's buffers: the same stage functions, kernels and buffer
+    layouts as ``render_sharded`` under torch.distributed, no process group.  For full-size functional checks
+    on 1-GPU boxes.  ``model``: the WHOLE model; ``v_img_of(rank, image, (y0, y1))`` -> upstream gradient of that
+    rank's stripe image.  -> (list of stripe images, list of (y0, y1), gradients of the six whole parameter
+    tensors in ``model.parameters()`` order, v_xy[N, 2], per-rank record counts)."""
+    dev = torch.device(device)
+    n_total = model.means.shape[0]
+    view, projview, origin = camera_on_device(camera, dev)
+    lib = _lib.load()
+    ch = 4 if with_depth else 3
+    layouts = [ShardLayout(n_total, world, k, dims, stripes) for k in range(world)]
+    owners, sends, stripes_, images, rows_px = [], [], [], [], []
+    with torch.cuda.device(dev):
+        s = _stream(dev)
+        for k, lay in enumerate(layouts):
+            shard = shard_model(model, world, k)
+            inp = _inputs(shard, view, projview, origin)
+            O, send = _owner_stage(lib, s, dev, lay, _LocalCounts(), *inp, camera.f_x, camera.f_y,
+                                   int(model.active_sh_degree), ch, keep=True)
+            O.inputs = inp
+            owners.append(O)
+            sends.append(send)
+        offs = [[0] for _ in range(world)]
+        for k in range(world):
+            for c in owners[k].send_counts:
+                offs[k].append(offs[k][-1] + c)
+        recv_counts = [[owners[src].send_counts[k] for src in range(world)] for k in range(world)]
+        for k, lay in enumerate(layouts):
+            records = torch.cat([sends[src][offs[src][k]:offs[src][k + 1]] for src in range(world)], dim=0)
+            S, out = _stripe_stage(lib, s, dev, lay, records, model.background, camera.f_x, camera.f_y, ch, keep=True)
+            stripes_.append(S)
+            images.append(out)
+            y0 = 16 * lay.tile_rows[0]
+            rows_px.append((y0, y0 + out.shape[0]))
+        grad_rows = []
+        for k in range(world):
+            v_img = _f32c(v_img_of(k, images[k], rows_px[k]))
+            grad_rows.append(_stripe_backward(lib, s, dev, stripes_[k], ch, v_img))
+        roff = [[0] for _ in range(world)]
+        for k in range(world):
+            for c in recv_counts[k]:
+                roff[k].append(roff[k][-1] + c)
+        grads, v_xys = [], []
+        for k, lay in enumerate(layouts):
+            back = torch.cat([grad_rows[d][roff[d][k]:roff[d][k + 1]] for d in range(world)], dim=0)
+            g, v_xy = _owner_backward(lib, s, dev, lay, owners[k], back, int(model.active_sh_degree),
+                                      model.opacities.shape, model.colors_rest.shape)
+            grads.append(g)
+            v_xys.append(v_xy)
+    # (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) per rank -> model.parameters() order
+    cat = lambda j: torch.cat([g[j] for g in grads], dim=0)
+    whole = [cat(0), cat(4), cat(5), cat(1), cat(2), cat(3)]
+    return images, rows_px, whole, torch.cat(v_xys, dim=0), recv_counts

@@ -362,6 +362,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--shard-mode", default="gaussians", choices=("gaussians", "replicated"),
+                    help="N > 1 (and --emulate-ranks): 'gaussians' = every rank owns N/G Gaussians and one stripe, "
+                         "records / gradient rows travel by all_to_all (sharded.py); 'replicated' = parameters on "
+                         "every rank, one dense all-reduce of the 2-D gradients (sharding.py)")
     ap.add_argument("--single-device", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with "
                          "--backend gloo; RCCL refuses two ranks on one GPU).  Not a measurement.")
@@ -427,6 +431,33 @@ def main():
     w_rgb, w_d = w_rgb.to(dev), w_d.to(dev)
     adapter = GaussianRasterizer(model, None, device=dev)
     sharded = world > 1 or args.emulate_ranks > 1 or args.force_dist
+    # Gaussian-sharded frame: this rank keeps only the rows it owns
+    gshard = None
+    if args.shard_mode == "gaussians" and (world > 1 or args.emulate_ranks > 1) and not args.train_step \
+            and not args.forward_only:
+        from tinysplat_amd.sharded import (DistExchange, ReplayExchange, ShardLayout, export_records,
+                                           render_sharded, shard_model)
+        if world > 1:
+            g_rank, g_world = rank, world
+        else:
+            g_rank, g_world = args.emulate_rank, args.emulate_ranks
+        layout = ShardLayout(n, g_world, g_rank, (w, h))
+        shard = shard_model(model, g_world, g_rank).requires_grad_(True)
+        if world > 1:
+            exchange = DistExchange()
+        else:       # what the other ranks would send to this one, recorded once (outside the timed region)
+            parts, counts = [], []
+            for src in range(g_world):
+                rec, cnt = export_records(shard_model(model, g_world, src), cam, dev, layout.for_rank(src), args.depth)
+                o = sum(cnt[:g_rank])
+                parts.append(rec[o:o + cnt[g_rank]].clone())
+                counts.append(cnt[g_rank])
+            exchange = ReplayExchange(g_rank, counts, torch.cat(parts, dim=0))
+        gshard = (shard, layout, exchange)
+        model_params = shard.parameters()
+        del model
+    else:
+        model_params = model.parameters()
 
     trainer = None
     if args.train_step:
@@ -442,8 +473,16 @@ def main():
         if trainer is not None:
             trainer(cam, tgt_rgb, tgt_depth)
             return
-        for p_ in model.parameters():
+        for p_ in model_params:
             p_.grad = None
+        if gshard is not None:
+            out, (y0, y1), _ = render_sharded(gshard[0], cam, dev, gshard[1], gshard[2], with_depth=args.depth)
+            if out.shape[2] == 3:
+                loss = torch.dot(out.reshape(-1), w_rgb[y0:y1].reshape(-1))
+            else:
+                loss = (out[:, :, :3] * w_rgb[y0:y1]).sum() + (out[:, :, 3] * w_d[y0:y1]).sum()
+            loss.backward()
+            return
         if args.forward_only:
             with torch.no_grad():
                 adapter(cam, (w, h), sh)
@@ -559,8 +598,9 @@ def main():
         p_local = p if (world == 1 and args.emulate_ranks <= 1) else binning.cam.tile_rows * 16 * w
         # D5 priced with the pairs a launch actually processes (the tight lists); the figure with gsplat's
         # bounding-box pair count - pairs that are never scattered, sorted or composited - is kept beside it
-        a_bytes = stage_alg_bytes(dom_stage, n, isects_listed, p_local, tiles, k, ch)
-        a_bytes_bbox = stage_alg_bytes(dom_stage, n, isects, p_local, tiles, k, ch)
+        n_local = int(binning.n)              # Gaussians (or imported records) this rank's stages run over
+        a_bytes = stage_alg_bytes(dom_stage, n_local, isects_listed, p_local, tiles, k, ch)
+        a_bytes_bbox = stage_alg_bytes(dom_stage, n_local, isects, p_local, tiles, k, ch)
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
         full_tiles = (w + 15) // 16 * ((h + 15) // 16)
         frame_bytes = frame_alg_bytes(n, isects_total, p, full_tiles, k, args.depth)
@@ -572,8 +612,8 @@ def main():
                   "--scale-mult", str(args.scale_mult)] + (["--depth"] if args.depth else []) \
                  + (["--spatial-sort"] if args.spatial_sort else []) \
                  + (["--forward-only"] if args.forward_only else []) \
-                 + (["--emulate-ranks", str(args.emulate_ranks), "--emulate-rank", str(args.emulate_rank)]
-                    if args.emulate_ranks > 1 else [])
+                 + (["--emulate-ranks", str(args.emulate_ranks), "--emulate-rank", str(args.emulate_rank),
+                     "--shard-mode", args.shard_mode] if args.emulate_ranks > 1 else [])
             _log("PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU)")
             pmc = collect_pmc(wl)
             _log("PMC passes done" if pmc else "PMC passes unavailable")
@@ -686,8 +726,11 @@ def main():
                                    f"({'RGB+depth' if args.depth else 'RGB'})",
                        "intersections": isects_total, "intersections_listed": listed_total,
                        "max_per_tile": max_per_tile,
-                       "parallelism": (f"tile-row stripes x{world}" + (" (ALL RANKS ON ONE GPU: functional test, "
-                                       "not a measurement)" if args.single_device else "")) if world > 1 else "single GPU",
+                       "parallelism": ((f"Gaussian shards + tile-row stripes x{world} (records / gradient rows by all_to_all)"
+                                        if gshard is not None else
+                                        f"tile-row stripes x{world}, replicated parameters, one all-reduce")
+                                       + (" (ALL RANKS ON ONE GPU: functional test, not a measurement)"
+                                          if args.single_device else "")) if world > 1 else "single GPU",
                        "scale_mult": args.scale_mult,
                        "tile_lists": {0: "16x16 (gsplat's)", 1: "32x16 lists, 32x16 waves",
                                       2: "32x16 lists (pairs of 16x16 tiles), one wave per 16x16 tile"}.get(
@@ -696,7 +739,8 @@ def main():
                        "gaussian_order": "Morton curve of the means (--spatial-sort)" if args.spatial_sort
                                          else "as generated (i.i.d.)",
                        **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "
-                                              "(per-rank estimate, not a multi-GPU measurement)"}
+                                              "(per-rank estimate, not a multi-GPU measurement), shard mode "
+                                              + args.shard_mode}
                           if args.emulate_ranks > 1 and world == 1 else {})},
             "roofline": roofline,
             "frame_roofline": frame_roofline,

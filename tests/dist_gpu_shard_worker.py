@@ -1,0 +1,48 @@
+"""Worker for the multi-process test of the Gaussian-sharded PRODUCT frame (sharded.render_sharded under
+torch.distributed): launched by torch.distributed.run with WORLD ranks that all use cuda:0 (the GPU boxes have
+one GPU; RCCL refuses two ranks on one device, so the backend is gloo and DistExchange moves the record / row
+buffers through the host - the same all_to_all_single calls RCCL serves on 8 GPUs).  Each rank owns 1 / WORLD of
+the Gaussians, renders its stripe, back-propagates its stripe's loss and stores image, the gradients of the rows
+it owns and xys.grad."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    out_dir, n, sh, w, h, mult, depth = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), \
+        int(sys.argv[5]), float(sys.argv[6]), bool(int(sys.argv[7]))
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    from tinysplat_amd.sharded import DistExchange, ShardLayout, render_sharded, shard_model
+    from tinysplat_amd.synthetic import loss_weights, make_scene
+    model, cam = make_scene(n, sh, w, h, seed=3, scale_mult=mult)
+    model.background = torch.tensor([0.2, 0.1, 0.3])
+    shard = shard_model(model, world, rank).to(dev).requires_grad_(True)
+    del model
+    layout = ShardLayout(n, world, rank, (w, h))
+    w_rgb, w_d = loss_weights(w, h)
+    out, (y0, y1), xys = render_sharded(shard, cam, dev, layout, DistExchange(), with_depth=depth)
+    loss = (out[:, :, :3] * w_rgb[y0:y1].to(dev)).sum()
+    if depth:
+        loss = loss + (out[:, :, 3] * w_d[y0:y1].to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.save({"img": out.detach().cpu(), "rows": (y0, y1), "owned": layout.owned, "xys_grad": xys.grad.cpu(),
+                "grads": [p.grad.cpu() for p in shard.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""The Gaussian-sharded multi-GPU frame on the HIP path (tinysplat_amd/sharded.py, csrc/shard.hip; SURVEY.md 8(e)
+E2-E4, BASELINE configs[3]).  The reference is single-device (rasterize.py:17): the contract is that the stripes
+of a sharded frame tile the single-GPU image bit for bit and that the gradients equal the single-GPU ones to
+rounding.  Checked three ways against the single-process frame (frame.py) on the same GPU:
+
+  * the routing kernels against oracle/route_oracle.py (groups, order, record contents bit for bit);
+  * ``simulate_frame``: the stages of all ranks run one after the other in one process - world 1, 2, 3, 8, RGB and
+    RGB + depth, stripes that do not divide the tile rows, and BASELINE configs[3] at FULL size (1 M Gaussians,
+    1920x1080) for world 2 and 8;
+  * real ranks: ``render_sharded`` + ``DistExchange`` launched by torch.distributed.run (gloo, all ranks on
+    cuda:0 - the boxes have one GPU), small scenes at world 2 / 3 and configs[3] at full size at world 2 and 8.
+"""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+from helpers import check_grad
+from tinysplat_amd.sharded import ShardLayout, export_records, shard_model, shard_range, simulate_frame
+from tinysplat_amd.sharding import render_stripe
+from tinysplat_amd.synthetic import loss_weights, make_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+DEV = torch.device("cuda", 0)
+NAMES = ["means", "colors_dc", "colors_rest", "scales", "quats", "opacities"]
+
+
+def _single(n, sh, w, h, mult, depth, seed=3, bg=(0.2, 0.1, 0.3)):
+    model, cam = make_scene(n, sh, w, h, seed=seed, scale_mult=mult)
+    model.background = torch.tensor(bg)
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    full, rows, xys = render_stripe(model, cam, (w, h), DEV, 0, 1, with_depth=depth)
+    loss = (full[:, :, :3] * w_rgb).sum()
+    if depth:
+        loss = loss + (full[:, :, 3] * w_d).sum()
+    loss.backward()
+    return model, cam, full.detach(), xys, w_rgb, w_d
+
+
+def test_route_kernels_match_the_oracle():
+    from oracle import route_oracle as R
+    n, sh, w, h, world = 30000, 2, 640, 360, 4
+    model, cam = make_scene(n, sh, w, h, seed=5, scale_mult=3.0)
+    md = model.to(DEV)
+    # single-process projection of everything: what every owner must reproduce for its rows
+    from tinysplat_amd import frame
+    _, xys_all, radii_all = frame.render_view(md, *_views(cam), cam.f_x, cam.f_y, w, h, True)
+    xys_all, radii_all = xys_all.cpu(), radii_all.cpu()
+    stripes = [0, 5, 11, 12, 23]              # uneven, one single-row stripe
+    lists = R.route(xys_all, radii_all, (w, h), stripes)
+    seen = [[] for _ in range(world)]
+    for r in range(world):
+        lay = ShardLayout(n, world, r, (w, h), stripes)
+        rec, counts = export_records(shard_model(md, world, r), cam, DEV, lay, with_depth=True)
+        rec = rec.cpu()
+        i0, i1 = shard_range(n, world, r)
+        off = 0
+        for d in range(world):
+            want = lists[d][(lists[d] >= i0) & (lists[d] < i1)]
+            got = rec[off:off + counts[d]]
+            gid = got[:, 12].view(torch.int32)
+            assert torch.equal(gid.long(), want), (r, d)                      # group, order
+            assert torch.equal(got[:, :2], xys_all[want])                     # x, y
+            assert torch.equal(got[:, 11].view(torch.int32), radii_all[want])  # radius
+            seen[d].append(gid)
+            off += counts[d]
+        assert off == rec.shape[0]
+    for d in range(world):                    # a destination's records, sources in rank order: ascending ids
+        ids = torch.cat(seen[d])
+        assert torch.all(ids[1:] > ids[:-1]) and torch.equal(ids.long(), lists[d])
+
+
+def _views(cam):
+    from tinysplat_amd.rasterizer import camera_on_device
+    view, projview, origin = camera_on_device(cam, DEV)
+    return view[:3, :], projview, origin
+
+
+def _check_simulated(n, sh, w, h, mult, depth, world, stripes=None, rel=1e-5):
+    model, cam, full, xys, w_rgb, w_d = _single(n, sh, w, h, mult, depth)
+
+    def v_img_of(k, img, rows):
+        y0, y1 = rows
+        v = torch.zeros_like(img)
+        v[:, :, :3] = w_rgb[y0:y1]
+        if depth:
+            v[:, :, 3] = w_d[y0:y1]
+        return v
+    with torch.no_grad():
+        images, rows_px, grads, v_xy, recv_counts = simulate_frame(model, cam, (w, h), DEV, world, v_img_of,
+                                                                   with_depth=depth, stripes=stripes)
+    assert rows_px[0][0] == 0 and rows_px[-1][1] == h
+    assert torch.equal(torch.cat(images, dim=0), full)                      # E2: the stripes tile the frame
+    for nm, g, p in zip(NAMES, grads, model.parameters()):
+        check_grad(f"world {world} {nm}", g, p.grad, rel=rel)               # E4
+    check_grad(f"world {world} xys", v_xy, xys.grad, rel=rel)
+    return recv_counts
+
+
+@pytest.mark.parametrize("world,depth,n,sh,w,h,mult,stripes", [
+    (1, False, 20000, 3, 400, 300, 3.0, None),
+    (2, False, 40000, 3, 640, 360, 2.0, None),
+    (2, True, 40000, 3, 640, 360, 2.0, None),
+    (3, True, 20000, 1, 400, 300, 3.0, None),
+    (8, True, 60000, 2, 640, 360, 2.0, None),
+    (4, False, 30000, 0, 500, 280, 4.0, [0, 1, 9, 9, 18]),        # a one-row stripe and an empty one
+])
+def test_all_ranks_in_one_process_equal_the_single_frame(world, depth, n, sh, w, h, mult, stripes):
+    _check_simulated(n, sh, w, h, mult, depth, world, stripes)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config3_full_size_sharded_equals_single_frame(world):
+    """BASELINE configs[3]: 1 M Gaussians, SH 3, 1920x1080, sharded over 2 and 8 ranks (all ranks' stages in this
+    process): image bitwise, the six gradients and xys.grad to 1e-5 * |ref|_inf.  Also: no rank receives more
+    than ~1.3 N / world records (per-record work is proportional to the stripe)."""
+    n = 1_000_000
+    recv_counts = _check_simulated(n, 3, 1920, 1080, 1.0, False, world)
+    per_rank = [sum(c) for c in recv_counts]
+    assert max(per_rank) <= 1.3 * n / world, per_rank
+    print("records per rank:", per_rank)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, out_dir, n, sh, w, h, mult, depth, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "tests" / "dist_gpu_shard_worker.py"), str(out_dir), str(n), str(sh), str(w), str(h),
+           str(mult), str(int(depth))]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [torch.load(Path(out_dir) / f"rank{k}.pt") for k in range(world)]
+
+
+@pytest.mark.parametrize("world,depth,n,sh,w,h,mult", [
+    (2, True, 40000, 3, 640, 360, 2.0),
+    (3, False, 20000, 1, 400, 300, 3.0),
+    (2, False, 1_000_000, 3, 1920, 1080, 1.0),          # BASELINE configs[3] at full size, 2 ranks
+    (8, False, 1_000_000, 3, 1920, 1080, 1.0),          # ... and 8 ranks
+])
+def test_real_ranks_equal_single_process(tmp_path, world, depth, n, sh, w, h, mult):
+    outs = _launch(world, tmp_path, n, sh, w, h, mult, depth)
+    model, cam, full, xys, _, _ = _single(n, sh, w, h, mult, depth)
+    assert torch.equal(torch.cat([o["img"] for o in outs], dim=0), full.cpu())      # E2
+    for k, o in enumerate(outs):
+        i0, i1 = o["owned"]
+        assert (i0, i1) == shard_range(n, world, k)
+    for j, (nm, p) in enumerate(zip(NAMES, model.parameters())):                    # E4: owners' rows, stitched
+        check_grad(f"ranks {world} {nm}", torch.cat([o["grads"][j] for o in outs], dim=0), p.grad, rel=1e-5)
+    check_grad(f"ranks {world} xys", torch.cat([o["xys_grad"] for o in outs], dim=0), xys.grad, rel=1e-5)

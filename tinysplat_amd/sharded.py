@@ -40,7 +40,7 @@ from torch import Tensor
 from . import _lib
 from . import frame as _frame
 from ._lib import TsStripes
-from .ops import _call, _camera, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
+from .ops import TileBinning, _call, _camera, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
 from .rasterizer import camera_on_device
 from .sharding import stripe_rows
 from .synthetic import SplatModel
@@ -294,6 +294,10 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)
     _call("ts_raster_fwd", lib.ts_raster_fwd, ch, flags, cam, p(S.tile_bins), S.bucket.data_ptr() + 4 * cap,
           p(S.splats), p(S.bg), p(out_img), p(S.final_Ts), p(S.final_index), p(S.clamp_mask), s)
+    b = TileBinning()                        # scene statistics of the most recent frame (bench.py / tools)
+    b.cam, b.n, b.num_tiles, b.num_intersects = cam, m, num_tiles, total
+    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = S.tile_bins[:num_tiles], S.ids, S.cum, S.nth
+    _frame.last_binning[dev.index] = b
     return S, out_img
 
 

@@ -271,7 +271,7 @@ def cpu_baseline_guarded(timeout_s: float = 240.0):
 # --------------------------------------------------------------------------------------------------
 KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel", "ts_raster_fwd"),
                    ("reduce_partials_kernel", "ts_reduce_partials"), ("sort_tiles", "ts_sort_tiles"),
-                   ("bin_scatter_kernel", "ts_bin_scatter"), ("bin_count_kernel", "ts_bin_count"),
+                   ("bin_scatter_", "ts_bin_scatter"), ("bin_count_kernel", "ts_bin_count"),
                    ("sh_colors_fwd_kernel", "ts_colors_pack_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_colors_pack_fwd"),
                    ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
                    ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
@@ -294,7 +294,7 @@ def collect_pmc(workload_argv, timeout_s: float = 150.0):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
                    sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1",
                    "--profile-steps", "1", "--no-cpu-baseline", "--no-pmc", "--no-bandwidth",
-                   "--gather-calibration"] + workload_argv
+                   "--gather-calibration", "--no-rgbd-figure"] + workload_argv
             env = dict(os.environ, TMPDIR="/tmp")
             for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k_, None)
@@ -303,6 +303,8 @@ def collect_pmc(workload_argv, timeout_s: float = 150.0):
             files = list(Path(tmp).rglob("*counter_collection.csv"))
             if r.returncode != 0 or not files:
                 return None
+            # per KERNEL means first, then summed per entry: an entry that launches several kernels per call
+            # (sort, scan, offsets, the two scatter hops) is the sum of its kernels' per-dispatch means
             acc, seen = collections.defaultdict(float), collections.defaultdict(set)
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] != counter:
@@ -311,10 +313,13 @@ def collect_pmc(workload_argv, timeout_s: float = 150.0):
                 entry = next((e for pat, e in KERNEL_TO_ENTRY if pat in name), None)
                 if entry is None:
                     continue
-                acc[entry] += float(row["Counter_Value"])
-                seen[entry].add(row["Dispatch_Id"])
-            for entry, tot in acc.items():
-                res[entry][key] = tot / max(1, len(seen[entry]))
+                acc[(entry, name)] += float(row["Counter_Value"])
+                seen[(entry, name)].add(row["Dispatch_Id"])
+            per_entry_sum = collections.defaultdict(float)
+            for (entry, name), tot in acc.items():
+                per_entry_sum[entry] += tot / max(1, len(seen[(entry, name)]))
+            for entry, v in per_entry_sum.items():
+                res[entry][key] = v
         except Exception:
             return None
         finally:

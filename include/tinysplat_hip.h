@@ -163,9 +163,12 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
 int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins, void* stream);
 
 /* Writes the id of every Gaussian into the bucket of each tile its rectangle covers (bucket_ids[I];
- * order inside a bucket is arbitrary until ts_sort_tiles). */
+ * order inside a bucket is arbitrary until ts_sort_tiles).  scratch: NULL, or I more int32 (the
+ * gaussian_ids_sorted buffer may be passed: it is dead until ts_sort_tiles) - the ids then reach their buckets in
+ * two coalesced hops (tile group, then tile) instead of one 4-byte store per cache line; same buckets. */
 int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const float* splats,
-                   const ts_camera* cam_host, const int32_t* bin_ws, int32_t* bucket_ids, void* stream);
+                   const ts_camera* cam_host, const int32_t* bin_ws, int32_t* bucket_ids, int32_t* scratch,
+                   void* stream);
 
 /* Sorts every tile bucket ascending by (depth bits, gaussian id) - i.e. the order of a stable sort
  * of (tile<<32 | depth-bits) keys emitted Gaussian-major - reading bucket_ids[I] and depths[n] and
@@ -257,6 +260,7 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_TIGHT 1
 #define TS_FRAME_SPLIT 2
 #define TS_FRAME_NARROW_WAVES 8        /* TS_RASTER_NARROW_WAVES for the compositing launches (cam.wide_tiles) */
+#define TS_FRAME_DIRECT_SCATTER 32     /* one-hop ts_bin_scatter (scratch = NULL): A/B timing */
 #define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
                                           stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */
 typedef struct ts_frame {

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_t
         if (threadIdx.x == 0) carry += total;
         __syncthreads();
     }
+    if (threadIdx.x == 0) tile_total[num_tiles] = carry;     // tile_start[T]: end of the last bucket
 }
 
 __global__ __launch_bounds__(kThreads) void column_finish_kernel(int num_tiles, int chunks,
@@ -420,6 +421,55 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
         t -= t0;
         if ((unsigned)t < (unsigned)tw) bucket_ids[atomicAdd(&cursor[t], 1)] = i;
     });
+}
+
+// Two-level scatter.  The direct scatter above writes every 4-byte id to a different cache line (a chunk of
+// 4096 Gaussians puts ~2 entries into each of 8160 buckets) from whichever XCD runs the chunk: the L2s hold
+// partial lines of the same bucket and write them back separately - WRITE_SIZE measured 8x the id bytes
+// (131 MB for 16 MB on config 3).  With a scratch buffer of I words the ids instead travel in two coalesced
+// hops:
+//   coarse  each chunk appends (id | tile-in-group << 27) to the region of the tile GROUP (kCoarseTiles = 32
+//           consecutive lists) - a group's region is the concatenation of its tiles' buckets, so a chunk's
+//           entries for it form one run of ~64 words;
+//   fine    one workgroup per group streams its region and places the ids in the tiles' buckets with LDS
+//           cursors: all of a bucket's lines are written by one workgroup, merge in one L2 and leave as full lines.
+constexpr int kCoarseShift = 5;
+constexpr int kCoarseTiles = 1 << kCoarseShift;
+constexpr int kCoarseIdBits = 32 - kCoarseShift;            // ids below 2^27
+
+__global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
+    int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
+    const float4* __restrict__ splats, const ts_camera cam, int num_tiles, const int* __restrict__ bases,
+    const int* __restrict__ tile_start, int* __restrict__ scratch) {
+    extern __shared__ int cursor[];
+    const int groups = (num_tiles + kCoarseTiles - 1) >> kCoarseShift;
+    const int* src = bases + (size_t)blockIdx.x * num_tiles;
+    for (int g = threadIdx.x; g < groups; g += kBinThreads) {
+        const int t0 = g << kCoarseShift, t1 = min(num_tiles, t0 + kCoarseTiles);
+        int c = tile_start[t0];
+        for (int t = t0; t < t1; ++t) c += src[t];          // entries of earlier chunks in this group's tiles
+        cursor[g] = c;
+    }
+    __syncthreads();
+    const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+    walk_chunk(g0, g1, xys, radii, splats, cam, [&](int t, int i) {
+        scratch[atomicAdd(&cursor[t >> kCoarseShift], 1)] = i | ((t & (kCoarseTiles - 1)) << kCoarseIdBits);
+    });
+}
+
+__global__ __launch_bounds__(kThreads) void bin_scatter_fine_kernel(int num_tiles,
+                                                                    const int* __restrict__ tile_start,
+                                                                    const int* __restrict__ scratch,
+                                                                    int* __restrict__ bucket_ids) {
+    __shared__ int cursor[kCoarseTiles];
+    const int t0 = blockIdx.x << kCoarseShift, t1 = min(num_tiles, t0 + kCoarseTiles);
+    if ((int)threadIdx.x < t1 - t0) cursor[threadIdx.x] = tile_start[t0 + threadIdx.x];
+    __syncthreads();
+    const int begin = tile_start[t0], end = tile_start[t1];
+    for (int j = begin + threadIdx.x; j < end; j += kThreads) {
+        const unsigned int w = (unsigned int)scratch[j];
+        bucket_ids[atomicAdd(&cursor[w >> kCoarseIdBits], 1)] = (int)(w & ((1u << kCoarseIdBits) - 1u));
+    }
 }
 
 // ---- per-tile bitonic sort ---------------------------------------------------------------------
@@ -800,7 +850,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
     if (num_tiles < 0) num_tiles = 0;
-    return (int64_t)(bin_num_chunks(n) + 1 + kScanGroups) * num_tiles + 1;
+    return (int64_t)(bin_num_chunks(n) + 1 + kScanGroups) * num_tiles + 2;     // + tile_start[T], + the spare word
 }
 
 
@@ -831,8 +881,8 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     if (num_tiles == 0) return 0;
     if (!bin_ws || !tile_bins) return TS_E_BADARG;
     const int chunks = bin_num_chunks(n);
-    int* tile_total = bin_ws + (size_t)chunks * num_tiles;
-    int* group_sum = tile_total + num_tiles;
+    int* tile_total = bin_ws + (size_t)chunks * num_tiles;     // [T + 1]: becomes tile_start, [T] = grand total
+    int* group_sum = tile_total + num_tiles + 1;
     const int per_group = (chunks + kScanGroups - 1) / kScanGroups;
     const int groups = (chunks + per_group - 1) / per_group;
     hipStream_t s = (hipStream_t)stream;
@@ -849,7 +899,8 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
 }
 
 int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const float* splats,
-                   const ts_camera* cam, const int32_t* bin_ws, int32_t* bucket_ids, void* stream) {
+                   const ts_camera* cam, const int32_t* bin_ws, int32_t* bucket_ids, int32_t* scratch,
+                   void* stream) {
     if (n < 0 || !cam) return TS_E_BADARG;
     if (n == 0) return 0;
     if (!xys || !radii || !bin_ws || !bucket_ids) return TS_E_BADARG;
@@ -857,6 +908,16 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
     if (nt <= 0) return 0;
     const int chunks = bin_num_chunks(n);
     const int chunk = (n + chunks - 1) / chunks;
+    const int* tile_start = bin_ws + (size_t)chunks * nt;
+    if (scratch && n < (1 << kCoarseIdBits)) {          // two coalesced hops (see bin_scatter_coarse_kernel)
+        const int groups = (nt + kCoarseTiles - 1) >> kCoarseShift;
+        hipLaunchKernelGGL(bin_scatter_coarse_kernel, dim3(chunks), dim3(kBinThreads), (size_t)groups * sizeof(int),
+                           (hipStream_t)stream, n, chunk, xys, radii, reinterpret_cast<const float4*>(splats), *cam,
+                           nt, bin_ws, tile_start, scratch);
+        hipLaunchKernelGGL(bin_scatter_fine_kernel, dim3(groups), dim3(kThreads), 0, (hipStream_t)stream, nt,
+                           tile_start, scratch, bucket_ids);
+        return launch_status();
+    }
     const int window = bin_window_tiles(n, nt);
     const int windows = (nt + window - 1) / window;
     const size_t lds = (size_t)window * sizeof(int);
@@ -866,7 +927,7 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
                        (hipStream_t)stream, n, chunk, xys, radii,
                        reinterpret_cast<const float4*>(splats), *cam, nt, window, bin_ws,
-                       bin_ws + (size_t)chunks * nt, bucket_ids);
+                       tile_start, bucket_ids);
     return launch_status();
 }
 

@@ -85,7 +85,9 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
     if (f->num_intersects > 0) {
         const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
-        TS_TRY(ts_bin_scatter(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, f->bucket_ids, stream));
+        // the sorted-id buffer is dead until the sort: it carries the ids between the two scatter hops
+        TS_TRY(ts_bin_scatter(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, f->bucket_ids,
+                              (f->flags & TS_FRAME_DIRECT_SCATTER) ? nullptr : f->gaussian_ids_sorted, stream));
         TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
                              f->bin_ws, f->bin_ws + (ts_bin_ws_ints(f->n, num_tiles(f)) - 1), stream));
     }

@@ -97,6 +97,9 @@ _bg_cache = {}          # (storage address, version, channels) -> contiguous bac
 # TS_STRIPE_SPARSE=0 for A/B timing.
 STRIPE_SPARSE = os.environ.get("TS_STRIPE_SPARSE", "1") != "0"
 
+# ts_bin_scatter in two coalesced hops through the (still unused) sorted-id buffer; TS_TWO_HOP_SCATTER=0: one hop
+TWO_HOP_SCATTER = os.environ.get("TS_TWO_HOP_SCATTER", "1") != "0"
+
 DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
 
 # How the host waits for the intersection count (the one host read of a frame; the scan kernel stores it
@@ -201,7 +204,8 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
         # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
         stripe = STRIPE_SPARSE and cam.tile_rows < cam.tile_bounds_y
-        fr.flags = (1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
+        fr.flags = ((1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
+                    | (0 if TWO_HOP_SCATTER else 32))
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -301,7 +305,7 @@ def _steps_composite(lib, fr, s):
     nt = int(lib.ts_num_tiles(ctypes.byref(fr.cam)))
     if fr.num_intersects > 0:
         _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
-              fr.bucket_ids, s)
+              fr.bucket_ids, None if fr.flags & 32 else fr.gaussian_ids_sorted, s)
         _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
               fr.gaussian_ids_sorted, fr.bin_ws, fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
     _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam, fr.tile_bins,

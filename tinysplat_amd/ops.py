@@ -411,7 +411,7 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
         ids = torch.empty((max(total, 1),), **i32)
         if total > 0:
             _call("ts_bin_scatter", lib.ts_bin_scatter, n, _ptr(xys_c), _ptr(radii_c), None, cam,
-                  _ptr(bin_ws), _ptr(bucket_ids), s)
+                  _ptr(bin_ws), _ptr(bucket_ids), _ptr(ids), s)
             _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, _ptr(tile_bins), _ptr(depths_c),
                   _ptr(bucket_ids), _ptr(ids), _ptr(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
     b.num_intersects = total

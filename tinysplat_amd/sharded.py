@@ -288,7 +288,8 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     S.bucket = torch.empty((2 * cap,), **i32)
     S.ids = S.bucket[cap:cap + total]
     if total > 0:
-        _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket), s)
+        _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket),
+              S.bucket.data_ptr() + 4 * cap if _frame.TWO_HOP_SCATTER else None, s)
         _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, p(S.tile_bins), p(S.depths), p(S.bucket),
               S.bucket.data_ptr() + 4 * cap, p(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
     flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)

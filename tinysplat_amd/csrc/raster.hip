@@ -440,8 +440,83 @@ __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
     return x;
 }
 
+// The same reduction with the levels reordered so that the two in-row levels which DPP can write under a
+// BANK MASK run first, while there are most values: lane bit 3 (partner lane ^ 8 = row_ror:8, banks 2-3 =
+// bank_mask 0xC) and lane bit 2 (row_half_mirror pairs the two quads of a half-row, banks 1,3 = 0xA).  A merge
+// of two values is then two masked DPP adds (all lanes take a + perm(a), the lanes of the set bit are
+// overwritten with b + perm(b)) instead of two selects and a DPP add.  The compiler cannot be made to emit a
+// DPP add that keeps its destination in the masked-off lanes, hence the one asm block; inside it every DPP read
+// of a register lies at least two instructions behind the write (the VALU -> DPP hazard), and it begins and ends
+// with s_nop 1 because the compiler's hazard recogniser does not look into it.  15 masked adds take the ten
+// values to three registers; the cross-row levels and the two quad levels follow on those.
+//   c0: value 2 * bit2 + bit3 | c1: value 4 + 2 * bit2 + bit3 | c2: value 8 + bit3
+// returns x with lane l holding the wave sum of value 4 * bit4 + 2 * bit2 + bit3 (l < 32) or 8 + bit3 (l >= 32).
+#ifndef TS_FLUSH_ASM
+#define TS_FLUSH_ASM 0
+#endif
+#define TS_DPP_ROR8 "row_ror:8 row_mask:0xf bank_mask:0xf"
+#define TS_DPP_ROR8_HI "row_ror:8 row_mask:0xf bank_mask:0xc"
+#define TS_DPP_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
+#define TS_DPP_HM_HI "row_half_mirror row_mask:0xf bank_mask:0xa"
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+template <bool HAVE9>
+__device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane) {
+    float c0, c1, c2, t1, t3;
+    if (HAVE9) {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %5, %5 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %3, %7, %7 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %1, %9, %9 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %4, %11, %11 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %2, %13, %13 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %0, %6, %6 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %3, %8, %8 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %1, %10, %10 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %4, %12, %12 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %2, %14, %14 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %0, %0, %0 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %1, %1, %1 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %2, %2, %2 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %0, %3, %3 " TS_DPP_HM_HI "\n\t"
+            "v_add_f32_dpp %1, %4, %4 " TS_DPP_HM_HI "\n\t"
+            "s_nop 1"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(t1), "=&v"(t3)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+              "v"(v[9]));
+    } else {        // nine values: both halves of a row end up holding value 8 in c2
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %5, %5 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %3, %7, %7 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %1, %9, %9 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %4, %11, %11 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %2, %13, %13 " TS_DPP_ROR8 "\n\t"
+            "v_add_f32_dpp %0, %6, %6 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %3, %8, %8 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %1, %10, %10 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %4, %12, %12 " TS_DPP_ROR8_HI "\n\t"
+            "v_add_f32_dpp %0, %0, %0 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %1, %1, %1 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %2, %2, %2 " TS_DPP_HM "\n\t"
+            "v_add_f32_dpp %0, %3, %3 " TS_DPP_HM_HI "\n\t"
+            "v_add_f32_dpp %1, %4, %4 " TS_DPP_HM_HI "\n\t"
+            "s_nop 1"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(t1), "=&v"(t3)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    }
+    // lane bit 4: odd / even rows exchanged in one issue (v_permlane16_swap), c0 stays in the even rows
+    const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0), __float_as_uint(c1), false, false);
+    float d = __uint_as_float(r.x) + __uint_as_float(r.y);
+    d += __shfl_xor(d, 32, 64);                      // lane bit 5
+    c2 += __shfl_xor(c2, 16, 64);
+    c2 += __shfl_xor(c2, 32, 64);
+    float x = (lane & 32) ? c2 : d;                  // one register for the two quad levels
+    x = dpp_add_t<0x4E, 0xF>(x);
+    return dpp_add_t<0xB1, 0xF>(x);
+}
+
 // Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
-// (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag).
+// (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag; TS_FLUSH_ASM: the first lane
+// of ten quads stores, lane 1 sets the flag).
 template <int CH>
 __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
@@ -453,11 +528,19 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         float v10[10];
 #pragma unroll
         for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
-        r = wave_sum10<(CH == 4)>(v10, lane);
+        r = TS_FLUSH_ASM ? wave_sum10_masked<(CH == 4)>(v10, lane) : wave_sum10<(CH == 4)>(v10, lane);
     }
-    const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
     const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
     (void)num_isects;
+    if (TS_FLUSH_ASM) {
+        const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1;
+        const int w = (lane & 32) ? 8 + b3 : 4 * b4 + 2 * b2 + b3;
+        const bool writer = (lane & 3) == 0 && ((lane & 32) == 0 || (lane & 0x14) == 0);
+        if (writer && w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
+        if (lane == 1) row_flags[slot] = 1;                    // this row now holds data
+        return;
+    }
+    const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
     if (w >= 0) {
         if (w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
         else if (w == 10) row_flags[slot] = 1;                 // this row now holds data

@@ -17,6 +17,22 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef TS_SH_THREADS
+#define TS_SH_THREADS 256
+#endif
+#ifndef TS_NT_STORE
+#define TS_NT_STORE 0        // write-once gradient streams with non-temporal stores (A/B knob)
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4(float4* p, float a, float b, float c, float d) {
+    if (TS_NT_STORE) {
+        f4v v = {a, b, c, d};
+        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+    } else {
+        *p = make_float4(a, b, c, d);
+    }
+}
+constexpr int kShThreads = TS_SH_THREADS;       // Gaussians (= threads) per workgroup of the fused colour stage
 
 __device__ __forceinline__ ts::Cam load_cam(const float* __restrict__ viewmat,
                                             const float* __restrict__ projmat, const ts_camera c) {
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
 // mask[n] bit c is set where the clamp passes gradient (pre-clamp value >= 0, torch's rule).
 // ------------------------------------------------------------------------------------------------
 template <int DEG>
-__global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
+__global__ __launch_bounds__(kShThreads) void sh_colors_fwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const float* __restrict__ dc, const float* __restrict__ rest, float* __restrict__ colors,
     unsigned char* __restrict__ mask, const ts::PackArgs pk) {
@@ -230,27 +246,27 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
     constexpr int RS = 3 * (KA - 1);                // active floats of a `rest` row
     constexpr int RSP = RS | 1;
     extern __shared__ __align__(16) float lds[];
-    const int g0 = blockIdx.x * kThreads;
-    const int cnt = min(kThreads, n - g0);
+    const int g0 = blockIdx.x * kShThreads;
+    const int cnt = min(kShThreads, n - g0);
     const int tid = threadIdx.x;
     if (RS > 0) {
         const size_t row = 3 * (size_t)(num_bases - 1);
         const float* src = rest + (size_t)g0 * row;
-        if (num_bases == KA && cnt == kThreads && ((kThreads * RS) & 3) == 0) {
+        if (num_bases == KA && cnt == kShThreads && ((kShThreads * RS) & 3) == 0) {
             // all 16-byte loads of the span are issued before the first LDS write, so every lane
             // has its ~RS/4 requests in flight at once (the kernel is a pure HBM stream)
             const float4* src4 = reinterpret_cast<const float4*>(src);
-            constexpr int total4 = kThreads * RS / 4;
-            constexpr int per = (total4 + kThreads - 1) / kThreads;
+            constexpr int total4 = kShThreads * RS / 4;
+            constexpr int per = (total4 + kShThreads - 1) / kShThreads;
             float4 v[per > 0 ? per : 1];
 #pragma unroll
             for (int u = 0; u < per; ++u) {
-                const int f4 = tid + u * kThreads;
+                const int f4 = tid + u * kShThreads;
                 v[u] = f4 < total4 ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < per; ++u) {
-                const int f4 = tid + u * kThreads;
+                const int f4 = tid + u * kShThreads;
                 if (f4 < total4) {
                     const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_kernel(
             }
         } else {
             const int total = cnt * RS;
-            for (int f = tid; f < total; f += kThreads) {
+            for (int f = tid; f < total; f += kShThreads) {
                 const int g = f / RS, j = f % RS;
                 lds[g * RSP + j] = src[(size_t)g * row + j];
             }
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
 }
 
 template <int DEG>
-__global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
+__global__ __launch_bounds__(kShThreads) void sh_colors_bwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const unsigned char* __restrict__ mask, const float* __restrict__ v_colors,
     float* __restrict__ v_dc, float* __restrict__ v_rest) {
@@ -330,8 +346,8 @@ __global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
     extern __shared__ __align__(16) float lds[];
     const int RS = 3 * (num_bases - 1);
     const int RSP = RS | 1;
-    const int g0 = blockIdx.x * kThreads;
-    const int cnt = min(kThreads, n - g0);
+    const int g0 = blockIdx.x * kShThreads;
+    const int cnt = min(kShThreads, n - g0);
     const int tid = threadIdx.x;
     if (tid < cnt) {
         const int i = g0 + tid;
@@ -355,17 +371,17 @@ __global__ __launch_bounds__(kThreads) void sh_colors_bwd_kernel(
     const int total = cnt * RS;
     if ((total & 3) == 0 && (((size_t)g0 * RS) & 3) == 0) {
         float4* dst4 = reinterpret_cast<float4*>(dst);
-        for (int f4 = tid; f4 < total / 4; f4 += kThreads) {
+        for (int f4 = tid; f4 < total / 4; f4 += kShThreads) {
             float e[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ff = 4 * f4 + u;
                 e[u] = lds[(ff / RS) * RSP + (ff % RS)];
             }
-            dst4[f4] = make_float4(e[0], e[1], e[2], e[3]);
+            store4(dst4 + f4, e[0], e[1], e[2], e[3]);
         }
     } else {
-        for (int f = tid; f < total; f += kThreads) dst[f] = lds[(f / RS) * RSP + (f % RS)];
+        for (int f = tid; f < total; f += kShThreads) dst[f] = lds[(f / RS) * RSP + (f % RS)];
     }
 }
 
@@ -540,13 +556,14 @@ static int launch_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_base
         return launch_status();
     }
     const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
-    const size_t lds = (size_t)kThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
+    const size_t lds = (size_t)kShThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
+    const int grid_d = (n + kShThreads - 1) / kShThreads;
 #define TS_SHC_FWD(D)                                                                             \
     do {                                                                                          \
         if (lds > 48 * 1024)                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_fwd_kernel<D>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n,         \
+        hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid_d), dim3(kShThreads), lds, s, n,     \
                            num_bases, means3d, origin, colors_dc, colors_rest, colors, clamp_mask, pk); \
     } while (0)
     switch (degrees_to_use) {
@@ -596,15 +613,15 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     if (n == 0) return 0;
     if (!means3d || !origin || !v_colors || !v_colors_dc || (num_bases > 1 && !v_colors_rest))
         return TS_E_BADARG;
-    const int grid = (n + kThreads - 1) / kThreads;
-    const size_t lds = (size_t)kThreads * ((3 * (num_bases - 1)) | 1) * sizeof(float);
+    const int grid = (n + kShThreads - 1) / kShThreads;
+    const size_t lds = (size_t)kShThreads * ((3 * (num_bases - 1)) | 1) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define TS_SHC_BWD(D)                                                                             \
     do {                                                                                          \
         if (lds > 48 * 1024)                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_bwd_kernel<D>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kThreads), lds, s, n,         \
+        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kShThreads), lds, s, n,       \
                            num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,         \
                            v_colors_rest);                                                        \
     } while (0)

@@ -56,6 +56,22 @@ namespace {
 #define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0)
 #endif
 
+// TS_STATS=1 (developer build, tools/raster_stats.py; slow): dynamic work counters of the compositing kernels,
+// ts_stats = {fwd staged entries, fwd block bodies, bwd staged entries, bwd block bodies entered, bwd bodies with
+// a valid lane, bwd rows flushed, bwd valid lanes, bwd list entries walked}.
+#ifndef TS_STATS
+#define TS_STATS 0
+#endif
+#if TS_STATS
+__device__ unsigned long long ts_stats[8];
+#define TS_STAT(i, v)                                                                       \
+    do {                                                                                    \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&ts_stats[i], (unsigned long long)(v));      \
+    } while (0)
+#else
+#define TS_STAT(i, v) ((void)0)
+#endif
+
 #ifndef TS_REDUCE_AHEAD
 #define TS_REDUCE_AHEAD 4                // rows of a Gaussian requested together by reduce_partials
 #endif
@@ -240,6 +256,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 #pragma unroll
         for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
+            TS_STAT(1, 1);
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k % NBX], r0.y - fpy[k / NBX]);
             float a = __builtin_amdgcn_exp2f(-sgl);
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             lds[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
         }
         TS_WAVE_SYNC();
+        TS_STAT(0, cnt);
         // bit NB of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
         // once per chunk so that the common case runs a loop without those tests
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
@@ -577,6 +595,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
 #pragma unroll
         for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
+            TS_STAT(3, 1);
             const float dx = r0.x - fpx[k % NBX], dy = r0.y - fpy[k / NBX];
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, dx, dy);
             const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
@@ -587,6 +606,8 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
                 validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
             }
             if (validm == 0ull) continue;                              // wave-uniform
+            TS_STAT(4, 1);
+            TS_STAT(6, __popcll(validm));
             any = 1;
             const float am = TS_LANE(validm) ? a : 0.0f;
             const float ra = __builtin_amdgcn_rcpf(1.0f - am);
@@ -616,6 +637,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         // joining paths; kept opaque, all four bodies accumulate in place and the flush reads acc.
         asm volatile("" : "+s"(any));
         if (any) {
+            TS_STAT(5, 1);
             flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
                           partials, row_flags, lane);
             // zero the accumulators two at a time (v_mov_b64 on a register pair)
@@ -762,6 +784,8 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             lds[4 * pos + 3] = make_float4(__int_as_float(s.mask), 0.f, 0.f, 0.f);
         }
         TS_WAVE_SYNC();
+        TS_STAT(2, cnt);
+        TS_STAT(7, min(64, hi - range.x + 1));
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
             bwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
                                      row_flags, lane);
@@ -877,6 +901,17 @@ inline int launch_status() { return (int)hipGetLastError(); }
 }  // namespace
 
 extern "C" {
+
+#if TS_STATS
+int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer builds only (not part of the ABI)
+    hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ts_stats), sizeof(ts_stats));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ts_stats), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,

@@ -144,7 +144,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 /* Tile bucketing without global atomics.  The Gaussians are cut into B = ts_bin_chunks(n) contiguous
  * chunks; bin_ws (>= ts_bin_ws_ints(n, num_tiles) int32, num_tiles = tile_rows * tile_bounds_x) holds
- * the B x num_tiles count matrix, num_tiles tile totals and a 16 x num_tiles scratch for the column scan.  Stripe-local tile index
+ * the B x num_tiles count matrix, num_tiles + 1 tile starts and one spare word.  Stripe-local tile index
  * t = (ty - tile_row0) * tile_bounds_x + tx. */
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles);
 

@@ -7,7 +7,7 @@
 // without a global sort:
 //   scan_tiles      wave-scan (DPP-free __shfl_up ladder inside a wave, LDS across the 4 waves)
 //   bin_count       per-chunk tile histograms in LDS (ds_add), B x T count matrix, no global atomics
-//   tile_offsets    column scan of the matrix (per-chunk bases) + exclusive scan over tiles -> tile_bins
+//   tile_offsets    column scan of the matrix (per-chunk bases, one launch) + exclusive scan over tiles -> tile_bins
 //   bin_scatter     replays each chunk with LDS cursors preloaded from its bases, 4-byte id stores
 //                   (the sort gathers depth by id from the 4 N-byte, L2-resident depth array;
 //                   sort key = depth_bits << 32 | gaussian_id, unique inside a tile)
@@ -312,41 +312,49 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) dst[j] = hist[j];
 }
 
-// Column scan of the B x T count matrix in three small steps so that it runs on (tiles x groups)
-// lanes instead of one lane per tile: per-group column sums, the scan over the <= kScanGroups group
-// sums of a tile, the exclusive scan over tiles, then the per-group finish.
-constexpr int kScanGroups = 16;
+constexpr int kScanGroups = 16;      // chunk groups of the column scan (waves of its workgroup)
 
-__global__ __launch_bounds__(kThreads) void column_group_sum_kernel(int num_tiles, int chunks,
-                                                                    int per_group,
-                                                                    const int* __restrict__ counts,
-                                                                    int* __restrict__ group_sum) {
-    const int t = blockIdx.x * kThreads + threadIdx.x;
-    const int g = blockIdx.y;
-    if (t >= num_tiles) return;
+// Column scan of the B x T count matrix in ONE launch: a workgroup owns 64 tile columns, its 16 waves own the
+// 16 chunk groups; thread (tile, group) loads its <= kColPer counts (coalesced across the tiles of a wave, all
+// loads issued before the first use), scans them in registers, the group sums of a tile are exchanged through LDS,
+// and the thread writes the exclusive prefixes back.  tile_total[t] = column sum.  Replaces three launches
+// (group sums, scan of the group sums, finish: ~6 us each on an in-order stream whatever their size).
+constexpr int kColTiles = 64;
+constexpr int kColPer = (kBinMaxChunks + kScanGroups - 1) / kScanGroups;      // 32 chunks per group at most
+__global__ __launch_bounds__(kColTiles * kScanGroups) void column_scan_kernel(int num_tiles, int chunks,
+                                                                              int per_group,
+                                                                              int* __restrict__ counts,
+                                                                              int* __restrict__ tile_total) {
+    __shared__ int gsum[kScanGroups][kColTiles];
+    const int tl = threadIdx.x & (kColTiles - 1), g = threadIdx.x / kColTiles;
+    const int t = blockIdx.x * kColTiles + tl;
     const int b0 = g * per_group, b1 = min(chunks, b0 + per_group);
+    int c[kColPer];
     int sum = 0;
-#pragma unroll 4
-    for (int b = b0; b < b1; ++b) sum += counts[(size_t)b * num_tiles + t];
-    group_sum[(size_t)g * num_tiles + t] = sum;
-}
-
-// one lane per tile: exclusive scan over its group sums -> group bases; tile_total[t] = column sum
-__global__ __launch_bounds__(kThreads) void column_group_scan_kernel(int num_tiles, int groups,
-                                                                     int* __restrict__ group_sum,
-                                                                     int* __restrict__ tile_total) {
-    const int t = blockIdx.x * kThreads + threadIdx.x;
-    if (t >= num_tiles) return;
-    int c[kScanGroups];
+    if (t < num_tiles) {
 #pragma unroll
-    for (int g = 0; g < kScanGroups; ++g) c[g] = g < groups ? group_sum[(size_t)g * num_tiles + t] : 0;
-    int v = 0;
+        for (int j = 0; j < kColPer; ++j) c[j] = (b0 + j < b1) ? counts[(size_t)(b0 + j) * num_tiles + t] : 0;
 #pragma unroll
-    for (int g = 0; g < kScanGroups; ++g) {
-        if (g < groups) group_sum[(size_t)g * num_tiles + t] = v;
-        v += c[g];
+        for (int j = 0; j < kColPer; ++j) {
+            const int v = c[j];
+            c[j] = sum;
+            sum += v;
+        }
     }
-    tile_total[t] = v;
+    gsum[g][tl] = sum;
+    __syncthreads();
+    if (t >= num_tiles) return;
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < kScanGroups; ++q) {
+        const int v = gsum[q][tl];
+        if (q < g) base += v;
+        tot += v;
+    }
+#pragma unroll
+    for (int j = 0; j < kColPer; ++j)
+        if (b0 + j < b1) counts[(size_t)(b0 + j) * num_tiles + t] = base + c[j];
+    if (g == 0) tile_total[t] = tot;
 }
 
 // single workgroup of 1024 threads, 8 tiles per lane and step (a 1080p frame's 8160 tiles in one step):
@@ -385,24 +393,6 @@ __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_t
         __syncthreads();
     }
     if (threadIdx.x == 0) tile_total[num_tiles] = carry;     // tile_start[T]: end of the last bucket
-}
-
-__global__ __launch_bounds__(kThreads) void column_finish_kernel(int num_tiles, int chunks,
-                                                                 int per_group,
-                                                                 int* __restrict__ counts,
-                                                                 const int* __restrict__ group_base) {
-    const int t = blockIdx.x * kThreads + threadIdx.x;
-    const int g = blockIdx.y;
-    if (t >= num_tiles) return;
-    const int b0 = g * per_group, b1 = min(chunks, b0 + per_group);
-    int run = group_base[(size_t)g * num_tiles + t];
-#pragma unroll 4
-    for (int b = b0; b < b1; ++b) {
-        int* p = counts + (size_t)b * num_tiles + t;
-        const int c = *p;
-        *p = run;
-        run += c;
-    }
 }
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
@@ -748,10 +738,9 @@ __device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
     }
 }
 
-// Three launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles
-// per workgroup) and lists the tiles beyond kSortCap; the second sorts the tiles in between with one
-// workgroup each; the third is a small persistent grid that walks the (normally empty) list with the
-// sample sort.
+// Two launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles per
+// workgroup) and queues the larger ones; the second is a persistent grid that walks the queue with one
+// workgroup per tile.
 __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     int num_tiles, const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_count,
@@ -762,8 +751,8 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     const int n = range.y - range.x;
     if (n <= 0) return;
-    if (n > kWaveSortMax) {                      // (kWaveSortMax, kSortCap]: sort_tiles_mid_kernel
-        if (n > kSortCap && lane == 0) large_list[atomicAdd(large_count, 1)] = tile;
+    if (n > kWaveSortMax) {                      // beyond one wave's network: queued for sort_tiles_big_kernel
+        if (lane == 0) large_list[atomicAdd(large_count, 1)] = tile;
         return;
     }
     const int* g = bucket_ids + range.x;
@@ -775,19 +764,10 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     else sort_tile_wave<16>(g, depths, out, n, lane);
 }
 
-// Tiles of kWaveSortMax < n <= kSortCap keys: one workgroup per tile, register network with LDS for the
-// cross-wave stages.  Launched over all tiles; the others leave at once.
-__global__ __launch_bounds__(kThreads) void sort_tiles_mid_kernel(
-    const int* __restrict__ tile_bins, const float* __restrict__ depths,
-    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
-    __shared__ unsigned long long lk[kSortCap];
-    const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
-    const int n = range.y - range.x;
-    if (n <= kWaveSortMax || n > kSortCap) return;
-    sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lk);
-}
-
-__global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
+// The queued tiles (more than kWaveSortMax keys), one workgroup per tile from a small persistent grid: up to
+// kSortCap keys the register network with LDS for the cross-wave stages, beyond that the sample sort.  One launch
+// that usually finds an empty queue (config 3: no tile above 614 keys) instead of two.
+__global__ __launch_bounds__(kThreads) void sort_tiles_big_kernel(
     const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted,
     const int* __restrict__ large_count, const int* __restrict__ large_list) {
@@ -795,9 +775,12 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
     const int count = *large_count;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int2 range = reinterpret_cast<const int2*>(tile_bins)[large_list[q]];
+        const int n = range.y - range.x;
         __syncthreads();
-        sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, range.y - range.x,
-                         lds_large);
+        if (n <= kSortCap)
+            sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_large);
+        else
+            sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_large);
     }
 }
 
@@ -850,7 +833,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
     if (num_tiles < 0) num_tiles = 0;
-    return (int64_t)(bin_num_chunks(n) + 1 + kScanGroups) * num_tiles + 2;     // + tile_start[T], + the spare word
+    return (int64_t)(bin_num_chunks(n) + 1) * num_tiles + 2;     // counts | tile_start[T + 1] | the spare word
 }
 
 
@@ -882,19 +865,12 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     if (!bin_ws || !tile_bins) return TS_E_BADARG;
     const int chunks = bin_num_chunks(n);
     int* tile_total = bin_ws + (size_t)chunks * num_tiles;     // [T + 1]: becomes tile_start, [T] = grand total
-    int* group_sum = tile_total + num_tiles + 1;
     const int per_group = (chunks + kScanGroups - 1) / kScanGroups;
-    const int groups = (chunks + per_group - 1) / per_group;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid2((num_tiles + kThreads - 1) / kThreads, groups);
-    hipLaunchKernelGGL(column_group_sum_kernel, grid2, dim3(kThreads), 0, s, num_tiles, chunks,
-                       per_group, bin_ws, group_sum);
-    hipLaunchKernelGGL(column_group_scan_kernel, dim3((num_tiles + kThreads - 1) / kThreads),
-                       dim3(kThreads), 0, s, num_tiles, groups, group_sum, tile_total);
+    hipLaunchKernelGGL(column_scan_kernel, dim3((num_tiles + kColTiles - 1) / kColTiles),
+                       dim3(kColTiles * kScanGroups), 0, s, num_tiles, chunks, per_group, bin_ws, tile_total);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kOffsetsThreads), 0, s, num_tiles, tile_total,
                        tile_bins, bin_ws + (ts_bin_ws_ints(n, num_tiles) - 1));
-    hipLaunchKernelGGL(column_finish_kernel, grid2, dim3(kThreads), 0, s, num_tiles, chunks,
-                       per_group, bin_ws, group_sum);
     return launch_status();
 }
 
@@ -949,10 +925,8 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
     hipLaunchKernelGGL(sort_tiles_small_kernel, dim3((num_tiles + kThreads / 64 - 1) / (kThreads / 64)),
                        dim3(kThreads), 0, s, (int)num_tiles, tile_bins, depths, bucket_ids,
                        gaussian_ids_sorted, counter, list);
-    hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
-                       bucket_ids, gaussian_ids_sorted);
-    const int grid = num_tiles < 768 ? num_tiles : 768;
-    hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
+    const int grid = num_tiles < 2048 ? num_tiles : 2048;
+    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
                        bucket_ids, gaussian_ids_sorted, counter, list);
     return launch_status();
 }

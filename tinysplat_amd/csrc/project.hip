@@ -17,11 +17,19 @@
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef TS_SH_THREADS
-#define TS_SH_THREADS 256
+// Gaussians (= threads) per workgroup of the fused colour stage.  Measured on config 3: forward 128 (23 KB of LDS
+// per workgroup, six of them per CU: 72 -> 63 us with the non-temporal stores below), backward 256 (128: 51 -> 56 us).
+#ifndef TS_SH_THREADS_FWD
+#define TS_SH_THREADS_FWD 128
+#endif
+#ifndef TS_SH_THREADS_BWD
+#define TS_SH_THREADS_BWD 256
 #endif
 #ifndef TS_NT_STORE
-#define TS_NT_STORE 0        // write-once gradient streams with non-temporal stores (A/B knob)
+// Write-once gradient streams (192 N bytes of v_colors_rest per frame) leave with NON-TEMPORAL stores: they do
+// not displace the coefficient rows that the next frame's forward reads from the 256 MB Infinity Cache
+// (measured on config 3: sh_colors_bwd 51 -> 47 us and colors_pack_fwd 73 -> 66 us).  TS_NT_STORE=0 for A/B timing.
+#define TS_NT_STORE 1
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store4(float4* p, float a, float b, float c, float d) {
@@ -32,7 +40,20 @@ __device__ __forceinline__ void store4(float4* p, float a, float b, float c, flo
         *p = make_float4(a, b, c, d);
     }
 }
-constexpr int kShThreads = TS_SH_THREADS;       // Gaussians (= threads) per workgroup of the fused colour stage
+#ifndef TS_NT_GRADS
+#define TS_NT_GRADS 0        // project_bwd's three gradient streams non-temporal (A/B knob)
+#endif
+constexpr int kShThreadsFwd = TS_SH_THREADS_FWD, kShThreadsBwd = TS_SH_THREADS_BWD;
+#ifndef TS_NT_LOAD
+#define TS_NT_LOAD 0         // read-once coefficient rows with non-temporal loads (A/B knob)
+#endif
+__device__ __forceinline__ float4 load4_stream(const float4* p) {
+    if (TS_NT_LOAD) {
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
 
 __device__ __forceinline__ ts::Cam load_cam(const float* __restrict__ viewmat,
                                             const float* __restrict__ projmat, const ts_camera c) {
@@ -126,12 +147,20 @@ __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
             for (int k = 0; k < 4; ++k) g.v_quat[k] = (g.v_quat[k] - q[k] * dotp) * inv_n;
         }
     }
+#if TS_NT_GRADS
+    __builtin_nontemporal_store(g.v_mean[0], v_means3d + 3 * i); __builtin_nontemporal_store(g.v_mean[1], v_means3d + 3 * i + 1);
+    __builtin_nontemporal_store(g.v_mean[2], v_means3d + 3 * i + 2);
+    __builtin_nontemporal_store(g.v_scale[0], v_scales + 3 * i); __builtin_nontemporal_store(g.v_scale[1], v_scales + 3 * i + 1);
+    __builtin_nontemporal_store(g.v_scale[2], v_scales + 3 * i + 2);
+    store4(reinterpret_cast<float4*>(v_quats) + i, g.v_quat[0], g.v_quat[1], g.v_quat[2], g.v_quat[3]);
+#else
     v_means3d[3 * i] = g.v_mean[0]; v_means3d[3 * i + 1] = g.v_mean[1];
     v_means3d[3 * i + 2] = g.v_mean[2];
     v_scales[3 * i] = g.v_scale[0]; v_scales[3 * i + 1] = g.v_scale[1];
     v_scales[3 * i + 2] = g.v_scale[2];
     reinterpret_cast<float4*>(v_quats)[i] =
         make_float4(g.v_quat[0], g.v_quat[1], g.v_quat[2], g.v_quat[3]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
 // mask[n] bit c is set where the clamp passes gradient (pre-clamp value >= 0, torch's rule).
 // ------------------------------------------------------------------------------------------------
 template <int DEG>
-__global__ __launch_bounds__(kShThreads) void sh_colors_fwd_kernel(
+__global__ __launch_bounds__(kShThreadsFwd) void sh_colors_fwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const float* __restrict__ dc, const float* __restrict__ rest, float* __restrict__ colors,
     unsigned char* __restrict__ mask, const ts::PackArgs pk) {
@@ -246,27 +275,27 @@ __global__ __launch_bounds__(kShThreads) void sh_colors_fwd_kernel(
     constexpr int RS = 3 * (KA - 1);                // active floats of a `rest` row
     constexpr int RSP = RS | 1;
     extern __shared__ __align__(16) float lds[];
-    const int g0 = blockIdx.x * kShThreads;
-    const int cnt = min(kShThreads, n - g0);
+    const int g0 = blockIdx.x * kShThreadsFwd;
+    const int cnt = min(kShThreadsFwd, n - g0);
     const int tid = threadIdx.x;
     if (RS > 0) {
         const size_t row = 3 * (size_t)(num_bases - 1);
         const float* src = rest + (size_t)g0 * row;
-        if (num_bases == KA && cnt == kShThreads && ((kShThreads * RS) & 3) == 0) {
+        if (num_bases == KA && cnt == kShThreadsFwd && ((kShThreadsFwd * RS) & 3) == 0) {
             // all 16-byte loads of the span are issued before the first LDS write, so every lane
             // has its ~RS/4 requests in flight at once (the kernel is a pure HBM stream)
             const float4* src4 = reinterpret_cast<const float4*>(src);
-            constexpr int total4 = kShThreads * RS / 4;
-            constexpr int per = (total4 + kShThreads - 1) / kShThreads;
+            constexpr int total4 = kShThreadsFwd * RS / 4;
+            constexpr int per = (total4 + kShThreadsFwd - 1) / kShThreadsFwd;
             float4 v[per > 0 ? per : 1];
 #pragma unroll
             for (int u = 0; u < per; ++u) {
-                const int f4 = tid + u * kShThreads;
-                v[u] = f4 < total4 ? src4[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int f4 = tid + u * kShThreadsFwd;
+                v[u] = f4 < total4 ? load4_stream(src4 + f4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < per; ++u) {
-                const int f4 = tid + u * kShThreads;
+                const int f4 = tid + u * kShThreadsFwd;
                 if (f4 < total4) {
                     const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(kShThreads) void sh_colors_fwd_kernel(
             }
         } else {
             const int total = cnt * RS;
-            for (int f = tid; f < total; f += kShThreads) {
+            for (int f = tid; f < total; f += kShThreadsFwd) {
                 const int g = f / RS, j = f % RS;
                 lds[g * RSP + j] = src[(size_t)g * row + j];
             }
@@ -338,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
 }
 
 template <int DEG>
-__global__ __launch_bounds__(kShThreads) void sh_colors_bwd_kernel(
+__global__ __launch_bounds__(kShThreadsBwd) void sh_colors_bwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const unsigned char* __restrict__ mask, const float* __restrict__ v_colors,
     float* __restrict__ v_dc, float* __restrict__ v_rest) {
@@ -346,8 +375,8 @@ __global__ __launch_bounds__(kShThreads) void sh_colors_bwd_kernel(
     extern __shared__ __align__(16) float lds[];
     const int RS = 3 * (num_bases - 1);
     const int RSP = RS | 1;
-    const int g0 = blockIdx.x * kShThreads;
-    const int cnt = min(kShThreads, n - g0);
+    const int g0 = blockIdx.x * kShThreadsBwd;
+    const int cnt = min(kShThreadsBwd, n - g0);
     const int tid = threadIdx.x;
     if (tid < cnt) {
         const int i = g0 + tid;
@@ -371,7 +400,7 @@ __global__ __launch_bounds__(kShThreads) void sh_colors_bwd_kernel(
     const int total = cnt * RS;
     if ((total & 3) == 0 && (((size_t)g0 * RS) & 3) == 0) {
         float4* dst4 = reinterpret_cast<float4*>(dst);
-        for (int f4 = tid; f4 < total / 4; f4 += kShThreads) {
+        for (int f4 = tid; f4 < total / 4; f4 += kShThreadsBwd) {
             float e[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -381,31 +410,37 @@ __global__ __launch_bounds__(kShThreads) void sh_colors_bwd_kernel(
             store4(dst4 + f4, e[0], e[1], e[2], e[3]);
         }
     } else {
-        for (int f = tid; f < total; f += kShThreads) dst[f] = lds[(f / RS) * RSP + (f % RS)];
+        for (int f = tid; f < total; f += kShThreadsBwd) dst[f] = lds[(f / RS) * RSP + (f % RS)];
     }
 }
 
 // Measurement utility (bench.py): streaming read of n16 16-byte words with a
-// grid-stride loop, 4 independent loads in flight per lane; the per-lane sums are folded into
+// grid-stride loop, 8 independent loads in flight per lane; the per-lane sums are folded into
 // sink[] so that the loads cannot be elided.  Gives the achievable HBM read bandwidth of this GPU.
 __global__ __launch_bounds__(kThreads) void stream_read_kernel(const float4* __restrict__ src,
                                                                size_t n16, float* __restrict__ sink) {
+    constexpr int U = 8;       // 8 x 16 B in flight per lane: 6.3 TB/s on MI355X (4: 5.6, tools/micro/stream_bench.hip)
     const size_t stride = (size_t)gridDim.x * kThreads;
     size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-        b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
-        c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w;
-        d.x += v3.x; d.y += v3.y; d.z += v3.z; d.w += v3.w;
+    float4 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+        }
     }
     for (; i < n16; i += stride) {
         const float4 v0 = src[i];
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        acc[0].x += v0.x; acc[0].y += v0.y; acc[0].z += v0.z; acc[0].w += v0.w;
     }
-    const float t = (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) +
-                    (d.x + d.y + d.z + d.w);
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) t += (acc[u].x + acc[u].y) + (acc[u].z + acc[u].w);
     if (t == 123456.789f) sink[0] = t;          // practically never true: keeps the loads alive
 }
 
@@ -556,14 +591,14 @@ static int launch_colors_fwd(int32_t n, int32_t degrees_to_use, int32_t num_base
         return launch_status();
     }
     const int ka = (degrees_to_use + 1) * (degrees_to_use + 1);
-    const size_t lds = (size_t)kShThreads * ((3 * (ka - 1)) | 1) * sizeof(float);
-    const int grid_d = (n + kShThreads - 1) / kShThreads;
+    const size_t lds = (size_t)kShThreadsFwd * ((3 * (ka - 1)) | 1) * sizeof(float);
+    const int grid_d = (n + kShThreadsFwd - 1) / kShThreadsFwd;
 #define TS_SHC_FWD(D)                                                                             \
     do {                                                                                          \
         if (lds > 48 * 1024)                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_fwd_kernel<D>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid_d), dim3(kShThreads), lds, s, n,     \
+        hipLaunchKernelGGL(sh_colors_fwd_kernel<D>, dim3(grid_d), dim3(kShThreadsFwd), lds, s, n,  \
                            num_bases, means3d, origin, colors_dc, colors_rest, colors, clamp_mask, pk); \
     } while (0)
     switch (degrees_to_use) {
@@ -613,15 +648,15 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
     if (n == 0) return 0;
     if (!means3d || !origin || !v_colors || !v_colors_dc || (num_bases > 1 && !v_colors_rest))
         return TS_E_BADARG;
-    const int grid = (n + kShThreads - 1) / kShThreads;
-    const size_t lds = (size_t)kShThreads * ((3 * (num_bases - 1)) | 1) * sizeof(float);
+    const int grid = (n + kShThreadsBwd - 1) / kShThreadsBwd;
+    const size_t lds = (size_t)kShThreadsBwd * ((3 * (num_bases - 1)) | 1) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define TS_SHC_BWD(D)                                                                             \
     do {                                                                                          \
         if (lds > 48 * 1024)                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_bwd_kernel<D>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kShThreads), lds, s, n,       \
+        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kShThreadsBwd), lds, s, n,    \
                            num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,         \
                            v_colors_rest);                                                        \
     } while (0)

@@ -72,6 +72,10 @@ __device__ unsigned long long ts_stats[8];
 #define TS_STAT(i, v) ((void)0)
 #endif
 
+#ifndef TS_NT_ROWS
+#define TS_NT_ROWS 0                    // gradient rows written (raster_bwd) / read (reduce_partials) non-temporally
+#endif
+
 #ifndef TS_REDUCE_AHEAD
 #define TS_REDUCE_AHEAD 4                // rows of a Gaussian requested together by reduce_partials
 #endif
@@ -470,7 +474,7 @@ __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
 //   c0: value 2 * bit2 + bit3 | c1: value 4 + 2 * bit2 + bit3 | c2: value 8 + bit3
 // returns x with lane l holding the wave sum of value 4 * bit4 + 2 * bit2 + bit3 (l < 32) or 8 + bit3 (l >= 32).
 #ifndef TS_FLUSH_ASM
-#define TS_FLUSH_ASM 0
+#define TS_FLUSH_ASM 1
 #endif
 #define TS_DPP_ROR8 "row_ror:8 row_mask:0xf bank_mask:0xf"
 #define TS_DPP_ROR8_HI "row_ror:8 row_mask:0xf bank_mask:0xc"
@@ -560,8 +564,12 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
     }
     const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
     if (w >= 0) {
-        if (w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
-        else if (w == 10) row_flags[slot] = 1;                 // this row now holds data
+        if (w < 6 + CH) {
+            if (TS_NT_ROWS) __builtin_nontemporal_store(r, partials + slot * TS_PARTIAL_ROW_FLOATS + w);
+            else partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
+        } else if (w == 10) {
+            row_flags[slot] = 1;                               // this row now holds data
+        }
     }
 }
 

@@ -159,8 +159,14 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
                  const ts_camera* cam_host, int32_t* bin_ws, void* stream);
 
 /* Turns the counts into bases in place (exclusive scan down the chunk axis, then over tiles) and
- * writes tile_bins[t] = {start, end} (both 0 for an empty tile). */
-int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins, void* stream);
+ * writes tile_bins[t] = {start, end} (both 0 for an empty tile).
+ * Capacity guard (cum_tiles_hit non-NULL and capacity >= 0): a caller that sized bucket_ids / gaussian_ids_sorted /
+ * partials from an ESTIMATE instead of waiting for the count passes that size; if the frame's total
+ * cum_tiles_hit[n-1] exceeds it, every list is left empty and ts_bin_scatter returns without writing, so nothing
+ * is touched beyond the buffers - the caller reads the count later, sees the same excess and repeats the frame
+ * with exact sizes.  NULL / -1: no guard. */
+int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
+                    const int32_t* cum_tiles_hit, int64_t capacity, void* stream);
 
 /* Writes the id of every Gaussian into the bucket of each tile its rectangle covers (bucket_ids[I];
  * order inside a bucket is arbitrary until ts_sort_tiles).  scratch: NULL, or I more int32 (the
@@ -275,8 +281,10 @@ typedef struct ts_frame {
     uint8_t* sh_mask;
     int32_t *scan_ws, *bin_ws, *tile_bins;
     int32_t* total_host;                      /* pinned HOST int32 */
-    /* per-intersection buffers and the count they are sized by */
+    /* per-intersection buffers and the count they are sized by; capacity >= 0: the buffers were sized from an
+     * estimate before the count was known (ts_tile_offsets' guard), -1: from the count itself */
     int64_t num_intersects;
+    int64_t capacity;
     int32_t *bucket_ids, *gaussian_ids_sorted;
     /* image outputs */
     float *out_img, *final_Ts;

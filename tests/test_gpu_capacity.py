@@ -1,0 +1,52 @@
+"""Capacity-based allocation of the per-intersection buffers (frame.py: CAPACITY_ALLOC; ts_tile_offsets' guard).
+From the second frame of a shape on, the whole forward is enqueued against buffers sized by an ESTIMATE of the pair
+count before the count is read.  Checked: frames rendered against an estimate are bitwise the frames rendered after
+waiting for the count; an estimate that is too small (forced here) leaves nothing written beyond the buffers and the
+frame that comes back - re-enqueued with exact sizes - is again bitwise the same, gradients included."""
+import pytest
+import torch
+
+from tinysplat_amd import frame
+from tinysplat_amd.sharding import render_stripe
+from tinysplat_amd.synthetic import loss_weights, make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _run(model, cam, w, h, depth, w_rgb, w_d):
+    for p in model.parameters():
+        p.grad = None
+    out, _, xys = render_stripe(model, cam, (w, h), DEV, 0, 1, with_depth=depth)
+    loss = (out[:, :, :3] * w_rgb).sum() + ((out[:, :, 3] * w_d).sum() if depth else 0.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return out.detach().clone(), [p.grad.clone() for p in model.parameters()], xys.grad.clone()
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_estimated_sizes_change_nothing_and_a_small_estimate_is_survived(depth, monkeypatch):
+    n, sh, w, h = 60000, 2, 640, 360
+    model, cam = make_scene(n, sh, w, h, seed=11, scale_mult=2.0)
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    monkeypatch.setattr(frame, "CAPACITY_ALLOC", False)
+    ref = _run(model, cam, w, h, depth, w_rgb, w_d)                # waits for the count, exact sizes
+    monkeypatch.setattr(frame, "CAPACITY_ALLOC", True)
+    frame._capacity.clear()
+    first = _run(model, cam, w, h, depth, w_rgb, w_d)              # no estimate yet: exact sizes, estimate recorded
+    assert len(frame._capacity) == 1
+    key = next(iter(frame._capacity))
+    total = frame.last_binning[DEV.index].num_intersects
+    assert frame._capacity[key] >= total
+    second = _run(model, cam, w, h, depth, w_rgb, w_d)             # enqueued against the estimate
+    frame._capacity[key] = max(64, total // 3)                      # far too small: the device guard must trip
+    third = _run(model, cam, w, h, depth, w_rgb, w_d)
+    assert frame._capacity[key] >= total                            # and the estimate recovers
+    frame._capacity[key] = total                                    # exactly enough: no guard, no second pass
+    fourth = _run(model, cam, w, h, depth, w_rgb, w_d)
+    for got in (first, second, third, fourth):
+        assert torch.equal(got[0], ref[0])
+        for a, b in zip(got[1], ref[1]):
+            assert torch.equal(a, b)
+        assert torch.equal(got[2], ref[2])

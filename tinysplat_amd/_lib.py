@@ -47,7 +47,7 @@ class TsFrame(ctypes.Structure):
                     "xys", "depths", "conics", "colors", "splats",
                     "radii", "num_tiles_hit", "cum_tiles_hit", "sh_mask",
                     "scan_ws", "bin_ws", "tile_bins", "total_host")]
-                + [("num_intersects", c_int64)]
+                + [("num_intersects", c_int64), ("capacity", c_int64)]
                 + [(name, c_void_p) for name in (
                     "bucket_ids", "gaussian_ids_sorted", "out_img", "final_Ts", "final_index", "clamp_mask",
                     "v_out_img", "partials", "row_flags",
@@ -80,7 +80,7 @@ SIGNATURES = {
     "ts_scan_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P]),
     "ts_bin_ws_ints": (c_int64, [c_int32, c_int32]),
     "ts_bin_count": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P]),
-    "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P]),
+    "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P, c_int64, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),

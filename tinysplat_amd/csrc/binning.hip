@@ -360,14 +360,33 @@ __global__ __launch_bounds__(kColTiles * kScanGroups) void column_scan_kernel(in
 // single workgroup of 1024 threads, 8 tiles per lane and step (a 1080p frame's 8160 tiles in one step):
 // exclusive scan over tiles -> tile_bins; tile_total[t] becomes start[t]
 constexpr int kOffsetsThreads = 1024;
+// CAPACITY GUARD: when the caller sized the per-intersection buffers from an estimate (capacity >= 0) instead of
+// waiting for the count, a frame whose bounding-box total cum[n-1] exceeds it must not touch them: the guard word
+// (spare[-1]) is set, every list is left empty (tile_bins = 0, tile_start = 0), ts_bin_scatter returns at once, and
+// the compositing kernels find nothing to do; the host sees the same total when it reads the count and runs the
+// frame again with exact sizes.
 __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_tiles,
                                                                        int* __restrict__ tile_total,
                                                                        int* __restrict__ tile_bins,
-                                                                       int* __restrict__ spare) {
+                                                                       int* __restrict__ spare,
+                                                                       const int* __restrict__ total_ptr,
+                                                                       long long capacity) {
     constexpr int kPer = 8;
-    __shared__ int carry;
-    if (threadIdx.x == 0) { carry = 0; *spare = 0; }     // the workspace's last word: ts_sort_tiles' tile counter
+    __shared__ int carry, over;
+    if (threadIdx.x == 0) {
+        carry = 0;
+        *spare = 0;                                       // the workspace's last word: ts_sort_tiles' tile counter
+        over = (total_ptr && capacity >= 0 && ((long long)*total_ptr > capacity || *total_ptr < 0)) ? 1 : 0;
+        spare[-1] = over;
+    }
     __syncthreads();
+    if (over) {
+        for (int t = threadIdx.x; t <= num_tiles; t += kOffsetsThreads) {
+            tile_total[t] = 0;
+            if (t < num_tiles) reinterpret_cast<int2*>(tile_bins)[t] = make_int2(0, 0);
+        }
+        return;
+    }
     for (int base = 0; base < num_tiles; base += kOffsetsThreads * kPer) {
         const int t0 = base + threadIdx.x * kPer;
         int v[kPer], sum = 0;
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
     int num_tiles, int window, const int* __restrict__ bases, const int* __restrict__ tile_start,
     int* __restrict__ bucket_ids) {
     extern __shared__ int cursor[];
+    if (tile_start[num_tiles + 1] != 0) return;              // capacity guard (tile_offsets_kernel)
     const int t0 = blockIdx.y * window;
     const int tw = min(num_tiles - t0, window);
     const int* src = bases + (size_t)blockIdx.x * num_tiles + t0;
@@ -432,6 +452,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     const float4* __restrict__ splats, const ts_camera cam, int num_tiles, const int* __restrict__ bases,
     const int* __restrict__ tile_start, int* __restrict__ scratch) {
     extern __shared__ int cursor[];
+    if (tile_start[num_tiles + 1] != 0) return;              // capacity guard (tile_offsets_kernel)
     const int groups = (num_tiles + kCoarseTiles - 1) >> kCoarseShift;
     const int* src = bases + (size_t)blockIdx.x * num_tiles;
     for (int g = threadIdx.x; g < groups; g += kBinThreads) {
@@ -833,7 +854,7 @@ int ts_scan_tiles(int32_t n, const int32_t* num_tiles_hit, int32_t* cum_tiles_hi
 
 int64_t ts_bin_ws_ints(int32_t n, int32_t num_tiles) {
     if (num_tiles < 0) num_tiles = 0;
-    return (int64_t)(bin_num_chunks(n) + 1) * num_tiles + 2;     // counts | tile_start[T + 1] | the spare word
+    return (int64_t)(bin_num_chunks(n) + 1) * num_tiles + 3;     // counts | tile_start[T + 1] | guard | the spare word
 }
 
 
@@ -859,7 +880,7 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
 }
 
 int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
-                    void* stream) {
+                    const int32_t* cum_tiles_hit, int64_t capacity, void* stream) {
     if (n < 0 || num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
     if (!bin_ws || !tile_bins) return TS_E_BADARG;
@@ -870,7 +891,8 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
     hipLaunchKernelGGL(column_scan_kernel, dim3((num_tiles + kColTiles - 1) / kColTiles),
                        dim3(kColTiles * kScanGroups), 0, s, num_tiles, chunks, per_group, bin_ws, tile_total);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kOffsetsThreads), 0, s, num_tiles, tile_total,
-                       tile_bins, bin_ws + (ts_bin_ws_ints(n, num_tiles) - 1));
+                       tile_bins, bin_ws + (ts_bin_ws_ints(n, num_tiles) - 1),
+                       (cum_tiles_hit && n > 0) ? cum_tiles_hit + (n - 1) : nullptr, (long long)capacity);
     return launch_status();
 }
 

@@ -77,7 +77,7 @@ int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
                               &f->cam, f->channels == 4 ? f->depths : nullptr, f->splats, stream));
     const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
     TS_TRY(ts_bin_count(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, stream));
-    TS_TRY(ts_tile_offsets(f->n, num_tiles(f), f->bin_ws, f->tile_bins, stream));
+    TS_TRY(ts_tile_offsets(f->n, num_tiles(f), f->bin_ws, f->tile_bins, f->cum_tiles_hit, f->capacity, stream));
     return 0;
 }
 

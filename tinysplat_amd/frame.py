@@ -102,6 +102,18 @@ TWO_HOP_SCATTER = os.environ.get("TS_TWO_HOP_SCATTER", "1") != "0"
 
 DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
 
+# CAPACITY ALLOCATION: the per-intersection buffers (bucket_ids | gaussian_ids_sorted; partials in backward) are
+# sized by the bounding-box pair count I, which only the GPU knows (gsplat synchronises for it at the same place,
+# rasterize.py:44).  From the second frame of a (scene size, image, stripe) on, the buffers are sized by the
+# previous frame's count x 1.25 and the WHOLE forward is enqueued before the count is read: the GPU never waits for
+# the host to allocate, and the word has long arrived when the host looks at it.  A frame that needs more than the
+# estimate leaves every list empty on the device (ts_tile_offsets' guard) and is enqueued again with exact sizes.
+# Measured: config 2 (100 k Gaussians, host-bound) and the stripes of a sharded frame; config 3 is kernel-bound
+# either way.  TS_CAPACITY_ALLOC=0: always wait for the count first.
+CAPACITY_ALLOC = os.environ.get("TS_CAPACITY_ALLOC", "1") != "0"
+CAPACITY_GROWTH = 1.25
+_capacity = {}          # (device index, n, width, height, tile rows) -> estimate for the next frame
+
 # How the host waits for the intersection count (the one host read of a frame; the scan kernel stores it
 # into the pinned word itself, csrc/frame.hip).  "event": synchronise on an event recorded behind the scan;
 # "spin": a sentinel (-2^31) is stored in the word before the scan is issued and the host polls the word -
@@ -221,7 +233,29 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         _mark("fwd:allocated + struct")
         timed = kernel_timer.enabled
         spin = COUNT_WAIT == "spin" and n > 0
+        cap_key = (dev.index, n, w, h, cam.tile_row0, cam.tile_rows)
+        est = _capacity.get(cap_key) if (CAPACITY_ALLOC and n > 0) else None
+
+        def lists(size):
+            cap = (max(int(size), 1) + 63) & ~63
+            F.bucket_ids = torch.empty((2 * cap,), **i32)         # bucket_ids | gaussian_ids_sorted
+            fr.bucket_ids, fr.gaussian_ids_sorted = F.bucket_ids.data_ptr(), F.bucket_ids.data_ptr() + 4 * cap
+            return cap
+
+        def prepare():
+            if timed:
+                _steps_prepare(lib, fr, s)
+            else:
+                _lib.check(lib.ts_frame_fwd_prepare(ctypes.byref(fr), s), "ts_frame_fwd_prepare")
+
+        def composite():
+            if timed:
+                _steps_composite(lib, fr, s)
+            else:
+                _lib.check(lib.ts_frame_fwd_composite(ctypes.byref(fr), s), "ts_frame_fwd_composite")
+
         count_lock.acquire()
+        issued = consumed = False
         try:
             if spin:
                 word = ctypes.c_int32.from_address(host.data_ptr())
@@ -232,13 +266,20 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
                     host.copy_(F.cum[-1:], non_blocking=True)
             else:
                 _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
+            issued = n > 0
             _mark("fwd:call project")
             event.record(torch.cuda.current_stream(dev))
-            # the kernels that do not need the count run while it travels to the host
-            if timed:
-                _steps_prepare(lib, fr, s)
+            cap = None
+            if est is not None:
+                # everything is enqueued against buffers of the estimated size; the device refuses to use them
+                # if the frame turns out larger (ts_tile_offsets' guard)
+                cap = lists(est)
+                fr.capacity, fr.num_intersects = cap, cap
+                prepare()
+                composite()
             else:
-                _lib.check(lib.ts_frame_fwd_prepare(ctypes.byref(fr), s), "ts_frame_fwd_prepare")
+                fr.capacity = -1
+                prepare()                                # the kernels that do not need the count run while it travels
             _mark("fwd:call prepare")
             total = 0
             if n > 0:
@@ -253,7 +294,15 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
                 else:
                     event.synchronize()
                     total = int(host[0])
+            consumed = True
         finally:
+            if issued and not consumed:
+                # an exception between the scan and the read of its count: the scan may still be queued and would
+                # overwrite the word under the NEXT frame's sentinel - wait for it before the word changes hands
+                try:
+                    event.synchronize()
+                except Exception:
+                    pass
             count_lock.release()
         if total < 0:
             raise OverflowError("more than 2^31-1 tile intersections: num_tiles_hit overflows its "
@@ -261,15 +310,21 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         _mark("fwd:waited for count")
         F.total = total
         _pairs_per_tile[dev.index] = total / max(1, cam.tile_rows * cam.tile_bounds_x)
-        cap = (max(total, 1) + 63) & ~63
-        F.bucket_ids = torch.empty((2 * cap,), **i32)             # bucket_ids | gaussian_ids_sorted
-        F.ids = F.bucket_ids[cap:cap + total]
-        fr.num_intersects = total
-        fr.bucket_ids, fr.gaussian_ids_sorted = F.bucket_ids.data_ptr(), F.bucket_ids.data_ptr() + 4 * cap
-        if timed:
-            _steps_composite(lib, fr, s)
+        if n > 0 and CAPACITY_ALLOC:
+            if len(_capacity) > 64:
+                _capacity.clear()
+            _capacity[cap_key] = int(total * CAPACITY_GROWTH) + 4096
+        if cap is None or total > cap:
+            # first frame of this shape, or the estimate was too small (the device left every list empty)
+            redo = cap is not None
+            cap = lists(total)
+            fr.capacity, fr.num_intersects = -1, total
+            if redo:
+                prepare()
+            composite()
         else:
-            _lib.check(lib.ts_frame_fwd_composite(ctypes.byref(fr), s), "ts_frame_fwd_composite")
+            fr.num_intersects = total
+        F.ids = F.bucket_ids[cap:cap + total]
         _mark("fwd:call composite")
     finally:
         if cur != dev.index:
@@ -297,7 +352,7 @@ def _steps_prepare(lib, fr, s):
     tight = fr.splats if fr.flags & 1 else None
     _call("ts_bin_count", lib.ts_bin_count, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws, s)
     _call("ts_tile_offsets", lib.ts_tile_offsets, fr.n, int(lib.ts_num_tiles(ctypes.byref(fr.cam))), fr.bin_ws,
-          fr.tile_bins, s)
+          fr.tile_bins, fr.cum_tiles_hit, fr.capacity, s)
 
 
 def _steps_composite(lib, fr, s):

@@ -405,7 +405,7 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
         bin_ws = torch.empty((int(lib.ts_bin_ws_ints(n, num_tiles)),), **i32)
         tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
         _call("ts_bin_count", lib.ts_bin_count, n, _ptr(xys_c), _ptr(radii_c), None, cam, _ptr(bin_ws), s)
-        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, n, num_tiles, _ptr(bin_ws), _ptr(tile_bins), None, -1, s)
         total = pending.wait()                       # ... and is awaited behind the two launches above
         bucket_ids = torch.empty((max(total, 1),), **i32)
         ids = torch.empty((max(total, 1),), **i32)

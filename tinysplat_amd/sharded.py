@@ -266,6 +266,29 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     p = lambda t: None if t is None else t.data_ptr()
     host, event, lock = _frame._total_slot(dev)
     tight = p(S.splats) if _frame.TIGHT_BINNING else None
+    flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+    cap_key = (dev.index, "stripe", layout.world, w, h, cam.tile_row0, cam.tile_rows)
+    est = _frame._capacity.get(cap_key) if (_frame.CAPACITY_ALLOC and m > 0) else None
+
+    def lists(size):
+        cap = (max(int(size), 1) + 63) & ~63
+        S.bucket = torch.empty((2 * cap,), **i32)
+        return cap
+
+    def offsets(capacity):
+        _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, p(bin_ws), p(S.tile_bins),
+              p(S.cum) if capacity >= 0 else None, capacity, s)
+
+    def composite(cap):
+        if m > 0:
+            _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket),
+                  S.bucket.data_ptr() + 4 * cap if _frame.TWO_HOP_SCATTER else None, s)
+            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, p(S.tile_bins), p(S.depths), p(S.bucket),
+                  S.bucket.data_ptr() + 4 * cap, p(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
+        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, flags, cam, p(S.tile_bins), S.bucket.data_ptr() + 4 * cap,
+              p(S.splats), p(S.bg), p(out_img), p(S.final_Ts), p(S.final_index), p(S.clamp_mask), s)
+
+    cap = None
     with lock:
         if m > 0:
             _call("ts_import_records", lib.ts_import_records, m, p(records), cam, p(S.xys), p(S.depths), p(S.radii),
@@ -275,7 +298,12 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
             event.record(torch.cuda.current_stream(dev))
             _call("ts_import_pack", lib.ts_import_pack, m, p(records), p(S.cum), cam, p(S.splats), s)
         _call("ts_bin_count", lib.ts_bin_count, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), s)
-        _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, p(bin_ws), p(S.tile_bins), s)
+        if est is not None:          # sized by the previous frame's count: everything is enqueued before the read
+            cap = lists(est)
+            offsets(cap)
+            composite(cap)
+        else:
+            offsets(-1)
         total = 0
         if m > 0:
             event.synchronize()                          # the stripe's intersection count (sizes the lists)
@@ -284,17 +312,15 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
         raise OverflowError("more than 2^31-1 tile intersections in one stripe")
     S.total = total
     _frame._pairs_per_tile[dev.index] = total / max(1, cam.tile_rows * cam.tile_bounds_x)
-    cap = (max(total, 1) + 63) & ~63
-    S.bucket = torch.empty((2 * cap,), **i32)
+    if m > 0 and _frame.CAPACITY_ALLOC:
+        _frame._capacity[cap_key] = int(total * _frame.CAPACITY_GROWTH) + 4096
+    if cap is None or total > cap:
+        redo = cap is not None
+        cap = lists(total)
+        if redo:
+            offsets(-1)
+        composite(cap)
     S.ids = S.bucket[cap:cap + total]
-    if total > 0:
-        _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket),
-              S.bucket.data_ptr() + 4 * cap if _frame.TWO_HOP_SCATTER else None, s)
-        _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, p(S.tile_bins), p(S.depths), p(S.bucket),
-              S.bucket.data_ptr() + 4 * cap, p(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
-    flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)
-    _call("ts_raster_fwd", lib.ts_raster_fwd, ch, flags, cam, p(S.tile_bins), S.bucket.data_ptr() + 4 * cap,
-          p(S.splats), p(S.bg), p(out_img), p(S.final_Ts), p(S.final_index), p(S.clamp_mask), s)
     b = TileBinning()                        # scene statistics of the most recent frame (bench.py / tools)
     b.cam, b.n, b.num_tiles, b.num_intersects = cam, m, num_tiles, total
     b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = S.tile_bins[:num_tiles], S.ids, S.cum, S.nth

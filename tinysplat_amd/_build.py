@@ -73,7 +73,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
             _stamp_path(o).write_text(" ".join(cmd[1:]))
             relink = True
         objs.append(str(o))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lrocprofiler-sdk-roctx", "-o", str(LIB_PATH)]
     # the library records the flag sets of all its objects: a variant library is relinked by the
     # next default build even though it is newer than every source
     want = "\n".join(_stamp_path(Path(o)).read_text() for o in objs)

@@ -10,8 +10,16 @@
 // (the intersection count that sizes the per-intersection buffers) stays with the caller: it is
 // copied into pinned memory by ts_frame_fwd_project and awaited between _prepare and _composite.
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "../../include/tinysplat_hip.h"
+
+// roctx ranges around the five executor calls: `rocprofv3 --marker-trace --kernel-trace` shows which kernels a
+// call enqueued and the gaps between them (no cost without a tool attached)
+struct TsRange {
+    explicit TsRange(const char* name) { roctxRangePush(name); }
+    ~TsRange() { roctxRangePop(); }
+};
 
 #define TS_TRY(call)                 \
     do {                             \
@@ -49,6 +57,7 @@ extern "C" {
 int32_t ts_frame_struct_bytes(void) { return (int32_t)sizeof(ts_frame); }
 
 int ts_frame_fwd_project(const ts_frame* f, void* stream) {
+    TsRange range_("ts_frame_fwd_project");
     if (bad(f)) return TS_E_BADARG;
     // flags 3: log-scales and raw quaternions go in as they are (rasterize.py:72-73 folded into the kernel);
     // cov3d is not produced (the adapter discards it, rasterize.py:32)
@@ -67,6 +76,7 @@ int ts_frame_fwd_project(const ts_frame* f, void* stream) {
 }
 
 int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
+    TsRange range_("ts_frame_fwd_prepare");
     if (bad(f)) return TS_E_BADARG;
     // colour stage and record packing in one launch; channel 3 of an RGB + depth frame is the depth itself
     // (rasterize.py:48-50), taken from `depths`
@@ -82,6 +92,7 @@ int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
 }
 
 int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
+    TsRange range_("ts_frame_fwd_composite");
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
     if (f->num_intersects > 0) {
         const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
@@ -96,6 +107,7 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
 }
 
 int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
+    TsRange range_("ts_frame_bwd_composite");
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
     TS_TRY(ts_raster_bwd(f->channels, raster_flags(f) & ~TS_RASTER_CLAMP_RGB, f->num_intersects,
                          &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background, f->final_Ts,
@@ -109,6 +121,7 @@ int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
 }
 
 int ts_frame_bwd_params(const ts_frame* f, void* stream) {
+    TsRange range_("ts_frame_bwd_params");
     if (bad(f)) return TS_E_BADARG;
     TS_TRY(ts_sh_colors_bwd(f->n, f->sh_degree, f->num_bases, f->means, f->origin,
                             (f->flags & TS_FRAME_STRIPE) ? nullptr : f->sh_mask, f->v_colors,

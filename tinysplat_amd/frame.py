@@ -102,15 +102,17 @@ TWO_HOP_SCATTER = os.environ.get("TS_TWO_HOP_SCATTER", "1") != "0"
 
 DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
 
-# CAPACITY ALLOCATION: the per-intersection buffers (bucket_ids | gaussian_ids_sorted; partials in backward) are
-# sized by the bounding-box pair count I, which only the GPU knows (gsplat synchronises for it at the same place,
-# rasterize.py:44).  From the second frame of a (scene size, image, stripe) on, the buffers are sized by the
-# previous frame's count x 1.25 and the WHOLE forward is enqueued before the count is read: the GPU never waits for
-# the host to allocate, and the word has long arrived when the host looks at it.  A frame that needs more than the
-# estimate leaves every list empty on the device (ts_tile_offsets' guard) and is enqueued again with exact sizes.
-# Measured: config 2 (100 k Gaussians, host-bound) and the stripes of a sharded frame; config 3 is kernel-bound
-# either way.  TS_CAPACITY_ALLOC=0: always wait for the count first.
-CAPACITY_ALLOC = os.environ.get("TS_CAPACITY_ALLOC", "1") != "0"
+# CAPACITY ALLOCATION (option, off by default): the per-intersection buffers (bucket_ids | gaussian_ids_sorted;
+# partials in backward) are sized by the bounding-box pair count I, which only the GPU knows (gsplat synchronises
+# for it at the same place, rasterize.py:44).  With TS_CAPACITY_ALLOC=1, from the second frame of a (scene size,
+# image, stripe) on the buffers are sized by the previous frame's count x 1.25 and the WHOLE forward is enqueued
+# before the count is read; a frame that needs more than the estimate leaves every list empty on the device
+# (ts_tile_offsets' guard) and is enqueued again with exact sizes (tests/test_gpu_capacity.py).  Measured on
+# MI355X it does not pay: the count word is already there when the host has enqueued the three kernels that do not
+# need it, config 2 (100 k Gaussians) runs at its kernel time either way (0.305 ms/frame) and in two of three runs
+# the early enqueue was SLOWER (0.39 ms), config 3 1.204 vs 1.193 ms - so the default waits for the count, which
+# also keeps the buffers exact.  The guard is what a hipGraph capture of the forward frame would build on.
+CAPACITY_ALLOC = os.environ.get("TS_CAPACITY_ALLOC", "0") != "0"
 CAPACITY_GROWTH = 1.25
 _capacity = {}          # (device index, n, width, height, tile rows) -> estimate for the next frame
 
@@ -318,10 +320,12 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
             # first frame of this shape, or the estimate was too small (the device left every list empty)
             redo = cap is not None
             cap = lists(total)
+            _mark("fwd:lists allocated")
             fr.capacity, fr.num_intersects = -1, total
             if redo:
                 prepare()
             composite()
+            _mark("fwd:composite enqueued")
         else:
             fr.num_intersects = total
         F.ids = F.bucket_ids[cap:cap + total]

@@ -350,6 +350,23 @@ int ts_route_accumulate(int32_t n, int32_t channels, const float* xys, const int
                         const int32_t* route_ws, const float* grad_rows, float* v_xy, float* v_conic,
                         float* v_colors, float* v_depth, float* v_opacity, void* stream);
 
+/* Executor entries of the sharded frame (one native call per group of launches, as ts_frame_* above).  Two
+ * ts_frame describe a rank's frame: fo = its OWNED Gaussians with the full-frame camera, fs = the records its
+ * stripe imported (n = number of records, cam = the stripe).
+ *   ts_shard_owner_fwd          project_fwd, colors_pack_fwd, route_count            (fo)
+ *   ts_route_pack               once the caller knows the counts
+ *   ts_shard_stripe_fwd_import  import_records, scan_tiles (total -> fs->total_host), import_pack, bin_count,
+ *                               tile_offsets                                          (fs)
+ *   ts_frame_fwd_composite      bin_scatter, sort_tiles, raster_fwd                   (fs)
+ *   ts_shard_stripe_bwd         raster_bwd, reduce_partials_rows -> grad_rows[n, 12]  (fs)
+ *   ts_shard_owner_bwd          route_accumulate, sh_colors_bwd, project_bwd          (fo) */
+int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes_host, int32_t* route_ws, int32_t* counts,
+                       void* stream);
+int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream);
+int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream);
+int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* route_ws,
+                       const float* grad_rows, void* stream);
+
 /* ============ training-step ops around the path (scripts/train.py:58-63,97) ===== */
 
 /* Photometric loss of the training step and its gradient w.r.t. the rendered image:

@@ -112,6 +112,10 @@ SIGNATURES = {
     "ts_import_pack": (c_int32, [c_int32, _P, _P, _CAM, _P, _P]),
     "ts_reduce_partials_rows": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_route_accumulate": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _CAM, _STRIPES, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_shard_owner_fwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),
+    "ts_shard_stripe_fwd_import": (c_int32, [_FRAME, _P, _P]),
+    "ts_shard_stripe_bwd": (c_int32, [_FRAME, _P, _P]),
+    "ts_shard_owner_bwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),
     "ts_frame_struct_bytes": (c_int32, []),
     "ts_frame_fwd_project": (c_int32, [_FRAME, _P]),
     "ts_frame_fwd_prepare": (c_int32, [_FRAME, _P]),

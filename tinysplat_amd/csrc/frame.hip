@@ -130,4 +130,70 @@ int ts_frame_bwd_params(const ts_frame* f, void* stream) {
                           f->v_xy, f->v_depth, f->v_conic, nullptr, f->v_means, f->v_scales, f->v_quats, stream);
 }
 
+// ---- Gaussian-sharded frame (csrc/shard.hip, tinysplat_amd/sharded.py): the same executor idea -----------------
+// Two ts_frame describe a rank's frame: `fo` its OWNED Gaussians with the full-frame camera, `fs` the records its
+// stripe imported (n = records, cam = the stripe); the per-stage entries are called in the order sharded.py
+// documents.  ts_frame_fwd_composite(fs) is the stripe's scatter + sort + compositing, unchanged.
+
+int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes, int32_t* route_ws, int32_t* counts,
+                       void* stream) {
+    TsRange range_("ts_shard_owner_fwd");
+    if (bad(fo) || !stripes) return TS_E_BADARG;
+    TS_TRY(ts_project_fwd(fo->n, fo->means, fo->scales, fo->quats, fo->view34, fo->projview, &fo->cam, 3, fo->xys,
+                          fo->depths, fo->radii, fo->conics, fo->num_tiles_hit, nullptr, stream));
+    // colour stage + packed records of the owned Gaussians; the slot fields are rewritten by the importing rank,
+    // so any int array serves as cum_tiles_hit
+    TS_TRY(ts_colors_pack_fwd(fo->n, fo->sh_degree, fo->num_bases, fo->means, fo->origin, fo->colors_dc,
+                              fo->num_bases > 1 ? fo->colors_rest : nullptr, fo->sh_mask, nullptr, fo->channels,
+                              TS_RASTER_LOGIT_OPACITY, fo->xys, fo->radii, fo->conics, fo->opacities,
+                              fo->num_tiles_hit, &fo->cam, fo->channels == 4 ? fo->depths : nullptr, fo->splats,
+                              stream));
+    return ts_route_count(fo->n, fo->xys, fo->radii, &fo->cam, stripes, route_ws, counts, stream);
+}
+
+int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream) {
+    TsRange range_("ts_shard_stripe_fwd_import");
+    if (bad(fs)) return TS_E_BADARG;
+    if (fs->n > 0) {
+        TS_TRY(ts_import_records(fs->n, records, &fs->cam, fs->xys, fs->depths, fs->radii, fs->num_tiles_hit, stream));
+        int32_t* total_dev = fs->total_host ? mapped_pointer(fs->total_host) : nullptr;
+        TS_TRY(ts_scan_tiles(fs->n, fs->num_tiles_hit, fs->cum_tiles_hit, fs->scan_ws, total_dev, stream));
+        if (fs->total_host && !total_dev) {
+            const hipError_t e = hipMemcpyAsync(fs->total_host, fs->cum_tiles_hit + (fs->n - 1), sizeof(int32_t),
+                                                hipMemcpyDeviceToHost, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        TS_TRY(ts_import_pack(fs->n, records, fs->cum_tiles_hit, &fs->cam, fs->splats, stream));
+    }
+    const float* tight = (fs->flags & TS_FRAME_TIGHT) ? fs->splats : nullptr;
+    TS_TRY(ts_bin_count(fs->n, fs->xys, fs->radii, tight, &fs->cam, fs->bin_ws, stream));
+    return ts_tile_offsets(fs->n, num_tiles(fs), fs->bin_ws, fs->tile_bins, fs->cum_tiles_hit, fs->capacity, stream);
+}
+
+int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream) {
+    TsRange range_("ts_shard_stripe_bwd");
+    if (bad(fs) || fs->num_intersects < 0) return TS_E_BADARG;
+    TS_TRY(ts_raster_bwd(fs->channels, raster_flags(fs) & ~TS_RASTER_CLAMP_RGB, fs->num_intersects, &fs->cam,
+                         fs->tile_bins, fs->gaussian_ids_sorted, fs->splats, fs->background, fs->final_Ts,
+                         fs->final_index, fs->v_out_img, nullptr, fs->clamp_mask, fs->partials, fs->row_flags,
+                         stream));
+    return ts_reduce_partials_rows(fs->n, fs->channels, (fs->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0,
+                                   fs->num_tiles_hit, fs->cum_tiles_hit, fs->partials, fs->row_flags, fs->splats,
+                                   grad_rows, stream);
+}
+
+int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes, const int32_t* route_ws,
+                       const float* grad_rows, void* stream) {
+    TsRange range_("ts_shard_owner_bwd");
+    if (bad(fo) || !stripes) return TS_E_BADARG;
+    TS_TRY(ts_route_accumulate(fo->n, fo->channels, fo->xys, fo->radii, fo->splats, fo->sh_mask, &fo->cam, stripes,
+                               route_ws, grad_rows, fo->v_xy, fo->v_conic, fo->v_colors,
+                               fo->channels == 4 ? fo->v_depth : nullptr, fo->v_opacity, stream));
+    TS_TRY(ts_sh_colors_bwd(fo->n, fo->sh_degree, fo->num_bases, fo->means, fo->origin, nullptr, fo->v_colors,
+                            fo->v_colors_dc, fo->num_bases > 1 ? fo->v_colors_rest : nullptr, stream));
+    return ts_project_bwd(fo->n, fo->means, fo->scales, fo->quats, fo->view34, fo->projview, &fo->cam, 3, fo->radii,
+                          fo->v_xy, fo->channels == 4 ? fo->v_depth : nullptr, fo->v_conic, nullptr, fo->v_means,
+                          fo->v_scales, fo->v_quats, stream);
+}
+
 }  // extern "C"

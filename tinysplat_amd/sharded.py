@@ -39,8 +39,8 @@ from torch import Tensor
 
 from . import _lib
 from . import frame as _frame
-from ._lib import TsStripes
-from .ops import TileBinning, _call, _camera, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
+from ._lib import TsFrame, TsStripes
+from .ops import TileBinning, _call, _camera, kernel_timer, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
 from .rasterizer import camera_on_device
 from .sharding import stripe_rows
 from .synthetic import SplatModel
@@ -185,13 +185,28 @@ class ReplayExchange(Exchange):
 # the frame
 # --------------------------------------------------------------------------------------------------
 class _Owner:
-    __slots__ = ("n", "nb", "ch", "cam", "xys", "depths", "radii", "conics", "nth", "splats", "sh_mask",
-                 "route_ws", "send_counts", "recv_counts", "inputs")
+    __slots__ = ("n", "nb", "ch", "cam", "fr", "ws", "xys", "radii", "send_counts", "recv_counts", "inputs",
+                 "p_route_ws")
 
 
 class _Stripe:
-    __slots__ = ("m", "cam", "split", "mode", "xys", "depths", "radii", "nth", "cum", "splats", "tile_bins",
-                 "ids", "bucket", "total", "final_Ts", "final_index", "clamp_mask", "bg", "num_tiles")
+    __slots__ = ("m", "cam", "fr", "ws", "split", "mode", "bucket", "total", "num_tiles", "tile_bins", "nth", "cum",
+                 "bg", "records")
+
+
+def _carve(dev, sizes):
+    """ONE allocation for a list of byte sizes (256-byte aligned sections) -> (tensor, section pointers, offsets)."""
+    offs, off = [], 0
+    for sz in sizes:
+        offs.append(off)
+        off += (int(sz) + 255) & ~255
+    ws = torch.empty((max(off, 256),), dtype=torch.uint8, device=dev)
+    base = ws.data_ptr()
+    return ws, [base + o for o in offs], offs
+
+
+def _view(ws, off, dtype, count, shape):
+    return ws[off:off + count * dtype.itemsize].view(dtype).view(shape)
 
 
 def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, scales, quats, opacities,
@@ -204,29 +219,40 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
     O = _Owner()
     O.n, O.nb, O.ch = n, nb, ch
     O.cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0)
-    f32 = dict(dtype=torch.float32, device=dev)
-    i32 = dict(dtype=torch.int32, device=dev)
     m = max(n, 1)
-    O.xys, O.depths = torch.empty((m, 2), **f32)[:n], torch.empty((m,), **f32)[:n]
-    O.radii, O.nth = torch.empty((m,), **i32)[:n], torch.empty((m,), **i32)[:n]
-    O.conics = torch.empty((m, 3), **f32)[:n]
-    O.splats = torch.empty((m, 12), **f32)
-    O.sh_mask = torch.empty((m,), dtype=torch.uint8, device=dev) if keep else None
-    O.route_ws = torch.empty((int(lib.ts_route_ws_ints(n, layout.world)),), **i32)
-    counts = torch.empty((layout.world,), **i32)
-    p = lambda t: None if t is None else t.data_ptr()
-    _call("ts_project_fwd", lib.ts_project_fwd, n, p(means), p(scales), p(quats), p(view34), p(projview), O.cam, 3,
-          p(O.xys), p(O.depths), p(O.radii), p(O.conics), p(O.nth), None, s)
-    # colour stage + packed records of the owned Gaussians (slot fields are rewritten by the importing rank)
-    _call("ts_colors_pack_fwd", lib.ts_colors_pack_fwd, n, int(sh_degree), nb, p(means), p(origin), p(colors_dc),
-          p(colors_rest) if nb > 1 else None, p(O.sh_mask), None, ch, 1, p(O.xys), p(O.radii), p(O.conics),
-          p(opacities), p(O.nth), O.cam, p(O.depths) if ch == 4 else None, p(O.splats), s)
-    _call("ts_route_count", lib.ts_route_count, n, p(O.xys), p(O.radii), O.cam, layout.c_stripes, p(O.route_ws),
-          p(counts), s)
+    n_route = int(lib.ts_route_ws_ints(n, layout.world))
+    #   xys | depths | radii | conics | nth | splats | sh_mask | route_ws | counts
+    O.ws, ptr, offs = _carve(dev, [8 * m, 4 * m, 4 * m, 12 * m, 4 * m, 48 * m, m, 4 * n_route, 4 * layout.world])
+    O.xys = _view(O.ws, offs[0], torch.float32, 2 * n, (n, 2))
+    O.radii = _view(O.ws, offs[2], torch.int32, n, (n,))
+    counts = _view(O.ws, offs[8], torch.int32, layout.world, (layout.world,))
+    O.p_route_ws = ptr[7]
+    fr = TsFrame()
+    fr.n, fr.num_bases, fr.sh_degree, fr.channels, fr.flags = n, nb, int(sh_degree), ch, 0
+    fr.cam, fr.capacity = O.cam, -1
+    fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
+    fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
+    fr.view34, fr.projview, fr.origin = view34.data_ptr(), projview.data_ptr(), origin.data_ptr()
+    fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, fr.splats = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5]
+    fr.sh_mask = ptr[6] if keep else None
+    O.fr = fr
+    if kernel_timer.enabled:
+        _call("ts_project_fwd", lib.ts_project_fwd, n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview, O.cam, 3,
+              fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, None, s)
+        # colour stage + packed records of the owned Gaussians (slot fields are rewritten by the importing rank)
+        _call("ts_colors_pack_fwd", lib.ts_colors_pack_fwd, n, int(sh_degree), nb, fr.means, fr.origin, fr.colors_dc,
+              fr.colors_rest if nb > 1 else None, fr.sh_mask, None, ch, 1, fr.xys, fr.radii, fr.conics,
+              fr.opacities, fr.num_tiles_hit, O.cam, fr.depths if ch == 4 else None, fr.splats, s)
+        _call("ts_route_count", lib.ts_route_count, n, fr.xys, fr.radii, O.cam, layout.c_stripes, O.p_route_ws,
+              counts.data_ptr(), s)
+    else:
+        _lib.check(lib.ts_shard_owner_fwd(ctypes.byref(fr), layout.c_stripes, O.p_route_ws, counts.data_ptr(), s),
+                   "ts_shard_owner_fwd")
     O.send_counts, O.recv_counts = exchange.counts(counts)
-    send = torch.empty((max(sum(O.send_counts), 1), RECORD_FLOATS), **f32)[:sum(O.send_counts)]
-    _call("ts_route_pack", lib.ts_route_pack, n, layout.owned[0], p(O.xys), p(O.radii), p(O.depths), p(O.splats),
-          O.cam, layout.c_stripes, p(O.route_ws), p(send), s)
+    total = sum(O.send_counts)
+    send = torch.empty((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
+    _call("ts_route_pack", lib.ts_route_pack, n, layout.owned[0], fr.xys, fr.radii, fr.depths, fr.splats,
+          O.cam, layout.c_stripes, O.p_route_ws, send.data_ptr(), s)
     return O, send
 
 
@@ -234,7 +260,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     w, h = layout.dims
     S = _Stripe()
     m = records.shape[0]
-    S.m = m
+    S.m, S.records = m, records
     cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=layout.tile_rows)
     S.mode = _frame._list_mode(dev.index, cam.tile_rows * cam.tile_bounds_x)
     cam.wide_tiles = 1 if S.mode else 0
@@ -243,71 +269,93 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
     S.num_tiles = num_tiles
     rows = _stripe_rows(cam)
-    f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     mm = max(m, 1)
-    S.xys, S.depths = torch.empty((mm, 2), **f32), torch.empty((mm,), **f32)
-    S.radii, S.nth, S.cum = torch.empty((mm,), **i32), torch.empty((mm,), **i32), torch.empty((mm,), **i32)
-    S.splats = torch.empty((mm, 12), **f32)
-    scan_ws = torch.empty((int(lib.ts_scan_ws_ints(m)),), **i32)
-    bin_ws = torch.empty((int(lib.ts_bin_ws_ints(m, num_tiles)),), **i32)
-    S.tile_bins = torch.empty((max(num_tiles, 1), 2), **i32)
-    out_img = torch.empty((rows, w, ch), **f32)
-    if keep:
-        S.final_Ts = torch.empty((rows, w), **f32)
-        S.final_index = torch.empty((rows, w), **i32)
-        S.clamp_mask = torch.empty((rows, w), dtype=torch.uint8, device=dev)
-    else:
-        S.final_Ts = S.final_index = S.clamp_mask = None
+    px = rows * w
+    nscan, nbin = int(lib.ts_scan_ws_ints(m)), int(lib.ts_bin_ws_ints(m, num_tiles))
+    #   xys | depths | radii | nth | cum | splats | scan_ws | bin_ws | tile_bins | final_Ts | final_index | clamp_mask
+    S.ws, ptr, offs = _carve(dev, [8 * mm, 4 * mm, 4 * mm, 4 * mm, 4 * mm, 48 * mm, 4 * nscan, 4 * nbin,
+                                   8 * max(num_tiles, 1)] + ([4 * px, 4 * px, px] if keep else []))
+    S.nth = _view(S.ws, offs[3], torch.int32, m, (m,))
+    S.cum = _view(S.ws, offs[4], torch.int32, m, (m,))
+    S.tile_bins = _view(S.ws, offs[8], torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
+    out_img = torch.empty((rows, w, ch), dtype=torch.float32, device=dev)
     if ch == 4:            # channel 3 is composited over background[0], as the reference's depth pass (:86)
         S.bg = _f32c(torch.cat([background, background[:1]]))
     else:
         S.bg = _f32c(background)
-    p = lambda t: None if t is None else t.data_ptr()
     host, event, lock = _frame._total_slot(dev)
-    tight = p(S.splats) if _frame.TIGHT_BINNING else None
-    flags = 2 | (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+    fr = TsFrame()
+    fr.n, fr.num_bases, fr.sh_degree, fr.channels = m, 1, 0, ch
+    fr.flags = ((1 if _frame.TIGHT_BINNING else 0) | (2 if S.split else 0) | (8 if S.mode == 2 else 0)
+                | (0 if _frame.TWO_HOP_SCATTER else 32))
+    fr.cam, fr.capacity = cam, -1
+    fr.background = S.bg.data_ptr()
+    fr.xys, fr.depths, fr.radii, fr.num_tiles_hit, fr.cum_tiles_hit, fr.splats = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5]
+    fr.scan_ws, fr.bin_ws, fr.tile_bins = ptr[6], ptr[7], ptr[8]
+    fr.total_host = host.data_ptr()
+    fr.out_img = out_img.data_ptr()
+    if keep:
+        fr.final_Ts, fr.final_index, fr.clamp_mask = ptr[9], ptr[10], ptr[11]
+    S.fr = fr
+    timed = kernel_timer.enabled
+    tight = fr.splats if _frame.TIGHT_BINNING else None
     cap_key = (dev.index, "stripe", layout.world, w, h, cam.tile_row0, cam.tile_rows)
     est = _frame._capacity.get(cap_key) if (_frame.CAPACITY_ALLOC and m > 0) else None
 
     def lists(size):
         cap = (max(int(size), 1) + 63) & ~63
         S.bucket = torch.empty((2 * cap,), **i32)
+        fr.bucket_ids, fr.gaussian_ids_sorted = S.bucket.data_ptr(), S.bucket.data_ptr() + 4 * cap
         return cap
 
-    def offsets(capacity):
-        _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, p(bin_ws), p(S.tile_bins),
-              p(S.cum) if capacity >= 0 else None, capacity, s)
-
-    def composite(cap):
+    def stage_import():
+        if not timed:
+            _lib.check(lib.ts_shard_stripe_fwd_import(ctypes.byref(fr), records.data_ptr() if m > 0 else None, s),
+                       "ts_shard_stripe_fwd_import")
+            return
         if m > 0:
-            _call("ts_bin_scatter", lib.ts_bin_scatter, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), p(S.bucket),
-                  S.bucket.data_ptr() + 4 * cap if _frame.TWO_HOP_SCATTER else None, s)
-            _call("ts_sort_tiles", lib.ts_sort_tiles, num_tiles, p(S.tile_bins), p(S.depths), p(S.bucket),
-                  S.bucket.data_ptr() + 4 * cap, p(bin_ws), bin_ws.data_ptr() + 4 * (bin_ws.numel() - 1), s)
-        _call("ts_raster_fwd", lib.ts_raster_fwd, ch, flags, cam, p(S.tile_bins), S.bucket.data_ptr() + 4 * cap,
-              p(S.splats), p(S.bg), p(out_img), p(S.final_Ts), p(S.final_index), p(S.clamp_mask), s)
+            _call("ts_import_records", lib.ts_import_records, m, records.data_ptr(), cam, fr.xys, fr.depths, fr.radii,
+                  fr.num_tiles_hit, s)
+            _call("ts_scan_tiles", lib.ts_scan_tiles, m, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws, None, s)
+            host.copy_(S.cum[m - 1:m], non_blocking=True)
+            _call("ts_import_pack", lib.ts_import_pack, m, records.data_ptr(), fr.cum_tiles_hit, cam, fr.splats, s)
+        _call("ts_bin_count", lib.ts_bin_count, m, fr.xys, fr.radii, tight, cam, fr.bin_ws, s)
+        _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, fr.bin_ws, fr.tile_bins, fr.cum_tiles_hit,
+              fr.capacity, s)
+
+    def composite():
+        if timed:
+            _frame._steps_composite(lib, fr, s)
+        else:
+            _lib.check(lib.ts_frame_fwd_composite(ctypes.byref(fr), s), "ts_frame_fwd_composite")
 
     cap = None
+    spin = _frame.COUNT_WAIT == "spin" and m > 0 and not timed
     with lock:
-        if m > 0:
-            _call("ts_import_records", lib.ts_import_records, m, p(records), cam, p(S.xys), p(S.depths), p(S.radii),
-                  p(S.nth), s)
-            _call("ts_scan_tiles", lib.ts_scan_tiles, m, p(S.nth), p(S.cum), p(scan_ws), None, s)
-            host.copy_(S.cum[m - 1:m], non_blocking=True)
-            event.record(torch.cuda.current_stream(dev))
-            _call("ts_import_pack", lib.ts_import_pack, m, p(records), p(S.cum), cam, p(S.splats), s)
-        _call("ts_bin_count", lib.ts_bin_count, m, p(S.xys), p(S.radii), tight, cam, p(bin_ws), s)
+        if spin:
+            word = ctypes.c_int32.from_address(host.data_ptr())
+            word.value = -(1 << 31)
         if est is not None:          # sized by the previous frame's count: everything is enqueued before the read
             cap = lists(est)
-            offsets(cap)
-            composite(cap)
-        else:
-            offsets(-1)
+            fr.capacity, fr.num_intersects = cap, cap
+        stage_import()
+        event.record(torch.cuda.current_stream(dev))
+        if est is not None:
+            composite()
         total = 0
-        if m > 0:
-            event.synchronize()                          # the stripe's intersection count (sizes the lists)
-            total = int(host[0])
+        if m > 0:                                        # the stripe's intersection count (sizes the lists)
+            if spin:
+                k = 0
+                while word.value == -(1 << 31):
+                    k += 1
+                    if k > _frame._SPIN_LIMIT:
+                        event.synchronize()
+                        break
+                total = int(word.value)
+            else:
+                event.synchronize()
+                total = int(host[0])
     if total < 0:
         raise OverflowError("more than 2^31-1 tile intersections in one stripe")
     S.total = total
@@ -317,13 +365,16 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     if cap is None or total > cap:
         redo = cap is not None
         cap = lists(total)
+        fr.capacity, fr.num_intersects = -1, total
         if redo:
-            offsets(-1)
-        composite(cap)
-    S.ids = S.bucket[cap:cap + total]
+            stage_import()
+        composite()
+    else:
+        fr.num_intersects = total
     b = TileBinning()                        # scene statistics of the most recent frame (bench.py / tools)
     b.cam, b.n, b.num_tiles, b.num_intersects = cam, m, num_tiles, total
-    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = S.tile_bins[:num_tiles], S.ids, S.cum, S.nth
+    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = (S.tile_bins[:num_tiles],
+                                                                             S.bucket[cap:cap + total], S.cum, S.nth)
     _frame.last_binning[dev.index] = b
     return S, out_img
 
@@ -331,47 +382,55 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
 def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
     """Compositing backward of the stripe -> one gradient row per imported record [m, 12]."""
     f32 = dict(dtype=torch.float32, device=dev)
-    p = lambda t: None if t is None else t.data_ptr()
-    m = S.m
-    cap = S.bucket.numel() // 2
+    m, fr = S.m, S.fr
     rows_n = max(S.total, 1) * (4 if S.split else 1)
     partials = torch.empty((rows_n, 12), **f32)
     row_flags = torch.empty((rows_n,), dtype=torch.uint8, device=dev)
     grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
-    rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0)
-    _call("ts_raster_bwd", lib.ts_raster_bwd, ch, rflags, S.total, S.cam, p(S.tile_bins),
-          S.bucket.data_ptr() + 4 * cap, p(S.splats), p(S.bg), p(S.final_Ts), p(S.final_index), p(v_img),
-          None, p(S.clamp_mask), p(partials), p(row_flags), s)
-    _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, 4 if S.split else 0, p(S.nth),
-          p(S.cum), p(partials), p(row_flags), p(S.splats), p(grad_rows), s)
+    fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
+    if kernel_timer.enabled:
+        rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+        _call("ts_raster_bwd", lib.ts_raster_bwd, ch, rflags, S.total, S.cam, fr.tile_bins, fr.gaussian_ids_sorted,
+              fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None, fr.clamp_mask, fr.partials,
+              fr.row_flags, s)
+        _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, 4 if S.split else 0, fr.num_tiles_hit,
+              fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, grad_rows.data_ptr(), s)
+    else:
+        _lib.check(lib.ts_shard_stripe_bwd(ctypes.byref(fr), grad_rows.data_ptr(), s), "ts_shard_stripe_bwd")
+    S.records = None
     return grad_rows
 
 
 def _owner_backward(lib, s, dev, layout: ShardLayout, O: _Owner, back: Tensor, sh_degree: int, opacity_shape,
                     rest_shape):
     """Rows returned by the destinations -> gradients of the six OWNED parameter tensors and v_xy."""
-    means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin = O.inputs
     f32 = dict(dtype=torch.float32, device=dev)
-    p = lambda t: None if t is None else t.data_ptr()
-    n, ch = O.n, O.ch
+    n, ch, fr = O.n, O.ch, O.fr
     nn = max(n, 1)
     v_xy = torch.empty((nn, 2), **f32)[:n]
-    v_conic = torch.empty((nn, 3), **f32)[:n]
-    v_colors = torch.empty((nn, 3), **f32)[:n]
-    v_depth = torch.empty((nn,), **f32)[:n] if ch == 4 else None
     v_opac = torch.empty((nn,) + tuple(opacity_shape[1:]), **f32)[:n]
-    _call("ts_route_accumulate", lib.ts_route_accumulate, n, ch, p(O.xys), p(O.radii), p(O.splats),
-          p(O.sh_mask), O.cam, layout.c_stripes, p(O.route_ws), p(back), p(v_xy), p(v_conic), p(v_colors),
-          p(v_depth), p(v_opac), s)
     v_means = torch.empty((nn, 3), **f32)[:n]
     v_scales = torch.empty((nn, 3), **f32)[:n]
     v_quats = torch.empty((nn, 4), **f32)[:n]
     v_dc = torch.empty((nn, 3), **f32)[:n]
     v_rest = torch.empty((nn,) + tuple(rest_shape[1:]), **f32)[:n]
-    _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, n, sh_degree, O.nb, p(means), p(origin), None,
-          p(v_colors), p(v_dc), p(v_rest) if O.nb > 1 else None, s)
-    _call("ts_project_bwd", lib.ts_project_bwd, n, p(means), p(scales), p(quats), p(view34), p(projview),
-          O.cam, 3, p(O.radii), p(v_xy), p(v_depth), p(v_conic), None, p(v_means), p(v_scales), p(v_quats), s)
+    tmp = torch.empty((nn * 7,), **f32)                      # v_conic | v_colors | v_depth
+    fr.v_xy, fr.v_opacity = v_xy.data_ptr(), v_opac.data_ptr()
+    fr.v_conic, fr.v_colors, fr.v_depth = tmp.data_ptr(), tmp.data_ptr() + 12 * nn, tmp.data_ptr() + 24 * nn
+    fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
+    fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
+    if kernel_timer.enabled:
+        _call("ts_route_accumulate", lib.ts_route_accumulate, n, ch, fr.xys, fr.radii, fr.splats, fr.sh_mask, O.cam,
+              layout.c_stripes, O.p_route_ws, back.data_ptr(), fr.v_xy, fr.v_conic, fr.v_colors,
+              fr.v_depth if ch == 4 else None, fr.v_opacity, s)
+        _call("ts_sh_colors_bwd", lib.ts_sh_colors_bwd, n, sh_degree, O.nb, fr.means, fr.origin, None, fr.v_colors,
+              fr.v_colors_dc, fr.v_colors_rest if O.nb > 1 else None, s)
+        _call("ts_project_bwd", lib.ts_project_bwd, n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview, O.cam, 3,
+              fr.radii, fr.v_xy, fr.v_depth if ch == 4 else None, fr.v_conic, None, fr.v_means, fr.v_scales,
+              fr.v_quats, s)
+    else:
+        _lib.check(lib.ts_shard_owner_bwd(ctypes.byref(fr), layout.c_stripes, O.p_route_ws, back.data_ptr(), s),
+                   "ts_shard_owner_bwd")
     return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest), v_xy
 
 

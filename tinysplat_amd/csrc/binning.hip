@@ -443,7 +443,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
 //           entries for it form one run of ~64 words;
 //   fine    one workgroup per group streams its region and places the ids in the tiles' buckets with LDS
 //           cursors: all of a bucket's lines are written by one workgroup, merge in one L2 and leave as full lines.
-constexpr int kCoarseShift = 5;
+#ifndef TS_COARSE_SHIFT
+#define TS_COARSE_SHIFT 5
+#endif
+constexpr int kCoarseShift = TS_COARSE_SHIFT;
 constexpr int kCoarseTiles = 1 << kCoarseShift;
 constexpr int kCoarseIdBits = 32 - kCoarseShift;            // ids below 2^27
 

@@ -519,6 +519,25 @@ def main():
 
     if rank == 0:
         _log(f"scene ready (N={n}, {w}x{h}); warm-up")
+    if gshard is not None and world > 1:
+        # the sharded exchange (all_to_all with split sizes) has only ever run over gloo on 1-GPU boxes: should the
+        # first frame fail on this node's RCCL, every rank falls back to the replicated-parameter mode together
+        ok = 1
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:                            # noqa: BLE001
+            ok = 0
+            _log(f"rank {rank}: Gaussian-sharded frame failed ({type(e).__name__}: {e}); falling back")
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            gshard = None
+            args.shard_mode = "replicated"
+            model, cam = make_scene(n, sh, w, h, seed=0, scale_mult=args.scale_mult)
+            model = model.to(dev)
+            model.requires_grad_(True)
+            model_params = model.parameters()
     for _ in range(args.warmup):
         step()
     barrier()

@@ -12,8 +12,40 @@ echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail 
 echo "== profile round"; timeout 1500 bash tools/profile_round.sh $TAG 2>&1 | tail -1 | cut -c1-300
 echo "== pmc raster"; timeout 600 bash tools/pmc_raster.sh $OUT/${TAG}_pmc_raster.txt > /dev/null 2>&1; cat $OUT/${TAG}_pmc_raster.txt | cut -c1-250
 echo "== other configurations"
-for a in "--config 2" "--config 5 --steps 20 --warmup 5" "--config 5 --steps 20 --warmup 5 --spatial-sort" "--spatial-sort" "--depth" "--forward-only" "--train-step" "--emulate-ranks 2 --emulate-rank 1" "--emulate-ranks 4 --emulate-rank 2" "--emulate-ranks 8 --emulate-rank 4" "--emulate-ranks 8 --emulate-rank 4 --force-dist"; do
+for a in "--config 2" "--config 5 --steps 20 --warmup 5" "--config 5 --steps 20 --warmup 5 --spatial-sort" "--spatial-sort" "--depth" "--forward-only" "--train-step" \
+         "--emulate-ranks 2 --emulate-rank 1" "--emulate-ranks 4 --emulate-rank 2" "--emulate-ranks 8 --emulate-rank 4" "--emulate-ranks 8 --emulate-rank 0" \
+         "--emulate-ranks 2 --emulate-rank 1 --shard-mode replicated" "--emulate-ranks 4 --emulate-rank 2 --shard-mode replicated" "--emulate-ranks 8 --emulate-rank 4 --shard-mode replicated" \
+         "--emulate-ranks 8 --emulate-rank 4 --shard-mode replicated --force-dist" \
+         "--config 5 --steps 20 --warmup 5 --emulate-ranks 8 --emulate-rank 4" "--config 5 --steps 20 --warmup 5 --emulate-ranks 8 --emulate-rank 4 --shard-mode replicated"; do
   timeout 300 python bench.py $a --no-cpu-baseline --no-pmc 2>/dev/null | tee "$OUT/bench_$(echo $a | tr -d ' -').json" | python tools/print_bench.py | head -1 | cut -c1-230
 done
 echo "== bench --gpus 2 (both ranks on this GPU, gloo: functional)"; timeout 300 python bench.py --gpus 2 --single-device --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | cut -c1-300
+echo "== marker + kernel trace of three frames (roctx ranges of the executor calls)"
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/mk && timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d /tmp/mk -o mk -- python $OLDPWD/bench.py --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-bandwidth --no-rgbd-figure > /dev/null 2>&1; \
+  for f in $(find /tmp/mk -name "*marker*stats*.csv" -o -name "*marker_api_stats.csv" | head -2); do cp $f $OUT/${TAG}_marker_stats.csv; done; \
+  python - $OUT/${TAG}_timeline.txt <<'PY'
+import csv, glob, sys
+out = open(sys.argv[1], "w")
+kt = glob.glob("/tmp/mk/**/*kernel_trace.csv", recursive=True)
+mt = glob.glob("/tmp/mk/**/*marker_api_trace.csv", recursive=True)
+if kt:
+    rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
+    # the last frame: kernels after the last project_fwd_kernel
+    idx = [i for i, r in enumerate(rows) if "project_fwd_kernel" in r["Kernel_Name"]]
+    if idx:
+        rows = rows[idx[-1]:]
+        t0 = int(rows[0]["Start_Timestamp"]); prev_end = t0
+        out.write("kernel | start us | duration us | gap before us\n")
+        for r in rows:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            out.write(f"{r['Kernel_Name'][:70]} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {(s - prev_end) / 1e3:.1f}\n")
+            prev_end = e
+if mt:
+    out.write("\nroctx ranges (host side) of the trace:\n")
+    for r in list(csv.DictReader(open(mt[0])))[-12:]:
+        out.write(" | ".join(f"{k}={v}" for k, v in r.items() if k in ("Function", "Start_Timestamp", "End_Timestamp")) + "\n")
+out.close()
+print(open(sys.argv[1]).read()[:3000])
+PY
+)
 echo "== host time"; python tools/host_time.py 100000 2>&1 | grep "host enqueue"; python tools/host_time.py 1000000 2>&1 | grep "host enqueue"

@@ -251,9 +251,10 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
  * entries enqueue the same kernels, in the same order, as the per-stage entries above - nothing else -
  * from native code: one ts_frame describes a frame (all buffers caller-allocated; device pointers
  * unless noted), and a frame costs five calls instead of thirty:
- *   ts_frame_fwd_project    project_fwd, scan_tiles, then an async copy of the intersection count
- *                           cum_tiles_hit[n-1] into total_host (pinned host memory) - the caller
- *                           records an event behind this call and waits for it only before step 3
+ *   ts_frame_fwd_project    project_fwd, scan_tiles; the scan stores the intersection count cum_tiles_hit[n-1]
+ *                           into total_host (mapped pinned host memory; a 4-byte copy is queued instead when the
+ *                           word is not device-visible) - the caller polls the word, or waits for an event it
+ *                           records behind this call, only before step 3
  *   ts_frame_fwd_prepare    colors_pack_fwd (= sh_colors_fwd + pack_splats), bin_count, tile_offsets   (do not need the count)
  *   ts_frame_fwd_composite  bin_scatter, sort_tiles, raster_fwd   (needs bucket_ids / gaussian_ids_sorted
  *                           sized by the count; num_intersects must be set)

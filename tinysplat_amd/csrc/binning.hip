@@ -449,6 +449,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
 constexpr int kCoarseShift = TS_COARSE_SHIFT;
 constexpr int kCoarseTiles = 1 << kCoarseShift;
 constexpr int kCoarseIdBits = 32 - kCoarseShift;            // ids below 2^27
+#ifndef TS_TWO_HOP_FROM
+#define TS_TWO_HOP_FROM (1 << 18)
+#endif
+constexpr int kTwoHopFrom = TS_TWO_HOP_FROM;
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
@@ -910,7 +914,10 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
     const int chunks = bin_num_chunks(n);
     const int chunk = (n + chunks - 1) / chunks;
     const int* tile_start = bin_ws + (size_t)chunks * nt;
-    if (scratch && n < (1 << kCoarseIdBits)) {          // two coalesced hops (see bin_scatter_coarse_kernel)
+    // two coalesced hops (see bin_scatter_coarse_kernel) where the write amplification of the direct scatter is what
+    // binds; a small launch (a 100 k scene, the ~125 k records of one rank of a sharded frame) is latency-bound and
+    // the second launch costs more than it saves (34 vs 12 us on a 1/8 stripe of config 3)
+    if (scratch && n >= kTwoHopFrom && n < (1 << kCoarseIdBits)) {
         const int groups = (nt + kCoarseTiles - 1) >> kCoarseShift;
         hipLaunchKernelGGL(bin_scatter_coarse_kernel, dim3(chunks), dim3(kBinThreads), (size_t)groups * sizeof(int),
                            (hipStream_t)stream, n, chunk, xys, radii, reinterpret_cast<const float4*>(splats), *cam,

@@ -7,8 +7,9 @@
 // ctypes.  What it buys is host time: a frame is ~30 kernel launches, and issuing them from Python
 // costs ~0.45 ms per frame - more than the GPU needs for a 100 k-Gaussian scene or for one tile
 // stripe of a multi-GPU frame.  From here a launch costs ~2 us.  The one host round trip of the path
-// (the intersection count that sizes the per-intersection buffers) stays with the caller: it is
-// copied into pinned memory by ts_frame_fwd_project and awaited between _prepare and _composite.
+// (the intersection count that sizes the per-intersection buffers) stays with the caller: the scan kernel
+// stores it into the caller's mapped pinned word (ts_frame_fwd_project), where the caller polls it between
+// _prepare and _composite.
 #include <hip/hip_runtime.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
 
@@ -32,17 +33,22 @@ inline bool bad(const ts_frame* f) {
     return !f || f->n < 0 || (f->channels != 3 && f->channels != 4) || f->num_bases < 1;
 }
 inline int num_tiles(const ts_frame* f) { return ts_num_tiles(&f->cam); }
-// device address of a pinned host word, or null (the last answer is kept: a host uses one word per device)
+// device address of a pinned host word, or null.  The last SUCCESSFUL answer is kept per (device, host address):
+// a host thread uses one word per device; a failed lookup is not remembered.
 inline int32_t* mapped_pointer(int32_t* host) {
     static thread_local int32_t* last_host = nullptr;
     static thread_local int32_t* last_dev = nullptr;
-    if (host == last_host) return last_dev;
+    static thread_local int last_device = -1;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (host == last_host && device == last_device) return last_dev;
     void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || !dev) {
         (void)hipGetLastError();
-        dev = nullptr;
+        return nullptr;
     }
     last_host = host;
+    last_device = device;
     last_dev = static_cast<int32_t*>(dev);
     return last_dev;
 }

@@ -190,12 +190,13 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         i32 = dict(dtype=torch.int32, device=dev)
         # ONE allocation for every fixed-size intermediate (a torch.empty costs ~3 us of host time, and a
         # frame used to make a dozen); 256-byte aligned sections:
-        #   splats[12n] f32 | xys[2n] | conics[3n] | colors[3n] | depths[n] | radii[n] i32 | nth[n] | cum[n] |
+        #   splats[12n] f32 | xys[2n] | conics[3n] | (unused) | depths[n] | radii[n] i32 | nth[n] | cum[n] |
         #   scan_ws | bin_ws | tile_bins[2T] | sh_mask[n] u8 | final_Ts[P] f32 | final_index[P] i32 | clamp_mask[P] u8
         nscan = int(lib.ts_scan_ws_ints(n))
         nbin = int(lib.ts_bin_ws_ints(n, num_tiles))
         px = rows * w
-        sizes = [48 * m, 8 * m, 12 * m, 12 * m, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
+        # (the colour stage keeps the colours in registers - ts_colors_pack_fwd - so no colors[n,3] section exists)
+        sizes = [48 * m, 8 * m, 12 * m, 0, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
                  8 * max(num_tiles, 1)] + ([m, 4 * px, 4 * px, px] if keep else [])
         offs, off = [], 0
         for sz in sizes:
@@ -224,7 +225,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
         fr.view34, fr.projview, fr.origin, fr.background = view34.data_ptr(), projview.data_ptr(), origin.data_ptr(), bg.data_ptr()
-        fr.splats, fr.xys, fr.conics, fr.colors, fr.depths = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4]
+        fr.splats, fr.xys, fr.conics, fr.depths = ptr[0], ptr[1], ptr[2], ptr[4]
         fr.radii, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws = ptr[5], ptr[6], ptr[7], ptr[8]
         fr.bin_ws, fr.tile_bins = ptr[9], ptr[10]
         fr.total_host = host.data_ptr()

@@ -167,11 +167,19 @@ class SplatModel:
         neighbours in memory those accesses hit few tiles / few cache lines per chunk.  A trained model
         is loaded once and densification rebuilds every row anyway (densify.py), so the order is free
         to choose; the reference leaves it to chance (model_gaussian.py:179-195 appends clones at the end).
+
+        Only for a model that no optimiser or densifier holds state for yet (a freshly generated or loaded
+        scene): per-row state kept elsewhere - Adam moments, the gradient accumulator - is NOT permuted here;
+        once training has started use ``Densifier.reorder(optimizer)``, which permutes all of it together.
+        The six tensors are REBOUND to new tensors (not swapped through ``.data``), so identity / version keyed
+        caches cannot mistake the reordered model for the old one; ``requires_grad`` is carried over.
         """
         perm = morton_order(self.means)
         for name in ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities"):
             t = getattr(self, name)
-            t.data = t.data.index_select(0, perm)
+            if t.grad is not None:
+                raise RuntimeError("spatial_sort_ on a model that is being trained: use Densifier.reorder(optimizer)")
+            setattr(self, name, t.detach().index_select(0, perm).requires_grad_(t.requires_grad))
         return perm
 
 

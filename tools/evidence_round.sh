@@ -30,10 +30,11 @@ kt = glob.glob("/tmp/mk/**/*kernel_trace.csv", recursive=True)
 mt = glob.glob("/tmp/mk/**/*marker_api_trace.csv", recursive=True)
 if kt:
     rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
-    # the last frame: kernels after the last project_fwd_kernel
+    # the last frame of the TIMED loop (native executor): the frame after it is bench.py's per-entry timing frame,
+    # whose launches are issued one by one from Python between event records
     idx = [i for i, r in enumerate(rows) if "project_fwd_kernel" in r["Kernel_Name"]]
-    if idx:
-        rows = rows[idx[-1]:]
+    if len(idx) >= 2:
+        rows = rows[idx[-2]:idx[-1]]
         t0 = int(rows[0]["Start_Timestamp"]); prev_end = t0
         out.write("kernel | start us | duration us | gap before us\n")
         for r in rows:

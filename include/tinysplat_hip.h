@@ -215,6 +215,11 @@ int ts_pack_splats(int32_t n, int32_t channels, int32_t flags, const float* xys,
 #define TS_RASTER_SPLIT_BLOCKS 4
 /* with ts_camera.wide_tiles: keep one wave per 16x16 tile; each walks the list of the wide tile it lies in */
 #define TS_RASTER_NARROW_WAVES 8
+/* ts_raster_bwd / ts_reduce_partials(_rows): ROW-FLAG GENERATION.  Without it (g = 0) ts_raster_bwd zeroes
+ * row_flags and marks the rows it writes with 1.  A caller that keeps ONE row_flags array alive across passes
+ * (all zero at first) can pass a fresh g in 1..255 to both entries of a pass instead: rows are marked with g, only
+ * rows marked g count, and nothing is zeroed (the caller zeroes the array itself before reusing a value). */
+#define TS_RASTER_FLAG_GEN(g) (((g) & 0xff) << 8)
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
@@ -271,7 +276,8 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
                                           stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */
 typedef struct ts_frame {
-    int32_t n, num_bases, sh_degree, channels, flags, reserved;
+    int32_t n, num_bases, sh_degree, channels, flags;
+    int32_t flag_gen;                         /* row-flag generation of the backward pass (0: zero row_flags) */
     ts_camera cam;
     /* parameters and camera (rasterize.py:64-86): log-scales, raw quaternions, opacity logits */
     const float *means, *scales, *quats, *opacities, *colors_dc, *colors_rest;

@@ -40,7 +40,7 @@ class TsFrame(ctypes.Structure):
     """struct ts_frame of include/tinysplat_hip.h: one frame of the adapter recipe for the native
     executor (ts_frame_*).  Pointers travel as integer addresses; unset ones stay NULL."""
     _fields_ = ([("n", c_int32), ("num_bases", c_int32), ("sh_degree", c_int32), ("channels", c_int32),
-                 ("flags", c_int32), ("reserved", c_int32), ("cam", TsCamera)]
+                 ("flags", c_int32), ("flag_gen", c_int32), ("cam", TsCamera)]
                 + [(name, c_void_p) for name in (
                     "means", "scales", "quats", "opacities", "colors_dc", "colors_rest",
                     "view34", "projview", "origin", "background",

@@ -115,12 +115,14 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
 int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
     TsRange range_("ts_frame_bwd_composite");
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
-    TS_TRY(ts_raster_bwd(f->channels, raster_flags(f) & ~TS_RASTER_CLAMP_RGB, f->num_intersects,
-                         &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background, f->final_Ts,
-                         f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags, stream));
+    TS_TRY(ts_raster_bwd(f->channels, (raster_flags(f) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(f->flag_gen),
+                         f->num_intersects, &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background,
+                         f->final_Ts, f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags,
+                         stream));
     const bool stripe = (f->flags & TS_FRAME_STRIPE) != 0;
     return ts_reduce_partials(f->n, f->channels,
-                              TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0),
+                              TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
+                                  TS_RASTER_FLAG_GEN(f->flag_gen),
                               f->num_tiles_hit, f->cum_tiles_hit, f->partials, f->row_flags, f->splats, f->v_xy,
                               f->v_conic, f->v_colors, f->v_opacity, f->channels == 4 ? f->v_depth : nullptr,
                               stripe ? f->sh_mask : nullptr, stream);
@@ -179,11 +181,13 @@ int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* s
 int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream) {
     TsRange range_("ts_shard_stripe_bwd");
     if (bad(fs) || fs->num_intersects < 0) return TS_E_BADARG;
-    TS_TRY(ts_raster_bwd(fs->channels, raster_flags(fs) & ~TS_RASTER_CLAMP_RGB, fs->num_intersects, &fs->cam,
-                         fs->tile_bins, fs->gaussian_ids_sorted, fs->splats, fs->background, fs->final_Ts,
-                         fs->final_index, fs->v_out_img, nullptr, fs->clamp_mask, fs->partials, fs->row_flags,
-                         stream));
-    return ts_reduce_partials_rows(fs->n, fs->channels, (fs->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0,
+    TS_TRY(ts_raster_bwd(fs->channels, (raster_flags(fs) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(fs->flag_gen),
+                         fs->num_intersects, &fs->cam, fs->tile_bins, fs->gaussian_ids_sorted, fs->splats,
+                         fs->background, fs->final_Ts, fs->final_index, fs->v_out_img, nullptr, fs->clamp_mask,
+                         fs->partials, fs->row_flags, stream));
+    return ts_reduce_partials_rows(fs->n, fs->channels,
+                                   ((fs->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
+                                       TS_RASTER_FLAG_GEN(fs->flag_gen),
                                    fs->num_tiles_hit, fs->cum_tiles_hit, fs->partials, fs->row_flags, fs->splats,
                                    grad_rows, stream);
 }

@@ -543,6 +543,8 @@ template <int CH>
 __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
                                           unsigned char* __restrict__ row_flags, int lane) {
+    // num_isects carries the row-flag value in its top byte (see ts_raster_bwd: TS_RASTER_FLAG_GEN)
+    const unsigned char flag_val = (unsigned char)((unsigned long long)num_isects >> 56);
     float r;
     if (TS_ABLATE == 4) {               // timing experiment: no cross-lane reduction
         r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + v[8];
@@ -559,7 +561,7 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         const int w = (lane & 32) ? 8 + b3 : 4 * b4 + 2 * b2 + b3;
         const bool writer = (lane & 3) == 0 && ((lane & 32) == 0 || (lane & 0x14) == 0);
         if (writer && w < 6 + CH) partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
-        if (lane == 1) row_flags[slot] = 1;                    // this row now holds data
+        if (lane == 1) row_flags[slot] = flag_val;             // this row now holds data
         return;
     }
     const int w = lane - 48;                                   // row 3: lane 48+w holds value w, w < 10
@@ -568,7 +570,7 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
             if (TS_NT_ROWS) __builtin_nontemporal_store(r, partials + slot * TS_PARTIAL_ROW_FLOATS + w);
             else partials[slot * TS_PARTIAL_ROW_FLOATS + w] = r;
         } else if (w == 10) {
-            row_flags[slot] = 1;                               // this row now holds data
+            row_flags[slot] = flag_val;                        // this row now holds data
         }
     }
 }
@@ -820,11 +822,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     if (i >= n) return;
     const int cnt = num_tiles_hit[i];
     const long long end = cum_tiles_hit[i];
+    // a row holds data of THIS pass iff its flag equals the pass's value (legacy value 1 on a zeroed array, or
+    // the caller's generation on a persistent one: TS_RASTER_FLAG_GEN)
+    const unsigned int gen = ((unsigned int)flags >> 8) & 0xffu ? ((unsigned int)flags >> 8) & 0xffu : 1u;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
         const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
         for (long long s = end - cnt; s < end; ++s) {
-            const unsigned int f = flags4[s];
+            const unsigned int fw = flags4[s];
+            unsigned int f = 0u;                      // byte k set: row k of the slot was written in this pass
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f |= (((fw >> (8 * k)) & 0xffu) == gen) ? (0xffu << (8 * k)) : 0u;
             if (f == 0u) continue;
             float4 p0[4], p1[4], p2[4];            // the slot's flagged rows requested together, added in order
 #pragma unroll
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             bool f[kAhead];
             float4 p0[kAhead], p1[kAhead], p2[kAhead];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) f[u] = (s0 + u < end) && row_flags[s0 + u] != 0;   // 0: never written (stale)
+            for (int u = 0; u < kAhead; ++u) f[u] = (s0 + u < end) && row_flags[s0 + u] == gen;   // else: not written in this pass (stale)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 if (f[u]) {
@@ -969,14 +977,22 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
     hipStream_t s = (hipStream_t)stream;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
     const bool wide = cam->wide_tiles != 0 && !narrow;
-    hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * (split ? 4 : 1), s);
-    if (e != hipSuccess) return (int)e;
+    // row flags: legacy = zero the array, rows written in this pass get 1; with TS_RASTER_FLAG_GEN(g) the caller keeps
+    // ONE flag array alive across passes and hands every pass a fresh value g in 1..255 (zeroing the array itself
+    // when the values wrap) - no 1-byte-per-pair memset per frame
+    const int gen = (flags >> 8) & 0xff;
+    if (gen == 0) {
+        hipError_t e = hipMemsetAsync(row_flags, 0, (size_t)num_intersects * (split ? 4 : 1), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long isects_tagged = (long long)(((unsigned long long)(gen ? gen : 1) << 56) |
+                                                ((unsigned long long)num_intersects & 0x00ffffffffffffffull));
     const int units = split ? (wide ? 8 : 4) * nt : nt;
     const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
 #define TS_LAUNCH_BWD(C, S, X, L)                                                                  \
     hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
-                       (long long)num_intersects, tile_bins, gaussian_ids_sorted, sp, background,  \
+                       isects_tagged, tile_bins, gaussian_ids_sorted, sp, background,              \
                        final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials, row_flags)
 #define TS_LAUNCH_BWD_X(C, S)                                                                      \
     do {                                                                                           \

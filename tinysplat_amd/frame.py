@@ -87,6 +87,28 @@ def _mark(label):
 
 
 _pinned_total = {}      # device index -> (pinned int32[1], event): the path's one host read
+_row_flags = {}         # device index -> [uint8 tensor, generation]: ONE flag array per device, see row_flags_for
+
+# Row flags of the backward pass (1 byte per partial row: written in THIS pass?).  Instead of zeroing I bytes per
+# frame (a 5-10 us fill launch on the critical path), one array per device lives across frames and every pass
+# marks its rows with a fresh generation 1..255 (TS_RASTER_FLAG_GEN); the array is zeroed only when it grows or
+# the generations wrap.  TS_FLAG_GENERATIONS=0: zero per pass as before.
+FLAG_GENERATIONS = os.environ.get("TS_FLAG_GENERATIONS", "1") != "0"
+
+
+def row_flags_for(dev: torch.device, rows: int):
+    """-> (uint8 tensor of >= rows bytes, generation).  generation 0: a fresh array the kernels zero themselves."""
+    if not FLAG_GENERATIONS:
+        return torch.empty((rows,), dtype=torch.uint8, device=dev), 0
+    slot = _row_flags.get(dev.index)
+    if slot is None or slot[0].numel() < rows:
+        slot = _row_flags[dev.index] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0]
+    slot[1] += 1
+    if slot[1] > 255:
+        slot[0].zero_()
+        slot[1] = 1
+    return slot[0], slot[1]
+
 _bg_cache = {}          # (storage address, version, channels) -> contiguous background with the depth channel
 
 
@@ -375,10 +397,11 @@ def _steps_composite(lib, fr, s):
 
 def _steps_bwd_composite(lib, fr, s):
     split = 4 if fr.flags & 2 else 0
-    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split | (fr.flags & 8), fr.num_intersects, fr.cam, fr.tile_bins,
+    gen = (fr.flag_gen & 0xff) << 8
+    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split | (fr.flags & 8) | gen, fr.num_intersects, fr.cam, fr.tile_bins,
           fr.gaussian_ids_sorted, fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None,
           fr.clamp_mask, fr.partials, fr.row_flags, s)
-    _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split, fr.num_tiles_hit,
+    _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split | gen, fr.num_tiles_hit,
           fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, fr.v_xy, fr.v_conic, fr.v_colors,
           fr.v_opacity, fr.v_depth if fr.channels == 4 else None, fr.sh_mask if fr.flags & 16 else None, s)
 
@@ -403,6 +426,7 @@ class _RenderFrame(torch.autograd.Function):
         xys, radii = F.xys, F.radii
         ctx.xys_out = xys
         ctx.mark_non_differentiable(xys, radii)
+        ctx.set_materialize_grads(False)      # no zero tensors for the two index outputs on the way into backward
         # the image must not stay reachable from ctx: it is the differentiable output, its grad_fn owns
         # ctx, and the cycle would keep every buffer of the frame alive until the garbage collector runs
         out, F.out_img = F.out_img, None
@@ -419,6 +443,8 @@ class _RenderFrame(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         lib = _lib.load()
         s = _stream(dev)
+        if v_img is None:                     # the image did not take part in the loss
+            v_img = torch.zeros((F.cam.tile_rows and _stripe_rows(F.cam), F.w, ch), dtype=torch.float32, device=dev)
         v_img = _f32c(v_img)
         _mark("bwd:v_img contiguous")
         with torch.cuda.device(dev):
@@ -433,7 +459,7 @@ class _RenderFrame(torch.autograd.Function):
                 v_opac = torch.empty(tuple(ctx.opacity_shape), **f32)
             rows = max(F.total, 1) * (4 if F.split else 1)
             partials = torch.empty((rows, 12), **f32)
-            row_flags = torch.empty((rows,), dtype=torch.uint8, device=dev)
+            row_flags, fr.flag_gen = row_flags_for(dev, rows)
             _mark("bwd:flat+partials+flags")
             v_means = torch.empty((n, 3), **f32)
             v_scales = torch.empty((n, 3), **f32)

@@ -385,15 +385,16 @@ def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
     m, fr = S.m, S.fr
     rows_n = max(S.total, 1) * (4 if S.split else 1)
     partials = torch.empty((rows_n, 12), **f32)
-    row_flags = torch.empty((rows_n,), dtype=torch.uint8, device=dev)
+    row_flags, fr.flag_gen = _frame.row_flags_for(dev, rows_n)
     grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
     fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
     if kernel_timer.enabled:
-        rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0)
+        gen = (fr.flag_gen & 0xff) << 8
+        rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0) | gen
         _call("ts_raster_bwd", lib.ts_raster_bwd, ch, rflags, S.total, S.cam, fr.tile_bins, fr.gaussian_ids_sorted,
               fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None, fr.clamp_mask, fr.partials,
               fr.row_flags, s)
-        _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, 4 if S.split else 0, fr.num_tiles_hit,
+        _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, (4 if S.split else 0) | gen, fr.num_tiles_hit,
               fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, grad_rows.data_ptr(), s)
     else:
         _lib.check(lib.ts_shard_stripe_bwd(ctypes.byref(fr), grad_rows.data_ptr(), s), "ts_shard_stripe_bwd")
@@ -461,6 +462,8 @@ class _ShardedFrame(torch.autograd.Function):
         xys, radii = O.xys, O.radii
         ctx.xys_out = xys
         ctx.mark_non_differentiable(xys, radii)
+        ctx.set_materialize_grads(False)
+        ctx.out_shape = tuple(out.shape)
         return out, xys, radii
 
     @staticmethod
@@ -470,6 +473,8 @@ class _ShardedFrame(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             s = _stream(dev)
+            if v_img is None:
+                v_img = torch.zeros(ctx.out_shape, dtype=torch.float32, device=dev)
             grad_rows = _stripe_backward(lib, s, dev, S, O.ch, _f32c(v_img))
             back = exchange.rows(grad_rows, O.recv_counts, O.send_counts, backward=True)
             grads, v_xy = _owner_backward(lib, s, dev, layout, O, back, ctx.sh_degree, ctx.opacity_shape,

@@ -56,7 +56,7 @@ STAGE_OF = {
     "ts_scan_tiles": "bin_sort", "ts_bin_count": "bin_sort", "ts_tile_offsets": "bin_sort",
     "ts_bin_scatter": "bin_sort", "ts_sort_tiles": "bin_sort", "ts_pack_splats": "bin_sort",
     "ts_raster_fwd": "raster_fwd",
-    "ts_raster_bwd": "raster_bwd", "ts_reduce_partials": "raster_bwd",
+    "ts_raster_bwd": "raster_bwd", "ts_reduce_partials": "raster_bwd", "ts_reduce_partials_rows": "raster_bwd",
 }
 
 
@@ -275,7 +275,12 @@ KERNEL_TO_ENTRY = [("raster_bwd_kernel", "ts_raster_bwd"), ("raster_fwd_kernel",
                    ("sh_colors_fwd_kernel", "ts_colors_pack_fwd"), ("sh_colors_fwd_sparse_kernel", "ts_colors_pack_fwd"),
                    ("sh_colors_bwd_kernel", "ts_sh_colors_bwd"),
                    ("project_fwd_kernel", "ts_project_fwd"), ("project_bwd_kernel", "ts_project_bwd"),
-                   ("pack_splats_kernel", "ts_pack_splats"), ("gather48_kernel", "gather48_calibration")]
+                   ("pack_splats_kernel", "ts_pack_splats"), ("gather48_kernel", "gather48_calibration"),
+                   ("column_scan_kernel", "ts_tile_offsets"), ("tile_offsets_kernel", "ts_tile_offsets"),
+                   ("scan_local_kernel", "ts_scan_tiles"), ("scan_add_kernel", "ts_scan_tiles"),
+                   ("route_count_kernel", "ts_route_count"), ("route_scan_kernel", "ts_route_count"),
+                   ("route_pack_kernel", "ts_route_pack"), ("route_accumulate_kernel", "ts_route_accumulate"),
+                   ("import_records_kernel", "ts_import_records"), ("import_pack_kernel", "ts_import_pack")]
 
 
 def collect_pmc(workload_argv, timeout_s: float = 150.0):
@@ -320,6 +325,8 @@ def collect_pmc(workload_argv, timeout_s: float = 150.0):
                 per_entry_sum[entry] += tot / max(1, len(seen[(entry, name)]))
             for entry, v in per_entry_sum.items():
                 res[entry][key] = v
+                if entry == "ts_reduce_partials":        # the sharded frame calls the same kernel through _rows
+                    res["ts_reduce_partials_rows"][key] = v
         except Exception:
             return None
         finally:

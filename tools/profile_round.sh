@@ -31,7 +31,7 @@ def load(g, col):
     return d
 f, w = load("fetch", "FETCH_SIZE_per_dispatch"), load("write", "WRITE_SIZE_per_dispatch")
 names = {"raster_bwd_kernel": "ts_raster_bwd", "raster_fwd_kernel": "ts_raster_fwd",
-         "sort_tiles_kernel": "ts_sort_tiles", "bin_scatter_kernel": "ts_bin_scatter",
+         "sort_tiles_small_kernel": "ts_sort_tiles", "bin_scatter_coarse_kernel": "ts_bin_scatter",
          "sh_fwd_kernel": "ts_sh_fwd", "sh_bwd_kernel": "ts_sh_bwd", "sh_colors_fwd_kernel": "ts_colors_pack_fwd", "sh_colors_fwd_sparse_kernel": "ts_colors_pack_fwd", "sh_colors_bwd_kernel": "ts_sh_colors_bwd", "reduce_partials_kernel": "ts_reduce_partials",
          "project_fwd_kernel": "ts_project_fwd", "project_bwd_kernel": "ts_project_bwd",
          "pack_splats_kernel": "ts_pack_splats", "bin_count_kernel": "ts_bin_count"}

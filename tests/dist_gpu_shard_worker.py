@@ -23,7 +23,11 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    backend = os.environ.get("TS_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     from tinysplat_amd.sharded import DistExchange, ShardLayout, render_sharded, shard_model
     from tinysplat_amd.synthetic import loss_weights, make_scene
     model, cam = make_scene(n, sh, w, h, seed=3, scale_mult=mult)

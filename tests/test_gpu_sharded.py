@@ -135,15 +135,28 @@ def _free_port():
     return p
 
 
-def _launch(world, out_dir, n, sh, w, h, mult, depth, timeout=900):
+def _launch(world, out_dir, n, sh, w, h, mult, depth, timeout=900, backend="gloo"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            str(ROOT / "tests" / "dist_gpu_shard_worker.py"), str(out_dir), str(n), str(sh), str(w), str(h),
            str(mult), str(int(depth))]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", TS_TEST_BACKEND=backend)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [torch.load(Path(out_dir) / f"rank{k}.pt") for k in range(world)]
+
+
+def test_one_rank_over_rccl_equals_single_process(tmp_path):
+    """The exchange layer on the REAL backend: one rank, backend "nccl" (= RCCL) - count exchange and both
+    all_to_all_single calls with split sizes run through RCCL on device tensors (the boxes have one GPU, so this is
+    as far as RCCL can be exercised here); the frame must equal the single-process frame."""
+    n, sh, w, h, mult = 40000, 2, 640, 360, 2.0
+    outs = _launch(1, tmp_path, n, sh, w, h, mult, True, backend="nccl")
+    model, cam, full, xys, _, _ = _single(n, sh, w, h, mult, True)
+    assert torch.equal(outs[0]["img"], full.cpu())
+    for j, (nm, p) in enumerate(zip(NAMES, model.parameters())):
+        check_grad(f"rccl 1 rank {nm}", outs[0]["grads"][j], p.grad, rel=1e-5)
+    check_grad("rccl 1 rank xys", outs[0]["xys_grad"], xys.grad, rel=1e-5)
 
 
 @pytest.mark.parametrize("world,depth,n,sh,w,h,mult", [

@@ -40,6 +40,7 @@ def test_binding_covers_the_header_and_version_matches():
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + reserved (ABI 3)
+    assert ctypes.sizeof(_lib.TsStripes) == 4 * (_lib.MAX_RANKS + 2)
     assert lib.ts_frame_struct_bytes() == ctypes.sizeof(_lib.TsFrame)
     assert lib.ts_frame_fwd_project(None, None) == -1 and lib.ts_frame_bwd_params(None, None) == -1
 
@@ -63,6 +64,31 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_colors_pack_fwd(4, 0, 1, *([None] * 6), 3, 0, *([None] * 5), cam, None, None, None) == -1
     assert lib.ts_colors_pack_fwd(4, 2, 4, *([None] * 6), 3, 0, *([None] * 5), None, None, None, None) == -1
     assert lib.ts_sort_tiles(-1, *([None] * 7)) == -1
+    # ABI 4: the sharded frame's entries check their stripes / pointers before any launch
+    st = _lib.TsStripes()
+    st.num = 2
+    st.row[0], st.row[1], st.row[2] = 0, 1, 1
+    assert lib.ts_route_ws_ints(1000, 8) >= 4 * 8 + 9
+    assert lib.ts_route_count(-1, None, None, cam, st, None, None, None) == -1
+    assert lib.ts_route_count(4, None, None, cam, st, None, None, None) == -1          # no workspace
+    bad = _lib.TsStripes()
+    bad.num = 2
+    bad.row[0], bad.row[1], bad.row[2] = 0, 2, 1                                       # not ascending
+    ws = (ctypes.c_int32 * 64)()
+    assert lib.ts_route_count(0, None, None, cam, bad, ws, ws, None) == -1
+    bad.num = 17                                                                       # more than TS_MAX_RANKS
+    assert lib.ts_route_count(0, None, None, cam, bad, ws, ws, None) == -1
+    assert lib.ts_route_pack(4, 0, None, None, None, None, cam, st, ws, None, None) == -1
+    assert lib.ts_route_accumulate(4, 5, *([None] * 4), cam, st, ws, *([None] * 7)) == -1
+    assert lib.ts_import_records(-1, None, cam, None, None, None, None, None) == -1
+    assert lib.ts_import_records(0, None, cam, None, None, None, None, None) == 0     # nothing to do
+    assert lib.ts_import_pack(3, None, None, cam, None, None) == -1
+    assert lib.ts_reduce_partials_rows(3, 2, 0, *([None] * 7)) == -1
+    assert lib.ts_shard_owner_fwd(None, st, None, None, None) == -1
+    assert lib.ts_shard_stripe_fwd_import(None, None, None) == -1
+    assert lib.ts_shard_stripe_bwd(None, None, None) == -1 and lib.ts_shard_owner_bwd(None, st, None, None, None) == -1
+    assert lib.ts_tile_offsets(-1, 4, None, None, None, -1, None) == -1
+    assert lib.ts_bin_scatter(-1, None, None, None, cam, None, None, None, None) == -1
 
 
 def test_ops_refuse_cpu_tensors_and_product_never_imports_the_oracle():

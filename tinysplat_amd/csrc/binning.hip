@@ -766,9 +766,9 @@ __device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
     }
 }
 
-// Two launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles per
-// workgroup) and queues the larger ones; the second is a persistent grid that walks the queue with one
-// workgroup per tile.
+// Three launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles per
+// workgroup) and queues those beyond kSortCap; the second sorts the tiles in between with one workgroup per
+// tile; the third walks the queue (sample sort).
 __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     int num_tiles, const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_count,
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
     const int n = range.y - range.x;
     if (n <= 0) return;
-    if (n > kWaveSortMax) {                      // beyond one wave's network: queued for sort_tiles_big_kernel
-        if (lane == 0) large_list[atomicAdd(large_count, 1)] = tile;
+    if (n > kWaveSortMax) {                      // (kWaveSortMax, kSortCap]: sort_tiles_mid_kernel; beyond: queued
+        if (n > kSortCap && lane == 0) large_list[atomicAdd(large_count, 1)] = tile;
         return;
     }
     const int* g = bucket_ids + range.x;
@@ -792,10 +792,23 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
     else sort_tile_wave<16>(g, depths, out, n, lane);
 }
 
-// The queued tiles (more than kWaveSortMax keys), one workgroup per tile from a small persistent grid: up to
-// kSortCap keys the register network with LDS for the cross-wave stages, beyond that the sample sort.  One launch
-// that usually finds an empty queue (config 3: no tile above 614 keys) instead of two.
-__global__ __launch_bounds__(kThreads) void sort_tiles_big_kernel(
+// Tiles beyond one wave's network.  Up to kSortCap keys: one workgroup per tile, the register network with LDS
+// for the cross-wave stages (32 KiB of LDS: five workgroups per CU), launched over ALL tiles - a workgroup whose
+// tile belongs to another kernel leaves at once.  Walking a queue of such tiles from a persistent grid instead
+// (one launch for everything above a wave's network, tried in round 3) saved 5 us on config 3 and ran config 5's
+// sort - 14 k tiles of ~1 900 keys - at 0.78 - 0.89 instead of 0.55 ms.  Beyond kSortCap: the sample sort
+// (48 KiB), a small persistent grid over the queue that sort_tiles_small_kernel filled.
+__global__ __launch_bounds__(kThreads) void sort_tiles_mid_kernel(
+    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
+    __shared__ unsigned long long lk[kSortCap];
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
+    const int n = range.y - range.x;
+    if (n <= kWaveSortMax || n > kSortCap) return;
+    sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lk);
+}
+
+__global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
     const int* __restrict__ tile_bins, const float* __restrict__ depths,
     const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted,
     const int* __restrict__ large_count, const int* __restrict__ large_list) {
@@ -804,11 +817,9 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_big_kernel(
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int2 range = reinterpret_cast<const int2*>(tile_bins)[large_list[q]];
         const int n = range.y - range.x;
+        if (n <= kSortCap) continue;
         __syncthreads();
-        if (n <= kSortCap)
-            sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_large);
-        else
-            sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_large);
+        sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_large);
     }
 }
 
@@ -957,8 +968,10 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
     hipLaunchKernelGGL(sort_tiles_small_kernel, dim3((num_tiles + kThreads / 64 - 1) / (kThreads / 64)),
                        dim3(kThreads), 0, s, (int)num_tiles, tile_bins, depths, bucket_ids,
                        gaussian_ids_sorted, counter, list);
-    const int grid = num_tiles < 2048 ? num_tiles : 2048;
-    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
+    hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
+                       bucket_ids, gaussian_ids_sorted);
+    const int grid = num_tiles < 768 ? num_tiles : 768;
+    hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
                        bucket_ids, gaussian_ids_sorted, counter, list);
     return launch_status();
 }

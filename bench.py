@@ -501,7 +501,8 @@ def main():
             return
         if not sharded and args.depth:           # the adapter call itself (rasterize.py:26-62)
             rgb, extras = adapter(cam, (w, h), sh)
-            loss = (rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()
+            # D2's loss on both outputs, (rgb * w).sum() + (depth * w_d).sum(), each as one pass over a contiguous image
+            loss = torch.dot(rgb.reshape(-1), w_rgb.reshape(-1)) + torch.dot(extras["depth"].reshape(-1), w_d.reshape(-1))
         else:
             if args.emulate_ranks > 1 and world == 1:
                 r_, ws_ = args.emulate_rank, args.emulate_ranks
@@ -572,7 +573,8 @@ def main():
             for p_ in model.parameters():
                 p_.grad = None
             rgb, extras = adapter(cam, (w, h), sh)
-            ((rgb * w_rgb).sum() + (extras["depth"] * w_d).sum()).backward()
+            (torch.dot(rgb.reshape(-1), w_rgb.reshape(-1))
+             + torch.dot(extras["depth"].reshape(-1), w_d.reshape(-1))).backward()
         for _ in range(3):
             step_rgbd()
         torch.cuda.synchronize()

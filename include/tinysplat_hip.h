@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 4
+#define TS_ABI_VERSION 5
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -224,6 +224,13 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam_host, co
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
                   void* stream);
+/* The RGB + depth image as TWO planes (channels = 4 with out_depth != NULL): out_img[P,3] and out_depth[P] - what
+ * the adapter hands out as `rgb` and `extras["depth"]` (rasterize.py:45, :51), both contiguous, so that losses on
+ * them and their gradients need no slicing of an interleaved image.  out_depth = NULL: ts_raster_fwd. */
+int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
+                         const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
+                         float* out_img, float* out_depth, float* final_Ts, int32_t* final_index,
+                         uint8_t* clamp_mask, void* stream);
 
 /* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
  * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
@@ -237,6 +244,14 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
                   const float* background, const float* final_Ts, const int32_t* final_index,
                   const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
                   float* partials, uint8_t* row_flags, void* stream);
+/* planes != 0 (channels = 4): the image gradient as two planes, v_out_img[P,3] and v_out_depth[P]; either may be
+ * NULL (that output took no part in the loss: its gradient is zero).  planes = 0: ts_raster_bwd. */
+int ts_raster_bwd_planes(int32_t channels, int32_t flags, int64_t num_intersects, const ts_camera* cam_host,
+                         const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
+                         const float* background, const float* final_Ts, const int32_t* final_index,
+                         const float* v_out_img, const float* v_out_depth, int32_t planes,
+                         const float* v_out_alpha, const uint8_t* clamp_mask,
+                         float* partials, uint8_t* row_flags, void* stream);
 
 /* Sums each Gaussian's flagged rows (a contiguous range of `partials`, fixed order => run-to-run
  * bit-reproducible gradients), applies the conic / opacity factors read from `splats`, and writes
@@ -273,6 +288,8 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_SPLIT 2
 #define TS_FRAME_NARROW_WAVES 8        /* TS_RASTER_NARROW_WAVES for the compositing launches (cam.wide_tiles) */
 #define TS_FRAME_DIRECT_SCATTER 32     /* one-hop ts_bin_scatter (scratch = NULL): A/B timing */
+#define TS_FRAME_PLANES 64             /* channels = 4: RGB and depth as two planes (out_img[P,3] + out_depth[P];
+                                          v_out_img / v_out_depth, either may be NULL), see ts_raster_fwd_planes */
 #define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
                                           stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */
 typedef struct ts_frame {
@@ -303,6 +320,9 @@ typedef struct ts_frame {
     uint8_t* row_flags;
     float *v_xy, *v_conic, *v_colors, *v_depth, *v_opacity;
     float *v_means, *v_scales, *v_quats, *v_colors_dc, *v_colors_rest;
+    /* TS_FRAME_PLANES: the depth plane of the image and of its gradient */
+    float* out_depth;
+    const float* v_out_depth;
 } ts_frame;
 int32_t ts_frame_struct_bytes(void);       /* sizeof(ts_frame): bindings check their mirror against it */
 int ts_frame_fwd_project(const ts_frame* f, void* stream);

@@ -36,7 +36,7 @@ def test_binding_covers_the_header_and_version_matches():
     from tinysplat_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.ts_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 5
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + reserved (ABI 3)
@@ -88,6 +88,15 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_shard_stripe_fwd_import(None, None, None) == -1
     assert lib.ts_shard_stripe_bwd(None, None, None) == -1 and lib.ts_shard_owner_bwd(None, st, None, None, None) == -1
     assert lib.ts_tile_offsets(-1, 4, None, None, None, -1, None) == -1
+    # ABI 5: the RGB + depth image as two planes - a depth plane needs four channels; the interleaved entry needs
+    # its gradient image, the planes entry takes either plane or none
+    one = (ctypes.c_float * 4)()
+    assert lib.ts_raster_fwd_planes(3, 0, cam, *([None] * 5), one, None, None, None, None) == -1
+    assert lib.ts_raster_fwd_planes(5, 0, cam, *([None] * 9), None) == -1
+    assert lib.ts_raster_bwd_planes(3, 0, 1, cam, *([None] * 8), 1, *([None] * 5)) == -1
+    assert lib.ts_raster_bwd_planes(4, 0, 1, cam, *([None] * 7), one, 0, *([None] * 5)) == -1   # depth plane, planes = 0
+    assert lib.ts_raster_bwd(3, 0, 1, cam, *([None] * 11), None) == -1                         # no buffers at all
+    assert lib.ts_raster_bwd_planes(4, 0, 0, cam, *([None] * 8), 1, *([None] * 5)) == 0        # nothing listed
     assert lib.ts_bin_scatter(-1, None, None, None, cam, None, None, None, None) == -1
 
 

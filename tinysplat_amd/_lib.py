@@ -11,7 +11,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TsCamera(ctypes.Structure):
@@ -52,7 +52,8 @@ class TsFrame(ctypes.Structure):
                     "bucket_ids", "gaussian_ids_sorted", "out_img", "final_Ts", "final_index", "clamp_mask",
                     "v_out_img", "partials", "row_flags",
                     "v_xy", "v_conic", "v_colors", "v_depth", "v_opacity",
-                    "v_means", "v_scales", "v_quats", "v_colors_dc", "v_colors_rest")])
+                    "v_means", "v_scales", "v_quats", "v_colors_dc", "v_colors_rest",
+                    "out_depth", "v_out_depth")])
 
 
 _FRAME = POINTER(TsFrame)
@@ -89,6 +90,9 @@ SIGNATURES = {
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_raster_fwd_planes": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_raster_bwd_planes": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, c_int32,
+                                       _P, _P, _P, _P, _P]),
     "ts_bench_stream_read": (c_int32, [_P, c_int64, _P, _P]),
     "ts_bench_gather48": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ts_photometric_ws_floats": (c_int64, [c_int32, c_int32]),

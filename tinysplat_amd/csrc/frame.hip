@@ -108,17 +108,23 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
         TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
                              f->bin_ws, f->bin_ws + (ts_bin_ws_ints(f->n, num_tiles(f)) - 1), stream));
     }
-    return ts_raster_fwd(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
-                         f->background, f->out_img, f->final_Ts, f->final_index, f->clamp_mask, stream);
+    const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
+    if (planes && (f->channels != 4 || !f->out_depth)) return TS_E_BADARG;
+    return ts_raster_fwd_planes(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
+                                f->background, f->out_img, planes ? f->out_depth : nullptr, f->final_Ts,
+                                f->final_index, f->clamp_mask, stream);
 }
 
 int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
     TsRange range_("ts_frame_bwd_composite");
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
-    TS_TRY(ts_raster_bwd(f->channels, (raster_flags(f) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(f->flag_gen),
-                         f->num_intersects, &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats, f->background,
-                         f->final_Ts, f->final_index, f->v_out_img, nullptr, f->clamp_mask, f->partials, f->row_flags,
-                         stream));
+    const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
+    TS_TRY(ts_raster_bwd_planes(f->channels,
+                                (raster_flags(f) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(f->flag_gen),
+                                f->num_intersects, &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
+                                f->background, f->final_Ts, f->final_index, f->v_out_img,
+                                planes ? f->v_out_depth : nullptr, planes ? 1 : 0, nullptr, f->clamp_mask, f->partials,
+                                f->row_flags, stream));
     const bool stripe = (f->flags & TS_FRAME_STRIPE) != 0;
     return ts_reduce_partials(f->n, f->channels,
                               TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |

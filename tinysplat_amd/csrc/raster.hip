@@ -298,7 +298,7 @@ template <int CH, bool SPLIT, int NBX, bool WL>
 __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
-    const float* __restrict__ background, float* __restrict__ out_img,
+    const float* __restrict__ background, float* __restrict__ out_img, float* __restrict__ out_depth,
     float* __restrict__ final_Ts, int* __restrict__ final_index, const int clamp_rgb,
     unsigned char* __restrict__ clamp_mask) {
     constexpr int NB = 2 * NBX;
@@ -406,7 +406,9 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             final_Ts[pix] = Tf;
             final_index[pix] = fidx[k];
         }
-        float* o = out_img + pix * CH;
+        // out_depth (CH == 4 only): the image as two planes - 3 floats per pixel in out_img, channel 3 apart
+        const bool planes = CH == 4 && out_depth != nullptr;
+        float* o = out_img + pix * (planes ? 3 : CH);
         int pass = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
                 pass |= (val <= 1.0f) ? (1 << c) : 0;          // torch's rule: gradient passes at x <= max
                 val = fminf(val, 1.0f);
             }
-            o[c] = val;
+            if (c == 3 && planes) out_depth[pix] = val;
+            else o[c] = val;
         }
         if (clamp_mask) clamp_mask[pix] = (unsigned char)pass;
     }
@@ -668,8 +671,8 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
     const float4* __restrict__ splats, const float* __restrict__ background,
     const float* __restrict__ final_Ts, const int* __restrict__ final_index,
-    const float* __restrict__ v_out_img, const float* __restrict__ v_out_alpha,
-    const unsigned char* __restrict__ clamp_mask,
+    const float* __restrict__ v_out_img, const float* __restrict__ v_out_depth, const int planes,
+    const float* __restrict__ v_out_alpha, const unsigned char* __restrict__ clamp_mask,
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     constexpr int NB = 2 * NBX;
     __shared__ float4 lds_all[kWaves][64 * 4];
@@ -723,7 +726,12 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
             const int pass = clamp_mask ? clamp_mask[pix] : 7;   // backward of the fused clamp(max=1)
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                vo[k][c] = (c >= 3 || (pass & (1 << c))) ? v_out_img[pix * CH + c] : 0.0f;
+                float g;
+                if (CH == 4 && planes)       // two gradient planes, either may be absent (no part in the loss)
+                    g = c < 3 ? (v_out_img ? v_out_img[pix * 3 + c] : 0.0f) : (v_out_depth ? v_out_depth[pix] : 0.0f);
+                else
+                    g = v_out_img[pix * CH + c];
+                vo[k][c] = (c >= 3 || (pass & (1 << c))) ? g : 0.0f;
                 dotbg += bg[c] * vo[k][c];
             }
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
@@ -933,7 +941,15 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const i
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
                   void* stream) {
-    if (!cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
+    return ts_raster_fwd_planes(channels, flags, cam, tile_bins, gaussian_ids_sorted, splats, background, out_img,
+                                nullptr, final_Ts, final_index, clamp_mask, stream);
+}
+
+int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
+                         const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
+                         float* out_img, float* out_depth, float* final_Ts, int32_t* final_index,
+                         uint8_t* clamp_mask, void* stream) {
+    if (!cam || (channels != 3 && channels != 4) || (out_depth && channels != 4)) return TS_E_BADARG;
     const bool narrow = cam->wide_tiles != 0 && (flags & TS_RASTER_NARROW_WAVES) != 0;   // 16x16 waves, wide lists
     const int nt = narrow ? cam->tile_rows * cam->tile_bounds_x : ts_num_tiles(cam);
     if (nt <= 0) return 0;
@@ -947,7 +963,7 @@ int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const i
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
 #define TS_LAUNCH_FWD(C, S, X, L)                                                                  \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
-                       tile_bins, gaussian_ids_sorted, sp, background, out_img, final_Ts,           \
+                       tile_bins, gaussian_ids_sorted, sp, background, out_img, out_depth, final_Ts, \
                        final_index, clamp, clamp ? clamp_mask : nullptr)
 #define TS_LAUNCH_FWD_X(C, S)                                                                      \
     do {                                                                                           \
@@ -967,12 +983,24 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
                   const float* background, const float* final_Ts, const int32_t* final_index,
                   const float* v_out_img, const float* v_out_alpha, const uint8_t* clamp_mask,
                   float* partials, uint8_t* row_flags, void* stream) {
+    return ts_raster_bwd_planes(channels, flags, num_intersects, cam, tile_bins, gaussian_ids_sorted, splats, background,
+                                final_Ts, final_index, v_out_img, nullptr, 0, v_out_alpha, clamp_mask, partials,
+                                row_flags, stream);
+}
+
+int ts_raster_bwd_planes(int32_t channels, int32_t flags, int64_t num_intersects, const ts_camera* cam,
+                         const int32_t* tile_bins, const int32_t* gaussian_ids_sorted, const float* splats,
+                         const float* background, const float* final_Ts, const int32_t* final_index,
+                         const float* v_out_img, const float* v_out_depth, int32_t planes,
+                         const float* v_out_alpha, const uint8_t* clamp_mask,
+                         float* partials, uint8_t* row_flags, void* stream) {
     if (!cam || (channels != 3 && channels != 4) || num_intersects < 0) return TS_E_BADARG;
+    if (planes ? channels != 4 : v_out_depth != nullptr) return TS_E_BADARG;
     const bool narrow = cam->wide_tiles != 0 && (flags & TS_RASTER_NARROW_WAVES) != 0;
     const int nt = narrow ? cam->tile_rows * cam->tile_bounds_x : ts_num_tiles(cam);
     if (nt <= 0 || num_intersects == 0) return 0;
     if (!tile_bins || !gaussian_ids_sorted || !splats || !background || !final_Ts || !final_index ||
-        !v_out_img || !partials || !row_flags)
+        (!planes && !v_out_img) || !partials || !row_flags)
         return TS_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
@@ -993,7 +1021,8 @@ int ts_raster_bwd(int32_t channels, int32_t flags, int64_t num_intersects, const
 #define TS_LAUNCH_BWD(C, S, X, L)                                                                  \
     hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        isects_tagged, tile_bins, gaussian_ids_sorted, sp, background,              \
-                       final_Ts, final_index, v_out_img, v_out_alpha, clamp_mask, partials, row_flags)
+                       final_Ts, final_index, v_out_img, v_out_depth, planes ? 1 : 0, v_out_alpha,  \
+                       clamp_mask, partials, row_flags)
 #define TS_LAUNCH_BWD_X(C, S)                                                                      \
     do {                                                                                           \
         if (wide) TS_LAUNCH_BWD(C, S, 4, false);                                                   \

@@ -161,12 +161,14 @@ def _total_slot(dev: torch.device):
 class _Frame:
     """Buffers of one frame plus the ``ts_frame`` struct that points at them."""
     __slots__ = ("fr", "cam", "n", "nb", "ch", "w", "h", "num_tiles", "total", "split", "keep",
-                 "wf", "tile_bins", "ids", "bucket_ids", "out_img", "xys", "radii", "nth", "cum", "inputs", "bg")
+                 "wf", "tile_bins", "ids", "bucket_ids", "out_img", "out_depth", "planes", "xys", "radii", "nth", "cum",
+                 "inputs", "bg")
 
 
 def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background,
-             fx, fy, width, height, sh_degree, with_depth, tile_rows, keep: bool) -> _Frame:
-    """Enqueues the forward frame; ``keep`` = also produce what the backward pass needs."""
+             fx, fy, width, height, sh_degree, with_depth, tile_rows, keep: bool, planes: bool = False) -> _Frame:
+    """Enqueues the forward frame; ``keep`` = also produce what the backward pass needs; ``planes`` (with
+    ``with_depth``) = RGB and depth as two contiguous images instead of one 4-channel image."""
     _mark("fwd:enter")
     dev = _need_hip(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background)
     n = means.shape[0]
@@ -227,7 +229,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         F.wf = torch.empty((off,), dtype=torch.uint8, device=dev)
         base = F.wf.data_ptr()
         ptr = [base + o for o in offs]
-        F.out_img = torch.empty((rows, w, ch), **f32)
+        F.planes = bool(planes and with_depth)
+        F.out_img = torch.empty((rows, w, 3 if F.planes else ch), **f32)
+        F.out_depth = torch.empty((rows, w), **f32) if F.planes else None
 
         def view(k, dtype, count, shape):
             return F.wf[offs[k]:offs[k] + count * dtype.itemsize].view(dtype).view(shape)
@@ -242,7 +246,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
         stripe = STRIPE_SPARSE and cam.tile_rows < cam.tile_bounds_y
         fr.flags = ((1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
-                    | (0 if TWO_HOP_SCATTER else 32))
+                    | (0 if TWO_HOP_SCATTER else 32) | (64 if F.planes else 0))
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -252,6 +256,8 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         fr.bin_ws, fr.tile_bins = ptr[9], ptr[10]
         fr.total_host = host.data_ptr()
         fr.out_img = F.out_img.data_ptr()
+        if F.planes:
+            fr.out_depth = F.out_depth.data_ptr()
         if keep:
             fr.sh_mask, fr.final_Ts, fr.final_index, fr.clamp_mask = ptr[11], ptr[12], ptr[13], ptr[14]
         F.fr = fr
@@ -390,17 +396,18 @@ def _steps_composite(lib, fr, s):
               fr.bucket_ids, None if fr.flags & 32 else fr.gaussian_ids_sorted, s)
         _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
               fr.gaussian_ids_sorted, fr.bin_ws, fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
-    _call("ts_raster_fwd", lib.ts_raster_fwd, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam, fr.tile_bins,
-          fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.final_Ts, fr.final_index,
-          fr.clamp_mask, s)
+    _call("ts_raster_fwd", lib.ts_raster_fwd_planes, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam,
+          fr.tile_bins, fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img,
+          fr.out_depth if fr.flags & 64 else None, fr.final_Ts, fr.final_index, fr.clamp_mask, s)
 
 
 def _steps_bwd_composite(lib, fr, s):
     split = 4 if fr.flags & 2 else 0
     gen = (fr.flag_gen & 0xff) << 8
-    _call("ts_raster_bwd", lib.ts_raster_bwd, fr.channels, split | (fr.flags & 8) | gen, fr.num_intersects, fr.cam, fr.tile_bins,
-          fr.gaussian_ids_sorted, fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None,
-          fr.clamp_mask, fr.partials, fr.row_flags, s)
+    planes = 1 if fr.flags & 64 else 0
+    _call("ts_raster_bwd", lib.ts_raster_bwd_planes, fr.channels, split | (fr.flags & 8) | gen, fr.num_intersects, fr.cam,
+          fr.tile_bins, fr.gaussian_ids_sorted, fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img,
+          fr.v_out_depth if planes else None, planes, None, fr.clamp_mask, fr.partials, fr.row_flags, s)
     _call("ts_reduce_partials", lib.ts_reduce_partials, fr.n, fr.channels, 1 | split | gen, fr.num_tiles_hit,
           fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, fr.v_xy, fr.v_conic, fr.v_colors,
           fr.v_opacity, fr.v_depth if fr.channels == 4 else None, fr.sh_mask if fr.flags & 16 else None, s)
@@ -417,9 +424,9 @@ def _steps_bwd_params(lib, fr, s):
 class _RenderFrame(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacities, colors_dc, colors_rest, view34, projview,
-                origin, background, fx, fy, width, height, sh_degree, with_depth, tile_rows, group):
+                origin, background, fx, fy, width, height, sh_degree, with_depth, tile_rows, group, planes=False):
         F = _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin,
-                     background, fx, fy, width, height, sh_degree, with_depth, tile_rows, keep=True)
+                     background, fx, fy, width, height, sh_degree, with_depth, tile_rows, keep=True, planes=planes)
         ctx.frame, ctx.group = F, group
         ctx.opacity_shape = opacities.shape
         ctx.rest_shape = colors_rest.shape
@@ -430,10 +437,11 @@ class _RenderFrame(torch.autograd.Function):
         # the image must not stay reachable from ctx: it is the differentiable output, its grad_fn owns
         # ctx, and the cycle would keep every buffer of the frame alive until the garbage collector runs
         out, F.out_img = F.out_img, None
-        return out, xys, radii
+        depth, F.out_depth = F.out_depth, None          # None unless the frame was rendered as two planes
+        return out, depth, xys, radii
 
     @staticmethod
-    def backward(ctx, v_img, _v_xys, _v_radii):
+    def backward(ctx, v_img, v_depth_img, _v_xys, _v_radii):
         _mark("bwd:enter")
         F = ctx.frame
         if F is None:
@@ -443,9 +451,13 @@ class _RenderFrame(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         lib = _lib.load()
         s = _stream(dev)
-        if v_img is None:                     # the image did not take part in the loss
-            v_img = torch.zeros((F.cam.tile_rows and _stripe_rows(F.cam), F.w, ch), dtype=torch.float32, device=dev)
-        v_img = _f32c(v_img)
+        if F.planes:                          # an absent plane's gradient is zero inside the kernel: no zero image
+            v_img = None if v_img is None else _f32c(v_img)
+            v_depth_img = None if v_depth_img is None else _f32c(v_depth_img)
+        else:
+            if v_img is None:                 # the image did not take part in the loss
+                v_img = torch.zeros((F.cam.tile_rows and _stripe_rows(F.cam), F.w, ch), dtype=torch.float32, device=dev)
+            v_img = _f32c(v_img)
         _mark("bwd:v_img contiguous")
         with torch.cuda.device(dev):
             _mark("bwd:device ctx")
@@ -467,7 +479,9 @@ class _RenderFrame(torch.autograd.Function):
             v_dc = torch.empty((n, 3), **f32)
             v_rest = torch.empty(tuple(ctx.rest_shape), **f32)
             p = flat.data_ptr()
-            fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
+            fr.v_out_img = None if v_img is None else v_img.data_ptr()
+            fr.v_out_depth = None if (not F.planes or v_depth_img is None) else v_depth_img.data_ptr()
+            fr.partials, fr.row_flags = partials.data_ptr(), row_flags.data_ptr()
             if single:
                 fr.v_xy, fr.v_conic, fr.v_colors = v_xy.data_ptr(), p, p + 12 * n
                 fr.v_depth = p + 24 * n if ch == 4 else None
@@ -501,21 +515,24 @@ class _RenderFrame(torch.autograd.Function):
         xo = ctx.xys_out
         xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
         _mark("bwd:exit")
-        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 12
+        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 13
 
 
 @torch.no_grad()
 def render_view(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,
                 width: int, height: int, with_depth: bool = True,
-                tile_rows: Optional[Tuple[int, int]] = None):
+                tile_rows: Optional[Tuple[int, int]] = None, planes: bool = False):
     """Forward-only frame (the viewer's ``with torch.no_grad(): scene.render(camera)``,
     viewer.py:89-93): the kernels of ``render_frame`` without anything kept for a backward pass -
     no cov3d, clamp mask, final_Ts / final_index outputs, no autograd node.
-    -> (image[rows, W, 3 or 4] with RGB clamped to <= 1, xys[N,2], radii[N])."""
+    -> (image[rows, W, 3 or 4] with RGB clamped to <= 1, xys[N,2], radii[N]); with ``planes`` (and
+    ``with_depth``) -> (rgb[rows, W, 3], depth[rows, W], xys, radii) as ``render_frame_planes``."""
     F = _forward(model.means.detach(), model.scales.detach(), model.quats.detach(), model.opacities.detach(),
                  model.colors_dc.detach(), model.colors_rest.detach(), view34, projview, origin,
                  model.background, fx, fy, width, height, int(model.active_sh_degree), with_depth, tile_rows,
-                 keep=False)
+                 keep=False, planes=planes)
+    if F.planes:
+        return F.out_img, F.out_depth, F.xys, F.radii
     return F.out_img, F.xys, F.radii
 
 
@@ -529,7 +546,21 @@ def render_frame(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: fl
     ``group`` (a process group, or ``dist.group.WORLD``) makes backward sum the 2-D gradients over
     the ranks rendering the other stripes; ``None`` = single GPU, no collective.
     """
+    out, _, xys, radii = _RenderFrame.apply(model.means, model.scales, model.quats, model.opacities,
+                                            model.colors_dc, model.colors_rest, view34, projview, origin,
+                                            model.background, fx, fy, width, height, model.active_sh_degree,
+                                            with_depth, tile_rows, group, False)
+    return out, xys, radii
+
+
+def render_frame_planes(model, view34: Tensor, projview: Tensor, origin: Tensor, fx: float, fy: float,
+                        width: int, height: int, tile_rows: Optional[Tuple[int, int]] = None):
+    """The RGB + depth frame as the adapter hands it out (rasterize.py:45, :51): -> (rgb[rows, W, 3] clamped to
+    <= 1, depth[rows, W], xys[N,2], radii[N]), both images contiguous and both differentiable.  One 4-channel
+    compositing pass as in ``render_frame``; only the image and its gradient are laid out as two planes, so a
+    loss on ``rgb`` and one on ``depth`` cost no slicing of an interleaved image in either direction (at 3840x2160
+    autograd's slice / zero-fill / add glue around an interleaved image was 0.3 ms of a 4.5 ms frame)."""
     return _RenderFrame.apply(model.means, model.scales, model.quats, model.opacities,
                               model.colors_dc, model.colors_rest, view34, projview, origin,
                               model.background, fx, fy, width, height, model.active_sh_degree,
-                              with_depth, tile_rows, group)
+                              True, tile_rows, None, True)

@@ -106,7 +106,8 @@ class GaussianRasterizer:
                                    rasterize_gaussians=_hip_ops.rasterize_gaussians,
                                    sh_colors=_hip_ops.sh_colors, fused_prep=True,
                                    four_channels=True, render_frame=_hip_frame.render_frame,
-                                   render_view=_hip_frame.render_view)
+                                   render_view=_hip_frame.render_view,
+                                   render_frame_planes=_hip_frame.render_frame_planes)
 
     def __call__(self, camera, dims=None, sh_degree: Optional[int] = None):
         if dims is None:
@@ -121,12 +122,25 @@ class GaussianRasterizer:
             view, projview, origin = camera_on_device(camera, self.device)
             w, h = dims
             # under torch.no_grad() (the viewer, viewer.py:89-93) nothing is kept for backward
-            fn = ops.render_frame if torch.is_grad_enabled() else getattr(ops, "render_view", ops.render_frame)
-            out, xys, radii = fn(self.model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
-                                 w, h, True)
-            extras = {"depth": out[:, :, 3], "radii": radii, "xys": xys,
+            planes = getattr(ops, "render_frame_planes", None)
+            if planes is not None:
+                # rgb and depth as two contiguous images (what rasterize.py:45 and :51 hand out), composited in
+                # one 4-channel pass: nothing downstream slices an interleaved image, forward or backward
+                if torch.is_grad_enabled():
+                    rgb, depth, xys, radii = planes(self.model, view[:3, :], projview, origin, camera.f_x,
+                                                    camera.f_y, w, h)
+                else:
+                    rgb, depth, xys, radii = ops.render_view(self.model, view[:3, :], projview, origin,
+                                                             camera.f_x, camera.f_y, w, h, True, planes=True)
+            else:
+                # under torch.no_grad() (the viewer, viewer.py:89-93) nothing is kept for backward
+                fn = ops.render_frame if torch.is_grad_enabled() else getattr(ops, "render_view", ops.render_frame)
+                out, xys, radii = fn(self.model, view[:3, :], projview, origin, camera.f_x, camera.f_y,
+                                     w, h, True)
+                rgb, depth = out[:, :, :3], out[:, :, 3]
+            extras = {"depth": depth, "radii": radii, "xys": xys,
                       "camera": {"height": camera.height, "width": camera.width}}
-            return out[:, :, :3], extras           # clamp(max=1) is applied inside the kernels
+            return rgb, extras                     # clamp(max=1) is applied inside the kernels
         if prep:
             w, h = dims
             _, projview, _ = camera_on_device(camera, self.device)

@@ -562,6 +562,9 @@ __device__ __forceinline__ unsigned int lane_xor_dpp(unsigned int x) {
     return x;
 }
 
+#ifndef TS_SORT_WAVE_DPP
+#define TS_SORT_WAVE_DPP 0          // 1: DPP exchanges in the one-wave-per-tile sort too (A/B knob)
+#endif
 template <int E, int M>
 __device__ __forceinline__ void exchange_stage_dpp(unsigned long long (&k)[E], bool keep_min) {
 #pragma unroll
@@ -578,7 +581,7 @@ __device__ __forceinline__ void bitonic_regs(unsigned long long (&k)[E], int t, 
     // lane ^ 1, 2, 4, 8 by DPP where the LDS pipe is the busy unit (a workgroup per tile: four waves per tile and
     // five and more tiles per CU); a wave sorting a tile on its own has that pipe to spare and fewer VALU
     // instructions with ds_bpermute (config 3's sort: 75 us, 80 with DPP)
-    constexpr bool kDpp = GROUP > 64;
+    constexpr bool kDpp = TS_SORT_WAVE_DPP || GROUP > 64;
     const int lane = t & 63;
     for (int kk = 2; kk <= npad; kk <<= 1) {
         for (int j = kk >> 1; j >= E && j >= 1; j >>= 1) {

@@ -417,6 +417,12 @@ int ts_photometric_loss_rgbd(int32_t height, int32_t width, int32_t pixel_floats
                              float w_ssim, float w_depth, float* ws, float* v_image, void* stream);
 int ts_photometric_loss(int32_t height, int32_t width, const float* image, const float* target,
                         float w_l1, float w_ssim, float* ws, float* v_image, void* stream);
+/* ABI 5: the same loss on the frame as two planes (ts_raster_fwd_planes): image[H,W,3], depth[H,W] (may be NULL
+ * without a depth target), gradients v_image[H,W,3] and v_depth[H,W] (NULL: not wanted; v_depth = 0 everywhere
+ * without a depth target).  Sums as ts_photometric_loss_rgbd. */
+int ts_photometric_loss_planes(int32_t height, int32_t width, const float* image, const float* depth,
+                               const float* target, const float* depth_target, float w_l1, float w_ssim,
+                               float w_depth, float* ws, float* v_image, float* v_depth, void* stream);
 
 /* torch.optim.Adam (defaults: no amsgrad, no weight decay; train.py:26) on up to TS_ADAM_MAX_TENSORS
  * tensors with per-tensor learning rates (model_gaussian.py:112-120) in one launch.  The pointer

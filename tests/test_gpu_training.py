@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import train_oracle as TO
-from tinysplat_amd.training import Adam, TrainStep, frame_loss, photometric_loss
+from tinysplat_amd.training import Adam, TrainStep, frame_loss, photometric_loss, planes_loss
 from tinysplat_amd.synthetic import make_scene
 
 pytestmark = pytest.mark.gpu
@@ -55,6 +55,31 @@ def test_frame_loss_on_rgbd_output_equals_the_separate_losses(h, w, with_depth):
     assert err < 2e-8 + 1e-4 * x64.grad.abs().max().item(), err
     if not with_depth:
         assert torch.all(xd.grad[:, :, 3] == 0)
+
+
+@pytest.mark.parametrize("h,w,with_depth", [(64, 96, True), (77, 131, False), (120, 50, True)])
+def test_planes_loss_is_the_frame_loss_bit_for_bit(h, w, with_depth):
+    """ABI 5: the fused loss on rgb[H,W,3] + depth[H,W] (ts_photometric_loss_planes) against the same loss on the
+    interleaved [H,W,4] frame: values and both gradient planes identical; no depth gradient without a target."""
+    g = torch.Generator().manual_seed(h * w)
+    frame = torch.rand(h, w, 4, generator=g)
+    frame[:, :, 3] = 2.0 + 8.0 * frame[:, :, 3]
+    tgt = (frame[:, :, :3] + 0.2 * torch.randn(h, w, 3, generator=g)).clamp(0, 1).to(DEV)
+    dtgt = (2.0 + 8.0 * torch.rand(h, w, generator=g)).to(DEV) if with_depth else None
+    xd = frame.to(DEV).requires_grad_(True)
+    ref = frame_loss(xd * 1.0, tgt, dtgt, 0.2, 0.3)
+    (2.0 * ref[0]).backward()
+    rgb = frame[:, :, :3].contiguous().to(DEV).requires_grad_(True)
+    dep = frame[:, :, 3].contiguous().to(DEV).requires_grad_(True)
+    out = planes_loss(rgb * 1.0, dep * 1.0, tgt, dtgt, 0.2, 0.3)
+    (2.0 * out[0]).backward()
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+    assert torch.equal(rgb.grad, xd.grad[:, :, :3])
+    if with_depth:
+        assert torch.equal(dep.grad, xd.grad[:, :, 3])
+    else:
+        assert dep.grad is None or torch.all(dep.grad == 0)
 
 
 def test_ssim_of_identical_images_is_one():

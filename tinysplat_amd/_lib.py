@@ -98,6 +98,8 @@ SIGNATURES = {
     "ts_photometric_ws_floats": (c_int64, [c_int32, c_int32]),
     "ts_photometric_loss": (c_int32, [c_int32, c_int32, _P, _P, c_float, c_float, _P, _P, _P]),
     "ts_photometric_loss_rgbd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),
+    "ts_photometric_loss_planes": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P,
+                                             _P]),
     "ts_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
     "ts_grad_accum": (c_int32, [c_int32, _P, _P, _P]),
     "ts_densify_classify": (c_int32, [c_int32, _P, _P, _P, POINTER(TsDensifyPolicy), _P, _P]),

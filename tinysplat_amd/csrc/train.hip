@@ -85,8 +85,10 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 // (image tiles of the same grid cover the whole image; sums[block*2+1]).
 // X has `xs` floats per pixel (3: an RGB image; 4: the compositing kernels' RGB+depth output, whose
 // channel 3 is compared with the depth target D when D != nullptr, train.py:65-69).
+// Xd (with xs == 3): the depth as its own [H,W] plane (ts_photometric_loss_planes).
 __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs,
                                                             const float* __restrict__ X,
+                                                            const float* __restrict__ Xd,
                                                             const float* __restrict__ Y,
                                                             const float* __restrict__ D,
                                                             float* __restrict__ dmaps,
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
                 xa[u][0] = v.x; xa[u][1] = v.y; xa[u][2] = v.z; x3 = v.w;
             } else {
                 xa[u][0] = X[pix * 3]; xa[u][1] = X[pix * 3 + 1]; xa[u][2] = X[pix * 3 + 2];
+                if (Xd && D && r < kTile && q < kTile) x3 = Xd[pix];
             }
             ya[u][0] = Y[pix * 3]; ya[u][1] = Y[pix * 3 + 1]; ya[u][2] = Y[pix * 3 + 2];
             if (r < kTile && q < kTile) {
@@ -206,11 +209,12 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
 // w_ssim, plus w_l1 * sign(X - Y).
 __global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, int xs,
                                                             const float* __restrict__ X,
+                                                            const float* __restrict__ Xd,
                                                             const float* __restrict__ Y,
                                                             const float* __restrict__ D,
                                                             const float* __restrict__ dmaps,
                                                             float w_l1, float w_ssim, float w_depth,
-                                                            float* __restrict__ gX) {
+                                                            float* __restrict__ gX, float* __restrict__ gXd) {
     __shared__ float p0[kPatch][kPatch + 1], p1[kPatch][kPatch + 1], p2[kPatch][kPatch + 1];
     __shared__ float h0[kPatch][kTile + 1], h1[kPatch][kTile + 1], h2[kPatch][kTile + 1];
     float g[kWin];
@@ -279,6 +283,14 @@ __global__ __launch_bounds__(kThreads) void ssim_bwd_kernel(int H, int W, int xs
                 reinterpret_cast<float4*>(gX)[pix] = make_float4(gacc[j][0], gacc[j][1], gacc[j][2], gd);
             } else {
                 gX[pix * 3] = gacc[j][0]; gX[pix * 3 + 1] = gacc[j][1]; gX[pix * 3 + 2] = gacc[j][2];
+                if (gXd) {                           // the depth plane's gradient (zero without a target)
+                    float gd = 0.0f;
+                    if (D) {
+                        const float dd = Xd[pix] - D[pix];
+                        gd = w_depth * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f));
+                    }
+                    gXd[pix] = gd;
+                }
             }
         }
     }
@@ -359,11 +371,27 @@ int ts_photometric_loss_rgbd(int32_t height, int32_t width, int32_t pixel_floats
     const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, (int)pixel_floats,
-                       image, target, depth_target, ws, ws + plane3);
+                       image, (const float*)nullptr, target, depth_target, ws, ws + plane3);
     if (v_image)
         hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width,
-                           (int)pixel_floats, image, target, depth_target, ws, w_l1, w_ssim, w_depth,
-                           v_image);
+                           (int)pixel_floats, image, (const float*)nullptr, target, depth_target, ws, w_l1, w_ssim,
+                           w_depth, v_image, (float*)nullptr);
+    return launch_status();
+}
+
+int ts_photometric_loss_planes(int32_t height, int32_t width, const float* image, const float* depth,
+                               const float* target, const float* depth_target, float w_l1, float w_ssim,
+                               float w_depth, float* ws, float* v_image, float* v_depth, void* stream) {
+    if (height <= kHalo || width <= kHalo) return TS_E_BADARG;
+    if (!image || !target || !ws || (depth_target && !depth) || (v_depth && (!depth || !v_image))) return TS_E_BADARG;
+    const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);
+    const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, 3, image, depth, target,
+                       depth_target, ws, ws + plane3);
+    if (v_image)
+        hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width, 3, image, depth, target,
+                           depth_target, ws, w_l1, w_ssim, w_depth, v_image, v_depth);
     return launch_status();
 }
 

@@ -98,6 +98,58 @@ class _FrameLoss(torch.autograd.Function):
         return (None if v_frame is None else v_frame * v_loss), None, None, None, None   # out of place: retain_graph re-runs this (train.py:71)
 
 
+class _PlanesLoss(torch.autograd.Function):
+    """train.py:58-69 on the adapter's two outputs as it hands them out (rgb[H,W,3] and depth[H,W], both
+    contiguous: frame.render_frame_planes) in one pair of launches; the gradient comes back as two planes too."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, target, depth_target, lambda_dssim, lambda_depth):
+        dev = _need_hip(rgb, depth, target)
+        if rgb.dim() != 3 or rgb.shape[2] != 3 or not rgb.is_contiguous() or not depth.is_contiguous():
+            raise ValueError("rgb must be a contiguous [H, W, 3] tensor and depth a contiguous [H, W] one")
+        h, w = rgb.shape[0], rgb.shape[1]
+        if depth.shape != (h, w) or target.shape != (h, w, 3) or (depth_target is not None and depth_target.shape != (h, w)):
+            raise ValueError("depth must be [H, W], target [H, W, 3] and depth_target [H, W]")
+        if h <= 10 or w <= 10:
+            raise ValueError("SSIM with an 11-tap window needs H, W > 10")
+        rgb, depth, target = _f32c(rgb), _f32c(depth), _f32c(target)
+        dt = None if depth_target is None else _f32c(depth_target)
+        lib = _lib.load()
+        ws = torch.empty((int(lib.ts_photometric_ws_floats(h, w)),), dtype=torch.float32, device=dev)
+        v_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
+        v_depth = torch.empty_like(depth) if (v_rgb is not None and ctx.needs_input_grad[1] and dt is not None) else None
+        ho, wo = h - 10, w - 10
+        lam, lamd = float(lambda_dssim), float(lambda_depth) if dt is not None else 0.0
+        with torch.cuda.device(dev):
+            _call("ts_photometric_loss_rgbd", lib.ts_photometric_loss_planes, h, w, _ptr(rgb), _ptr(depth),
+                  _ptr(target), _ptr(dt), (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo),
+                  lamd / (h * w), _ptr(ws), _ptr(v_rgb), _ptr(v_depth), _stream(dev))
+        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
+        ssim = sums[0] / (3.0 * ho * wo)
+        l1 = sums[1] / (3.0 * h * w)
+        ldepth = sums[2] / (h * w)
+        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim) + lamd * ldepth).to(torch.float32)
+        ctx.has_depth = v_depth is not None
+        ctx.save_for_backward(*(t for t in (v_rgb, v_depth) if t is not None))
+        outs = (l1.to(torch.float32), ssim.to(torch.float32), ldepth.to(torch.float32))
+        ctx.mark_non_differentiable(*outs)
+        return (loss,) + outs
+
+    @staticmethod
+    def backward(ctx, v_loss, *_):
+        saved = ctx.saved_tensors
+        v_rgb = saved[0] * v_loss if saved else None             # out of place: retain_graph re-runs this (train.py:71)
+        v_depth = saved[1] * v_loss if ctx.has_depth else None   # None: no depth target, the kernels take "no gradient"
+        return v_rgb, v_depth, None, None, None, None
+
+
+def planes_loss(rgb: Tensor, depth: Tensor, target: Tensor, depth_target: Optional[Tensor] = None,
+                lambda_dssim: float = 0.2, lambda_depth: float = 0.2):
+    """``frame_loss`` on the frame as two planes: ``(loss, l1, ssim, depth_l1)``, differentiable w.r.t. ``rgb`` and
+    ``depth``."""
+    return _PlanesLoss.apply(rgb, depth, target, depth_target, lambda_dssim, lambda_depth)
+
+
 def frame_loss(frame: Tensor, target: Tensor, depth_target: Optional[Tensor] = None,
                lambda_dssim: float = 0.2, lambda_depth: float = 0.2):
     """Total training loss of train.py:58-69 on the adapter's [H, W, 4] output (RGB already clamped,
@@ -179,7 +231,14 @@ class TrainStep:
         gradient accumulation and, on the policy's steps, clone / split / prune."""
         rgb, extras = self.scene.render(camera)
         frame = getattr(rgb, "_base", None)
-        if (frame is not None and frame.dim() == 3 and frame.shape[2] == 4 and frame.is_contiguous()
+        depth = extras["depth"]
+        if (rgb.dim() == 3 and rgb.shape[2] == 3 and rgb.is_contiguous() and rgb.is_cuda and depth.is_contiguous()
+                and depth.shape == rgb.shape[:2] and frame is None):
+            # the adapter's one-node path hands out two contiguous images: the whole loss (train.py:58-69) on
+            # them in one pair of launches, gradients back as two planes
+            loss, l1, ssim, _ = planes_loss(rgb, depth, target_rgb, target_depth, self.lambda_dssim,
+                                            self.lambda_depth)
+        elif (frame is not None and frame.dim() == 3 and frame.shape[2] == 4 and frame.is_contiguous()
                 and extras["depth"]._base is frame):
             # the adapter's one-node path hands out views of ONE [H, W, 4] tensor: evaluate the
             # whole loss (train.py:58-69) on it in place, no slicing / re-packing of image or gradient

@@ -461,12 +461,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     extern __shared__ int cursor[];
     if (tile_start[num_tiles + 1] != 0) return;              // capacity guard (tile_offsets_kernel)
     const int groups = (num_tiles + kCoarseTiles - 1) >> kCoarseShift;
+    // cursor[g] = start of the group's region + the entries earlier chunks put into the group's tiles; the chunk's
+    // row of the base matrix is read coalesced by the whole workgroup and summed per group with LDS atomics
     const int* src = bases + (size_t)blockIdx.x * num_tiles;
-    for (int g = threadIdx.x; g < groups; g += kBinThreads) {
-        const int t0 = g << kCoarseShift, t1 = min(num_tiles, t0 + kCoarseTiles);
-        int c = tile_start[t0];
-        for (int t = t0; t < t1; ++t) c += src[t];          // entries of earlier chunks in this group's tiles
-        cursor[g] = c;
+    for (int g = threadIdx.x; g < groups; g += kBinThreads) cursor[g] = tile_start[g << kCoarseShift];
+    __syncthreads();
+    for (int t = threadIdx.x; t < num_tiles; t += kBinThreads) {
+        const int v = src[t];
+        if (v) atomicAdd(&cursor[t >> kCoarseShift], v);
     }
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
@@ -475,19 +477,104 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     });
 }
 
-__global__ __launch_bounds__(kThreads) void bin_scatter_fine_kernel(int num_tiles,
-                                                                    const int* __restrict__ tile_start,
-                                                                    const int* __restrict__ scratch,
-                                                                    int* __restrict__ bucket_ids) {
-    __shared__ int cursor[kCoarseTiles];
+#ifndef TS_FINE_THREADS
+#define TS_FINE_THREADS 1024
+#endif
+#ifndef TS_FINE_AHEAD
+#define TS_FINE_AHEAD 8
+#endif
+#ifndef TS_FINE_REORDER
+#define TS_FINE_REORDER 1
+#endif
+constexpr int kFineThreads = TS_FINE_THREADS;
+constexpr int kFineAhead = TS_FINE_AHEAD;
+constexpr int kFinePass = kFineThreads * kFineAhead;     // entries handled together
+// Fine hop: one workgroup per tile group streams the group's region in passes of kFinePass entries.  A pass is
+// reordered by tile in LDS before it is written (rank inside the tile from a returning LDS atomic, tile offsets
+// from a 32-entry scan), so that consecutive lanes store consecutive words of one bucket: with one 4-byte store
+// per entry straight from the stream a wave's store touched ~32 different lines, and the kernel was bound by
+// those write transactions (137 us for 250 MB on config 5), not by bytes.  The order inside a bucket is
+// arbitrary, as before; ts_sort_tiles follows.
+__global__ __launch_bounds__(kFineThreads) void bin_scatter_fine_kernel(int num_tiles,
+                                                                        const int* __restrict__ tile_start,
+                                                                        const int* __restrict__ scratch,
+                                                                        int* __restrict__ bucket_ids) {
+    __shared__ int cursor[kCoarseTiles];                 // next free word of every bucket of the group
     const int t0 = blockIdx.x << kCoarseShift, t1 = min(num_tiles, t0 + kCoarseTiles);
     if ((int)threadIdx.x < t1 - t0) cursor[threadIdx.x] = tile_start[t0 + threadIdx.x];
-    __syncthreads();
     const int begin = tile_start[t0], end = tile_start[t1];
-    for (int j = begin + threadIdx.x; j < end; j += kThreads) {
-        const unsigned int w = (unsigned int)scratch[j];
-        bucket_ids[atomicAdd(&cursor[w >> kCoarseIdBits], 1)] = (int)(w & ((1u << kCoarseIdBits) - 1u));
+#if TS_FINE_REORDER
+    __shared__ int hist[kCoarseTiles], loff[kCoarseTiles + 1], gbase[kCoarseTiles];
+    __shared__ int ids[kFinePass];
+    __shared__ unsigned char tiles[kFinePass];
+    if ((int)threadIdx.x < kCoarseTiles) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int c0 = begin; c0 < end; c0 += kFinePass) {
+        const int m = min(kFinePass, end - c0);                       // entries of this pass
+        unsigned int w[kFineAhead];
+        int rank[kFineAhead];
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u) {
+            const int k = u * kFineThreads + (int)threadIdx.x;
+            if (k < m) w[u] = (unsigned int)scratch[c0 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u) {
+            const int k = u * kFineThreads + (int)threadIdx.x;
+            if (k < m) rank[u] = atomicAdd(&hist[w[u] >> kCoarseIdBits], 1);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 64) {                                  // one wave: offsets of the pass, bases, reset
+            const int t = threadIdx.x;
+            const int c = t < kCoarseTiles ? hist[t] : 0;
+            int inc = c;                                              // inclusive scan over the first 32 lanes
+#pragma unroll
+            for (int d = 1; d < kCoarseTiles; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (t >= d) inc += o;
+            }
+            if (t < kCoarseTiles) {
+                loff[t] = inc - c;
+                gbase[t] = cursor[t];
+                cursor[t] += c;
+                hist[t] = 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u) {
+            const int k = u * kFineThreads + (int)threadIdx.x;
+            if (k < m) {
+                const int t = (int)(w[u] >> kCoarseIdBits);
+                const int lp = loff[t] + rank[u];
+                ids[lp] = (int)(w[u] & ((1u << kCoarseIdBits) - 1u));
+                tiles[lp] = (unsigned char)t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u) {
+            const int k = u * kFineThreads + (int)threadIdx.x;
+            if (k < m) {
+                const int t = tiles[k];
+                bucket_ids[gbase[t] + (k - loff[t])] = ids[k];
+            }
+        }
+        __syncthreads();                                              // ids / tiles / loff are rewritten by the next pass
     }
+#else
+    __syncthreads();
+    for (int j = begin + threadIdx.x; j < end; j += kFineAhead * kFineThreads) {
+        unsigned int w[kFineAhead];
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u)
+            if (j + u * kFineThreads < end) w[u] = (unsigned int)scratch[j + u * kFineThreads];
+#pragma unroll
+        for (int u = 0; u < kFineAhead; ++u)
+            if (j + u * kFineThreads < end)
+                bucket_ids[atomicAdd(&cursor[w[u] >> kCoarseIdBits], 1)] = (int)(w[u] & ((1u << kCoarseIdBits) - 1u));
+    }
+#endif
 }
 
 // ---- per-tile bitonic sort ---------------------------------------------------------------------
@@ -798,7 +885,10 @@ __device__ __forceinline__ void sort_tile_sample(const int* __restrict__ g,
 // registers and lane exchanges, no LDS storage, no barrier, and the E independent keys of a lane
 // keep E exchanges in flight per stage.  Which key starts in which position is irrelevant to a sort,
 // so the ids are loaded coalesced (position e*64 + lane); the result is stored by position.
-constexpr int kWaveSortMax = 1024;
+#ifndef TS_WAVE_SORT_MAX
+#define TS_WAVE_SORT_MAX 1024   // 512 / 256 (more tiles to the workgroup sort): config 3's sort 74 -> 84 / 94 us
+#endif
+constexpr int kWaveSortMax = TS_WAVE_SORT_MAX;
 template <int E>
 __device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
                                                const float* __restrict__ depths,
@@ -984,7 +1074,7 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
         hipLaunchKernelGGL(bin_scatter_coarse_kernel, dim3(chunks), dim3(kBinThreads), (size_t)groups * sizeof(int),
                            (hipStream_t)stream, n, chunk, xys, radii, reinterpret_cast<const float4*>(splats), *cam,
                            nt, bin_ws, tile_start, scratch);
-        hipLaunchKernelGGL(bin_scatter_fine_kernel, dim3(groups), dim3(kThreads), 0, (hipStream_t)stream, nt,
+        hipLaunchKernelGGL(bin_scatter_fine_kernel, dim3(groups), dim3(kFineThreads), 0, (hipStream_t)stream, nt,
                            tile_start, scratch, bucket_ids);
         return launch_status();
     }

@@ -80,3 +80,29 @@ def test_row_flag_generations_wrap_and_match_zeroed_flags(monkeypatch):
         assert torch.equal(g[0], ref[0]) and torch.equal(g[2], ref[2])
         for a, b in zip(g[1], ref[1]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,sh,w,h,mult,wide", [(300000, 1, 1920, 1080, 1.0, 0), (270000, 0, 1000, 523, 3.0, 0),
+                                                (400000, 0, 1283, 717, 2.0, 2), (262144, 2, 640, 360, 6.0, 0)])
+def test_two_hop_scatter_fills_the_buckets_of_the_direct_scatter(n, sh, w, h, mult, wide, monkeypatch):
+    """ts_bin_scatter from 256 k Gaussians on: ids travel to their buckets in two hops (tile group, then tile, the
+    second hop reordered by tile in LDS).  Same buckets as the one-hop scatter: the sorted lists, the image and the
+    gradients are bit for bit the same; images that are not a multiple of the tile, long lists (scale 6: workgroup
+    sort) and the 32x16 lists included."""
+    model, cam = make_scene(n, sh, w, h, seed=21, scale_mult=mult)
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    monkeypatch.setattr(frame, "WIDE_TILES", wide)
+    res = []
+    for two_hop in (False, True):
+        monkeypatch.setattr(frame, "TWO_HOP_SCATTER", two_hop)
+        out = _run(model, cam, w, h, True, w_rgb, w_d)
+        b = frame.last_binning[DEV.index]
+        res.append((out, b.tile_bins.clone(), b.gaussian_ids_sorted.clone()))
+    (ref, bins0, ids0), (got, bins1, ids1) = res
+    listed = int(bins0[:, 1].max())              # the buffers are sized by gsplat's bounding-box count; the tail is unused
+    assert listed > 0
+    assert torch.equal(bins0, bins1) and torch.equal(ids0[:listed], ids1[:listed])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    for a, b_ in zip(got[1], ref[1]):
+        assert torch.equal(a, b_)

@@ -183,6 +183,11 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
 int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
                   const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
                   int32_t* zeroed_counter, void* stream);
+/* ABI 5: ts_sort_tiles for the tiles of MORE than 1024 entries only - the companion of ts_raster_fwd_sort, which
+ * sorts the shorter lists itself (one wave per tile) right before it composites them. */
+int ts_sort_tiles_above(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
+                        const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
+                        int32_t* zeroed_counter, void* stream);
 /* zeroed_counter: NULL, or a device word known to be zero that the sort may use as its counter of oversized
  * tiles (it is left non-zero).  ts_tile_offsets zeroes the LAST word of its workspace,
  * bin_ws[ts_bin_ws_ints(n, num_tiles) - 1], for this purpose: passing it saves a 4-byte memset launch. */
@@ -231,6 +236,16 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam_h
                          const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                          float* out_img, float* out_depth, float* final_Ts, int32_t* final_index,
                          uint8_t* clamp_mask, void* stream);
+
+/* ABI 5: ts_raster_fwd_planes with the per-tile sort of the lists of <= 1024 entries inside (bucket_ids[I] ->
+ * gaussian_ids_sorted[I], which ts_raster_bwd reads later; ts_sort_tiles_above must have run for the longer lists).
+ * Only for one wave per 16x16 tile on 16x16 lists (cam->wide_tiles = 0, no TS_RASTER_SPLIT_BLOCKS /
+ * TS_RASTER_NARROW_WAVES: TS_E_BADARG otherwise).  Same image, same sorted lists; the latency-bound sort overlaps
+ * the VALU-bound compositing of other tiles instead of running as a phase of its own. */
+int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
+                       const int32_t* bucket_ids, const float* depths, int32_t* gaussian_ids_sorted,
+                       const float* splats, const float* background, float* out_img, float* out_depth,
+                       float* final_Ts, int32_t* final_index, uint8_t* clamp_mask, void* stream);
 
 /* Back-to-front replay.  Writes one TS_PARTIAL_ROW_FLOATS row of raw per-tile sums per contributing
  * (tile,Gaussian), with v_s = dL/dsigma of a pixel and d = xy - pixel:
@@ -290,6 +305,7 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_DIRECT_SCATTER 32     /* one-hop ts_bin_scatter (scratch = NULL): A/B timing */
 #define TS_FRAME_PLANES 64             /* channels = 4: RGB and depth as two planes (out_img[P,3] + out_depth[P];
                                           v_out_img / v_out_depth, either may be NULL), see ts_raster_fwd_planes */
+#define TS_FRAME_SEPARATE_SORT 128     /* ts_sort_tiles + ts_raster_fwd_planes even where ts_raster_fwd_sort applies: A/B */
 #define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
                                           stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */
 typedef struct ts_frame {

@@ -106,3 +106,31 @@ def test_two_hop_scatter_fills_the_buckets_of_the_direct_scatter(n, sh, w, h, mu
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
     for a, b_ in zip(got[1], ref[1]):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("n,sh,w,h,mult,depth", [(60000, 2, 640, 360, 2.0, True), (300000, 1, 1920, 1080, 1.0, False),
+                                                 (50000, 0, 333, 211, 14.0, True), (3000, 3, 1280, 720, 1.0, False)])
+def test_the_sort_inside_the_compositing_launch_changes_nothing(n, sh, w, h, mult, depth, monkeypatch):
+    """ts_raster_fwd_sort (one wave per 16x16 tile on 16x16 lists): the forward compositing kernel sorts the lists
+    of <= 1024 entries itself, ts_sort_tiles_above the longer ones (scale 14: lists of several thousand entries,
+    workgroup sort and sample sort).  Sorted lists, image and gradients are bit for bit those of the separate sort."""
+    model, cam = make_scene(n, sh, w, h, seed=31, scale_mult=mult)
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    monkeypatch.setattr(frame, "WIDE_TILES", 0)
+    monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 0)             # one wave per tile also on the small images
+    res = []
+    for inline in (False, True):
+        monkeypatch.setattr(frame, "INLINE_SORT", inline)
+        out = _run(model, cam, w, h, depth, w_rgb, w_d)
+        b = frame.last_binning[DEV.index]
+        res.append((out, b.tile_bins.clone(), b.gaussian_ids_sorted.clone()))
+    (ref, bins0, ids0), (got, bins1, ids1) = res
+    listed = int(bins0[:, 1].max())
+    assert listed > 0
+    if mult > 10:
+        assert int((bins0[:, 1] - bins0[:, 0]).max()) > 1024        # lists beyond one wave's network are present
+    assert torch.equal(bins0, bins1) and torch.equal(ids0[:listed], ids1[:listed])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    for a, b_ in zip(got[1], ref[1]):
+        assert torch.equal(a, b_)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P, c_int64, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_sort_tiles_above": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),
     "ts_colors_pack_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
                                      _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "ts_raster_fwd": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_fwd_planes": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ts_raster_fwd_sort": (c_int32, [c_int32, c_int32, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_raster_bwd_planes": (c_int32, [c_int32, c_int32, c_int64, _CAM, _P, _P, _P, _P, _P, _P, _P, _P, c_int32,
                                        _P, _P, _P, _P, _P]),
     "ts_bench_stream_read": (c_int32, [_P, c_int64, _P, _P]),

@@ -580,10 +580,7 @@ __global__ __launch_bounds__(kFineThreads) void bin_scatter_fine_kernel(int num_
 // ---- per-tile bitonic sort ---------------------------------------------------------------------
 constexpr int kSortCap = 4096;   // keys held in LDS (32 KiB); larger buckets sort in global memory
 
-// sort key of a bucket entry: depth bits (positive floats order like their bit patterns) then id
-__device__ __forceinline__ unsigned long long make_key(const float* __restrict__ depths, int id) {
-    return ((unsigned long long)__float_as_uint(depths[id]) << 32) | (unsigned int)id;
-}
+#include "sort_network.h"
 
 struct IdKeyArray {                 // in-place view of a bucket of ids compared through their keys
     volatile int* ids;
@@ -618,119 +615,6 @@ __device__ __forceinline__ void bitonic_network(Ptr a, int n) {
             __syncthreads();
         }
     }
-}
-
-// Register-resident bitonic sort of one tile bucket by a 256-thread workgroup: thread t holds the E
-// consecutive keys t*E .. t*E+E-1 (padded with +inf to npad = 256*E).  Compare-exchange partners at
-// distance j are in the same thread (j < E: pure register work), in the same wave (E <= j < 64 E:
-// 64-bit lane exchange through the LDS crossbar, no barrier) or in another wave (j >= 64 E: one LDS
-// round trip with a barrier - at most 3 of the 55 stages of a 1024-key sort).
-// Bitonic network over GROUP threads (GROUP = 256: the workgroup, with LDS + barriers for the
-// cross-wave stages; GROUP = 64: one wave, shuffles only, no barrier).  Thread t of the group holds
-// the E consecutive keys t*E .. t*E+E-1; npad (a power of two <= GROUP*E) bounds the stages that can
-// see anything but +inf padding.
-// The 32-bit value of lane ^ M for M = 1, 2, 4, 8 without the LDS crossbar: quad_perm, row_ror:8, and for M = 4
-// row_half_mirror (lane 7 - i of each 8) followed by a reversed quad_perm.  Every lane is written, so no previous
-// value of the destination is needed (old = 0 with bound_ctrl: no copy in front of the DPP move).  26 of the 33
-// in-wave stages of a 2048-key sort exchange at these distances; with ds_bpermute for all of them the LDS pipe
-// was the busiest unit of the sort (config 5: ~675 LDS instructions per wave, SQ_ACTIVE_INST_LDS at the kernel's
-// duration).
-template <int M>
-__device__ __forceinline__ unsigned int lane_xor_dpp(unsigned int x) {
-    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "DPP reaches lane ^ 1, 2, 4, 8");
-    const int v = (int)x;
-    if constexpr (M == 1) return (unsigned int)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
-    if constexpr (M == 2) return (unsigned int)__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
-    if constexpr (M == 8) return (unsigned int)__builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
-    if constexpr (M == 4) {
-        const int r = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);                            // row_half_mirror
-        return (unsigned int)__builtin_amdgcn_update_dpp(0, r, 0x1B, 0xF, 0xF, true);                      // quad_perm:[3,2,1,0]
-    }
-    return x;
-}
-
-#ifndef TS_SORT_WAVE_DPP
-#define TS_SORT_WAVE_DPP 0          // 1: DPP exchanges in the one-wave-per-tile sort too (A/B knob)
-#endif
-template <int E, int M>
-__device__ __forceinline__ void exchange_stage_dpp(unsigned long long (&k)[E], bool keep_min) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const unsigned long long o = ((unsigned long long)lane_xor_dpp<M>((unsigned int)(k[e] >> 32)) << 32) |
-                                     lane_xor_dpp<M>((unsigned int)k[e]);
-        k[e] = ((o < k[e]) == keep_min) ? o : k[e];                   // keys are unique: no ties
-    }
-}
-
-template <int E, int GROUP>
-__device__ __forceinline__ void bitonic_regs(unsigned long long (&k)[E], int t, int npad,
-                                             unsigned long long* lds) {
-    // lane ^ 1, 2, 4, 8 by DPP where the LDS pipe is the busy unit (a workgroup per tile: four waves per tile and
-    // five and more tiles per CU); a wave sorting a tile on its own has that pipe to spare and fewer VALU
-    // instructions with ds_bpermute (config 3's sort: 75 us, 80 with DPP)
-    constexpr bool kDpp = TS_SORT_WAVE_DPP || GROUP > 64;
-    const int lane = t & 63;
-    for (int kk = 2; kk <= npad; kk <<= 1) {
-        for (int j = kk >> 1; j >= E && j >= 1; j >>= 1) {
-            // for j >= E the direction bit (i & kk) and the side bit (i & j) depend on t only
-            const bool asc = ((t * E) & kk) == 0;
-            if (GROUP > 64 && j >= 64 * E) {         // partner in another wave: thread t ^ (j / E), same register
-                // element e of thread t at lds[e * GROUP + t] (consecutive lanes, consecutive 8-byte words), half of
-                // the elements per round: GROUP * E / 2 words of LDS, so that a 4096-key sort needs 16 KiB, not 32
-                constexpr int H = E >= 2 ? E / 2 : 1;
-                const bool keep_min = (((t * E) & j) == 0) == asc;
-                const int partner = t ^ (j / E);
-#pragma unroll
-                for (int r = 0; r < E / H; ++r) {
-#pragma unroll
-                    for (int e = 0; e < H; ++e) lds[e * GROUP + t] = k[r * H + e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < H; ++e) {
-                        const unsigned long long o = lds[e * GROUP + partner];
-                        k[r * H + e] = ((o < k[r * H + e]) == keep_min) ? o : k[r * H + e];
-                    }
-                    __syncthreads();
-                }
-            } else {                                 // partner lane = lane ^ (j / E), same register
-                const int m = j / E;
-                const bool keep_min = ((lane & m) == 0) == asc;
-                switch (kDpp ? m : 0) {
-                    case 1: exchange_stage_dpp<E, 1>(k, keep_min); break;
-                    case 2: exchange_stage_dpp<E, 2>(k, keep_min); break;
-                    case 4: exchange_stage_dpp<E, 4>(k, keep_min); break;
-                    case 8: exchange_stage_dpp<E, 8>(k, keep_min); break;
-                    default:                         // lane ^ 16, lane ^ 32: through the LDS crossbar
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            const unsigned long long o = __shfl_xor(k[e], m, 64);
-                            k[e] = ((o < k[e]) == keep_min) ? o : k[e];
-                        }
-                }
-            }
-        }
-#pragma unroll
-        for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // in-thread stages (compile-time register ids)
-            if (jj < kk) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if ((e & jj) == 0) {
-                        const bool asc = (((t * E + e) & kk) == 0);
-                        const unsigned long long x = k[e], y = k[e | jj];
-                        const bool sw = (x > y) == asc;
-                        k[e] = sw ? y : x;
-                        k[e | jj] = sw ? x : y;
-                    }
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ int pow2_at_least(int n) {
-    int p = 2;
-    while (p < n) p <<= 1;
-    return p;
 }
 
 // Register-resident bitonic sort of one bucket of ids by the whole workgroup (n <= 256 E): in-thread
@@ -881,32 +765,6 @@ __device__ __forceinline__ void sort_tile_sample(const int* __restrict__ g,
     }
 }
 
-// One WAVE sorts one tile (n <= 64 E keys, E = 1..16 per lane): the whole bitonic network runs on
-// registers and lane exchanges, no LDS storage, no barrier, and the E independent keys of a lane
-// keep E exchanges in flight per stage.  Which key starts in which position is irrelevant to a sort,
-// so the ids are loaded coalesced (position e*64 + lane); the result is stored by position.
-#ifndef TS_WAVE_SORT_MAX
-#define TS_WAVE_SORT_MAX 1024   // 512 / 256 (more tiles to the workgroup sort): config 3's sort 74 -> 84 / 94 us
-#endif
-constexpr int kWaveSortMax = TS_WAVE_SORT_MAX;
-template <int E>
-__device__ __forceinline__ void sort_tile_wave(const int* __restrict__ g,
-                                               const float* __restrict__ depths,
-                                               int* __restrict__ out, int n, int lane) {
-    unsigned long long k[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * 64 + lane;
-        k[e] = i < n ? make_key(depths, g[i]) : ~0ull;
-    }
-    bitonic_regs<E, 64>(k, lane, min(pow2_at_least(n), 64 * E), nullptr);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = lane * E + e;
-        if (i < n) out[i] = (int)(unsigned int)k[e];
-    }
-}
-
 // Three launches: the first kernel gives every tile of up to kWaveSortMax keys to one wave (four tiles per
 // workgroup) and queues those beyond kSortCap; the second sorts the tiles in between with one workgroup per
 // tile; the third walks the queue (sample sort).
@@ -939,12 +797,16 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_small_kernel(
 // (one launch for everything above a wave's network, tried in round 3) saved 5 us on config 3 and ran config 5's
 // sort - 14 k tiles of ~1 900 keys - at 0.78 - 0.89 instead of 0.55 ms.  Beyond kSortCap: the sample sort
 // (48 KiB), a small persistent grid over the queue that sort_tiles_small_kernel filled.
+// large_count / large_list (ts_sort_tiles_above: no sort_tiles_small_kernel runs): this kernel queues the tiles
+// beyond kSortCap for the sample sort itself.
 __global__ __launch_bounds__(kThreads) void sort_tiles_mid_kernel(
     const int* __restrict__ tile_bins, const float* __restrict__ depths,
-    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted, int* __restrict__ large_count,
+    int* __restrict__ large_list) {
     __shared__ unsigned long long lk[kSortCap / 2];
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
     const int n = range.y - range.x;
+    if (n > kSortCap && large_count && threadIdx.x == 0) large_list[atomicAdd(large_count, 1)] = blockIdx.x;
     if (n <= kWaveSortMax || n > kSortCap) return;
     sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lk);
 }
@@ -1110,7 +972,28 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
                        dim3(kThreads), 0, s, (int)num_tiles, tile_bins, depths, bucket_ids,
                        gaussian_ids_sorted, counter, list);
     hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
-                       bucket_ids, gaussian_ids_sorted);
+                       bucket_ids, gaussian_ids_sorted, (int*)nullptr, (int*)nullptr);
+    const int grid = num_tiles < 768 ? num_tiles : 768;
+    hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
+                       bucket_ids, gaussian_ids_sorted, counter, list);
+    return launch_status();
+}
+
+int ts_sort_tiles_above(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
+                        const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
+                        int32_t* zeroed_counter, void* stream) {
+    if (num_tiles < 0) return TS_E_BADARG;
+    if (num_tiles == 0) return 0;
+    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted || !sort_ws) return TS_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* counter = zeroed_counter ? zeroed_counter : sort_ws;
+    int32_t* list = zeroed_counter ? sort_ws : sort_ws + 1;
+    if (!zeroed_counter) {
+        hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
+                       bucket_ids, gaussian_ids_sorted, counter, list);
     const int grid = num_tiles < 768 ? num_tiles : 768;
     hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
                        bucket_ids, gaussian_ids_sorted, counter, list);

@@ -100,16 +100,28 @@ int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
 int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
     TsRange range_("ts_frame_fwd_composite");
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
+    const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
+    if (planes && (f->channels != 4 || !f->out_depth)) return TS_E_BADARG;
+    // one wave per 16x16 tile on 16x16 lists: the compositing kernel sorts the lists of <= 1024 entries itself
+    const bool fused_sort = f->num_intersects > 0 && f->cam.wide_tiles == 0 &&
+                            !(f->flags & (TS_FRAME_SPLIT | TS_FRAME_NARROW_WAVES | TS_FRAME_SEPARATE_SORT));
     if (f->num_intersects > 0) {
         const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
         // the sorted-id buffer is dead until the sort: it carries the ids between the two scatter hops
         TS_TRY(ts_bin_scatter(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, f->bucket_ids,
                               (f->flags & TS_FRAME_DIRECT_SCATTER) ? nullptr : f->gaussian_ids_sorted, stream));
-        TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
-                             f->bin_ws, f->bin_ws + (ts_bin_ws_ints(f->n, num_tiles(f)) - 1), stream));
+        int32_t* counter = f->bin_ws + (ts_bin_ws_ints(f->n, num_tiles(f)) - 1);
+        if (fused_sort)
+            TS_TRY(ts_sort_tiles_above(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
+                                       f->bin_ws, counter, stream));
+        else
+            TS_TRY(ts_sort_tiles(num_tiles(f), f->tile_bins, f->depths, f->bucket_ids, f->gaussian_ids_sorted,
+                                 f->bin_ws, counter, stream));
     }
-    const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
-    if (planes && (f->channels != 4 || !f->out_depth)) return TS_E_BADARG;
+    if (fused_sort)
+        return ts_raster_fwd_sort(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->bucket_ids, f->depths,
+                                  f->gaussian_ids_sorted, f->splats, f->background, f->out_img,
+                                  planes ? f->out_depth : nullptr, f->final_Ts, f->final_index, f->clamp_mask, stream);
     return ts_raster_fwd_planes(f->channels, raster_flags(f), &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
                                 f->background, f->out_img, planes ? f->out_depth : nullptr, f->final_Ts,
                                 f->final_index, f->clamp_mask, stream);

@@ -43,6 +43,7 @@
 #include "splat_math.h"
 
 namespace {
+#include "sort_network.h"
 
 // tuning knobs (overridable with -D for the ablation runs of tools/time_raster.py)
 #ifndef TS_FWD_MIN_WAVES
@@ -294,10 +295,15 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 // keeps a wave of its own, which walks the list of the wide tile it belongs to and drops the Gaussians
 // whose tile box does not contain it - binning and sorting at the wide tiles' price, compositing at the
 // register footprint of four pixels per lane.
-template <int CH, bool SPLIT, int NBX, bool WL>
+// SORT (one wave per 16x16 tile on 16x16 lists only): the wave first sorts its tile's list itself - bucket_ids ->
+// ids_rw, the network of sort_tiles_small_kernel - when the list has at most kWaveSortMax entries (longer lists were
+// sorted by ts_sort_tiles_above before this launch).  The per-tile sort on its own is latency-bound (VALU 40 %, LDS
+// 59 % busy on config 3); inside this VALU-bound kernel its stalls are filled by other tiles' compositing.
+template <int CH, bool SPLIT, int NBX, bool WL, bool SORT = false>
 __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
-    const int* __restrict__ ids_sorted, const float4* __restrict__ splats,
+    const int* __restrict__ ids_sorted, const int* __restrict__ bucket_ids, const float* __restrict__ depths,
+    int* ids_rw, const float4* __restrict__ splats,
     const float* __restrict__ background, float* __restrict__ out_img, float* __restrict__ out_depth,
     float* __restrict__ final_Ts, int* __restrict__ final_index, const int clamp_rgb,
     unsigned char* __restrict__ clamp_mask) {
@@ -341,6 +347,24 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
 
+    if (SORT) {
+        static_assert(!SORT || (!SPLIT && !WL && NBX == 2), "one wave per list");
+        const int n = range.y - range.x;
+        if (n > 0 && n <= kWaveSortMax) {
+            const int* g = bucket_ids + range.x;
+            int* out = ids_rw + range.x;
+            if (n <= 64) sort_tile_wave<1>(g, depths, out, n, lane);
+            else if (n <= 128) sort_tile_wave<2>(g, depths, out, n, lane);
+            else if (n <= 256) sort_tile_wave<4>(g, depths, out, n, lane);
+            else if (n <= 512) sort_tile_wave<8>(g, depths, out, n, lane);
+            else sort_tile_wave<16>(g, depths, out, n, lane);
+            // the list is read back below by other lanes of this wave: stores done before the loads are issued
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    // (SORT: reads go through the pointer the sort wrote through; ids_sorted is the same buffer)
+    const int* ids = SORT ? ids_rw : ids_sorted;
+
     // Software pipeline over 64-entry chunks: the id of chunk c+2 and the packed record of chunk
     // c+1 are in flight while chunk c is composited (two dependent gathers = ~2 us of latency
     // that a wave with ~3 co-resident waves per SIMD cannot hide otherwise).
@@ -348,10 +372,10 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
     int id_next = 0;
     if (range.x + lane < range.y) {
-        const int g = ids_sorted[range.x + lane];
+        const int g = ids[range.x + lane];
         n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
     }
-    if (range.x + 64 + lane < range.y) id_next = ids_sorted[range.x + 64 + lane];
+    if (range.x + 64 + lane < range.y) id_next = ids[range.x + 64 + lane];
 
     for (int base = range.x; base < range.y && live != 0; base += 64) {
         const int i = base + lane;
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             const int g = id_next;
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
-        if (i + 128 < range.y) id_next = ids_sorted[i + 128];
+        if (i + 128 < range.y) id_next = ids[i + 128];
         {   // rectangle of the still-unfinished pixels of each block: saturated pixels need no more
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
             bool sel[NB];
@@ -963,7 +987,8 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
 #define TS_LAUNCH_FWD(C, S, X, L)                                                                  \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
-                       tile_bins, gaussian_ids_sorted, sp, background, out_img, out_depth, final_Ts, \
+                       tile_bins, gaussian_ids_sorted, (const int*)nullptr, (const float*)nullptr,   \
+                       (int*)nullptr, sp, background, out_img, out_depth, final_Ts,                  \
                        final_index, clamp, clamp ? clamp_mask : nullptr)
 #define TS_LAUNCH_FWD_X(C, S)                                                                      \
     do {                                                                                           \
@@ -975,6 +1000,33 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     else { if (split) TS_LAUNCH_FWD_X(4, true); else TS_LAUNCH_FWD_X(4, false); }
 #undef TS_LAUNCH_FWD_X
 #undef TS_LAUNCH_FWD
+    return launch_status();
+}
+
+int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
+                       const int32_t* bucket_ids, const float* depths, int32_t* gaussian_ids_sorted,
+                       const float* splats, const float* background, float* out_img, float* out_depth,
+                       float* final_Ts, int32_t* final_index, uint8_t* clamp_mask, void* stream) {
+    if (!cam || (channels != 3 && channels != 4) || (out_depth && channels != 4)) return TS_E_BADARG;
+    // one wave per 16x16 tile on 16x16 lists: the only mapping in which a list belongs to exactly one wave
+    if (cam->wide_tiles != 0 || (flags & (TS_RASTER_SPLIT_BLOCKS | TS_RASTER_NARROW_WAVES))) return TS_E_BADARG;
+    const int nt = ts_num_tiles(cam);
+    if (nt <= 0) return 0;
+    if (!tile_bins || !background || !out_img || (!final_Ts != !final_index) || !bucket_ids || !depths ||
+        !gaussian_ids_sorted)
+        return TS_E_BADARG;
+    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);         // see xcd_tile_group
+    hipStream_t s = (hipStream_t)stream;
+    const float4* sp = reinterpret_cast<const float4*>(splats);
+    const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
+    if (channels == 3)
+        hipLaunchKernelGGL((raster_fwd_kernel<3, false, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,
+                           tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background,
+                           out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr);
+    else
+        hipLaunchKernelGGL((raster_fwd_kernel<4, false, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,
+                           tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background,
+                           out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr);
     return launch_status();
 }
 

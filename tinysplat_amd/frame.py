@@ -121,6 +121,9 @@ STRIPE_SPARSE = os.environ.get("TS_STRIPE_SPARSE", "1") != "0"
 
 # ts_bin_scatter in two coalesced hops through the (still unused) sorted-id buffer; TS_TWO_HOP_SCATTER=0: one hop
 TWO_HOP_SCATTER = os.environ.get("TS_TWO_HOP_SCATTER", "1") != "0"
+# one wave per 16x16 tile on 16x16 lists: the forward compositing kernel sorts the lists of <= 1024 entries itself
+# (ts_raster_fwd_sort); TS_INLINE_SORT=0: the sort as a phase of its own (TS_FRAME_SEPARATE_SORT)
+INLINE_SORT = os.environ.get("TS_INLINE_SORT", "1") != "0"
 
 DIRECT_GRADS = os.environ.get("TS_DIRECT_GRADS", "1") != "0"      # A/B switch (see _RenderFrame.backward)
 
@@ -246,7 +249,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
         stripe = STRIPE_SPARSE and cam.tile_rows < cam.tile_bounds_y
         fr.flags = ((1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
-                    | (0 if TWO_HOP_SCATTER else 32) | (64 if F.planes else 0))
+                    | (0 if TWO_HOP_SCATTER else 32) | (64 if F.planes else 0) | (0 if INLINE_SORT else 128))
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -391,11 +394,18 @@ def _steps_prepare(lib, fr, s):
 def _steps_composite(lib, fr, s):
     tight = fr.splats if fr.flags & 1 else None
     nt = int(lib.ts_num_tiles(ctypes.byref(fr.cam)))
+    fused = fr.num_intersects > 0 and fr.cam.wide_tiles == 0 and not fr.flags & (2 | 8 | 128)
     if fr.num_intersects > 0:
         _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
               fr.bucket_ids, None if fr.flags & 32 else fr.gaussian_ids_sorted, s)
-        _call("ts_sort_tiles", lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths, fr.bucket_ids,
-              fr.gaussian_ids_sorted, fr.bin_ws, fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
+        _call("ts_sort_tiles", lib.ts_sort_tiles_above if fused else lib.ts_sort_tiles, nt, fr.tile_bins, fr.depths,
+              fr.bucket_ids, fr.gaussian_ids_sorted, fr.bin_ws,
+              fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
+    if fused:
+        _call("ts_raster_fwd", lib.ts_raster_fwd_sort, fr.channels, 2, fr.cam, fr.tile_bins, fr.bucket_ids, fr.depths,
+              fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.out_depth if fr.flags & 64 else None,
+              fr.final_Ts, fr.final_index, fr.clamp_mask, s)
+        return
     _call("ts_raster_fwd", lib.ts_raster_fwd_planes, fr.channels, 2 | (4 if fr.flags & 2 else 0) | (fr.flags & 8), fr.cam,
           fr.tile_bins, fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img,
           fr.out_depth if fr.flags & 64 else None, fr.final_Ts, fr.final_index, fr.clamp_mask, s)

@@ -239,8 +239,8 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam_h
 
 /* ABI 5: ts_raster_fwd_planes with the per-tile sort of the lists of <= 1024 entries inside (bucket_ids[I] ->
  * gaussian_ids_sorted[I], which ts_raster_bwd reads later; ts_sort_tiles_above must have run for the longer lists).
- * Only for one wave per 16x16 tile on 16x16 lists (cam->wide_tiles = 0, no TS_RASTER_SPLIT_BLOCKS /
- * TS_RASTER_NARROW_WAVES: TS_E_BADARG otherwise).  Same image, same sorted lists; the latency-bound sort overlaps
+ * Only on 16x16 lists (cam->wide_tiles = 0, no TS_RASTER_NARROW_WAVES: TS_E_BADARG otherwise), with one wave per tile
+ * or - TS_RASTER_SPLIT_BLOCKS - one workgroup per tile (its first wave sorts).  Same image, same sorted lists; the latency-bound sort overlaps
  * the VALU-bound compositing of other tiles instead of running as a phase of its own. */
 int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam_host, const int32_t* tile_bins,
                        const int32_t* bucket_ids, const float* depths, int32_t* gaussian_ids_sorted,

@@ -98,7 +98,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_raster_bwd(3, 0, 1, cam, *([None] * 11), None) == -1                         # no buffers at all
     assert lib.ts_raster_bwd_planes(4, 0, 0, cam, *([None] * 8), 1, *([None] * 5)) == 0        # nothing listed
     # the compositing launch that sorts its lists: one wave per 16x16 tile on 16x16 lists only
-    assert lib.ts_raster_fwd_sort(3, 4, cam, *([None] * 12)) == -1                             # TS_RASTER_SPLIT_BLOCKS
+    assert lib.ts_raster_fwd_sort(3, 8, cam, *([None] * 12)) == -1                             # TS_RASTER_NARROW_WAVES
     assert lib.ts_raster_fwd_sort(3, 0, wide, *([None] * 12)) == -1                            # 32x16 lists
     assert lib.ts_raster_fwd_sort(3, 0, cam, *([None] * 12)) == -1                             # no buffers
     assert lib.ts_sort_tiles_above(-1, *([None] * 7)) == -1 and lib.ts_sort_tiles_above(0, *([None] * 7)) == 0

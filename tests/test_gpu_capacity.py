@@ -108,17 +108,20 @@ def test_two_hop_scatter_fills_the_buckets_of_the_direct_scatter(n, sh, w, h, mu
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n,sh,w,h,mult,depth", [(60000, 2, 640, 360, 2.0, True), (300000, 1, 1920, 1080, 1.0, False),
                                                  (50000, 0, 333, 211, 14.0, True), (3000, 3, 1280, 720, 1.0, False)])
-def test_the_sort_inside_the_compositing_launch_changes_nothing(n, sh, w, h, mult, depth, monkeypatch):
+def test_the_sort_inside_the_compositing_launch_changes_nothing(n, sh, w, h, mult, depth, split, monkeypatch):
     """ts_raster_fwd_sort (one wave per 16x16 tile on 16x16 lists): the forward compositing kernel sorts the lists
     of <= 1024 entries itself, ts_sort_tiles_above the longer ones (scale 14: lists of several thousand entries,
-    workgroup sort and sample sort).  Sorted lists, image and gradients are bit for bit those of the separate sort."""
+    workgroup sort and sample sort).  Sorted lists, image and gradients are bit for bit those of the separate sort,
+    with one wave per tile and with the split mapping (small stripes of a multi-GPU frame)."""
     model, cam = make_scene(n, sh, w, h, seed=31, scale_mult=mult)
     model = model.to(DEV).requires_grad_(True)
     w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
     monkeypatch.setattr(frame, "WIDE_TILES", 0)
-    monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 0)             # one wave per tile also on the small images
+    # one wave per tile (the wave sorts its list) or four waves per tile (wave 0 of the workgroup sorts)
+    monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 1 << 30 if split else 0)
     res = []
     for inline in (False, True):
         monkeypatch.setattr(frame, "INLINE_SORT", inline)

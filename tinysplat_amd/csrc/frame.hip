@@ -102,9 +102,10 @@ int ts_frame_fwd_composite(const ts_frame* f, void* stream) {
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
     const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
     if (planes && (f->channels != 4 || !f->out_depth)) return TS_E_BADARG;
-    // one wave per 16x16 tile on 16x16 lists: the compositing kernel sorts the lists of <= 1024 entries itself
+    // 16x16 lists, one wave or (split) one workgroup per tile: the compositing kernel sorts the lists of <= 1024
+    // entries itself
     const bool fused_sort = f->num_intersects > 0 && f->cam.wide_tiles == 0 &&
-                            !(f->flags & (TS_FRAME_SPLIT | TS_FRAME_NARROW_WAVES | TS_FRAME_SEPARATE_SORT));
+                            !(f->flags & (TS_FRAME_NARROW_WAVES | TS_FRAME_SEPARATE_SORT));
     if (f->num_intersects > 0) {
         const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
         // the sorted-id buffer is dead until the sort: it carries the ids between the two scatter hops

@@ -348,9 +348,11 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
 
     if (SORT) {
-        static_assert(!SORT || (!SPLIT && !WL && NBX == 2), "one wave per list");
+        // one list per wave, or (SPLIT) per workgroup: its four waves composite the four 8x8 blocks of ONE tile,
+        // wave 0 sorts the list and the others wait at the barrier
+        static_assert(!SORT || (!WL && NBX == 2), "16x16 lists");
         const int n = range.y - range.x;
-        if (n > 0 && n <= kWaveSortMax) {
+        if (n > 0 && n <= kWaveSortMax && (!SPLIT || wave == 0)) {
             const int* g = bucket_ids + range.x;
             int* out = ids_rw + range.x;
             if (n <= 64) sort_tile_wave<1>(g, depths, out, n, lane);
@@ -358,9 +360,10 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
             else if (n <= 256) sort_tile_wave<4>(g, depths, out, n, lane);
             else if (n <= 512) sort_tile_wave<8>(g, depths, out, n, lane);
             else sort_tile_wave<16>(g, depths, out, n, lane);
-            // the list is read back below by other lanes of this wave: stores done before the loads are issued
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
+        // the list is read back below by other lanes (SPLIT: other waves): stores done before the loads are issued
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (SPLIT) __syncthreads();       // units = 4 * tiles: the four waves of a workgroup are valid together
     }
     // (SORT: reads go through the pointer the sort wrote through; ids_sorted is the same buffer)
     const int* ids = SORT ? ids_rw : ids_sorted;
@@ -1008,25 +1011,26 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
                        const float* splats, const float* background, float* out_img, float* out_depth,
                        float* final_Ts, int32_t* final_index, uint8_t* clamp_mask, void* stream) {
     if (!cam || (channels != 3 && channels != 4) || (out_depth && channels != 4)) return TS_E_BADARG;
-    // one wave per 16x16 tile on 16x16 lists: the only mapping in which a list belongs to exactly one wave
-    if (cam->wide_tiles != 0 || (flags & (TS_RASTER_SPLIT_BLOCKS | TS_RASTER_NARROW_WAVES))) return TS_E_BADARG;
+    // 16x16 lists, one wave (or, split, one workgroup) per tile: the mappings in which a list has one owner
+    if (cam->wide_tiles != 0 || (flags & TS_RASTER_NARROW_WAVES)) return TS_E_BADARG;
     const int nt = ts_num_tiles(cam);
     if (nt <= 0) return 0;
     if (!tile_bins || !background || !out_img || (!final_Ts != !final_index) || !bucket_ids || !depths ||
         !gaussian_ids_sorted)
         return TS_E_BADARG;
-    const int grid = 8 * (((nt + kWaves - 1) / kWaves + 7) / 8);         // see xcd_tile_group
+    const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    const int units = split ? 4 * nt : nt;
+    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-    if (channels == 3)
-        hipLaunchKernelGGL((raster_fwd_kernel<3, false, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background,
-                           out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr);
-    else
-        hipLaunchKernelGGL((raster_fwd_kernel<4, false, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,
-                           tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background,
-                           out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr);
+#define TS_LAUNCH_FWD_SORT(C, S)                                                                               \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,   \
+                       tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background, \
+                       out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr)
+    if (channels == 3) { if (split) TS_LAUNCH_FWD_SORT(3, true); else TS_LAUNCH_FWD_SORT(3, false); }
+    else { if (split) TS_LAUNCH_FWD_SORT(4, true); else TS_LAUNCH_FWD_SORT(4, false); }
+#undef TS_LAUNCH_FWD_SORT
     return launch_status();
 }
 

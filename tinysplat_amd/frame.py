@@ -394,7 +394,7 @@ def _steps_prepare(lib, fr, s):
 def _steps_composite(lib, fr, s):
     tight = fr.splats if fr.flags & 1 else None
     nt = int(lib.ts_num_tiles(ctypes.byref(fr.cam)))
-    fused = fr.num_intersects > 0 and fr.cam.wide_tiles == 0 and not fr.flags & (2 | 8 | 128)
+    fused = fr.num_intersects > 0 and fr.cam.wide_tiles == 0 and not fr.flags & (8 | 128)
     if fr.num_intersects > 0:
         _call("ts_bin_scatter", lib.ts_bin_scatter, fr.n, fr.xys, fr.radii, tight, fr.cam, fr.bin_ws,
               fr.bucket_ids, None if fr.flags & 32 else fr.gaussian_ids_sorted, s)
@@ -402,7 +402,8 @@ def _steps_composite(lib, fr, s):
               fr.bucket_ids, fr.gaussian_ids_sorted, fr.bin_ws,
               fr.bin_ws + 4 * (int(lib.ts_bin_ws_ints(fr.n, nt)) - 1), s)
     if fused:
-        _call("ts_raster_fwd", lib.ts_raster_fwd_sort, fr.channels, 2, fr.cam, fr.tile_bins, fr.bucket_ids, fr.depths,
+        _call("ts_raster_fwd", lib.ts_raster_fwd_sort, fr.channels, 2 | (4 if fr.flags & 2 else 0), fr.cam, fr.tile_bins,
+              fr.bucket_ids, fr.depths,
               fr.gaussian_ids_sorted, fr.splats, fr.background, fr.out_img, fr.out_depth if fr.flags & 64 else None,
               fr.final_Ts, fr.final_index, fr.clamp_mask, s)
         return

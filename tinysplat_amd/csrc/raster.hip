@@ -73,6 +73,94 @@ __device__ unsigned long long ts_stats[8];
 #define TS_STAT(i, v) ((void)0)
 #endif
 
+// TS_TIMELINE=1 (developer build, tools/raster_timeline.py): every wave of the two compositing kernels records
+// {start, end} on the 100 MHz constant clock, its hardware slot (HW_ID | XCC_ID << 16) and its list length.
+#ifndef TS_TIMELINE
+#define TS_TIMELINE 0
+#endif
+#if TS_TIMELINE
+constexpr int kTimelineMax = 1 << 17;
+constexpr int kTimelineRow = 12;
+__device__ unsigned long long ts_timeline[2][kTimelineMax][kTimelineRow];
+struct WaveClock {
+    unsigned long long t0, c0;
+    unsigned long long seg[4] = {0ull, 0ull, 0ull, 0ull};     // shader-clock ticks per segment (TS_SEG_*)
+    unsigned int work[3] = {0u, 0u, 0u};                       // staged entries, block bodies, rows flushed
+    int which, unit, n;
+    __device__ WaveClock(int which_, int unit_, int n_) : which(which_), unit(unit_), n(n_) {
+        t0 = __builtin_amdgcn_s_memrealtime();
+        c0 = __builtin_amdgcn_s_memtime();
+    }
+    __device__ ~WaveClock() {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((threadIdx.x & 63) == 0 && unit < kTimelineMax) {
+            ts_timeline[which][unit][0] = t0;
+            ts_timeline[which][unit][1] = t1;
+            ts_timeline[which][unit][2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            ts_timeline[which][unit][3] = (unsigned long long)n;
+            for (int i = 0; i < 4; ++i) ts_timeline[which][unit][4 + i] = seg[i];
+            ts_timeline[which][unit][8] = c1 - c0;
+            for (int i = 0; i < 3; ++i) ts_timeline[which][unit][9 + i] = work[i];
+        }
+    }
+};
+#define TS_WAVE_CLOCK(which, unit, n) WaveClock ts_wave_clock_(which, unit, n)
+#define TS_SEG_PARAM , unsigned long long (&ts_seg_)[4], unsigned int (&ts_work_)[3]
+#define TS_SEG_ARG , ts_wave_clock_.seg, ts_wave_clock_.work
+#define TS_WORK(i, v) ts_work_[i] += (unsigned int)(v)
+#define TS_SEG_T0(var)                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long var = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_sched_barrier(0)
+#define TS_SEG_ADD(segs, i, var)                                     \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    segs[i] += __builtin_amdgcn_s_memtime() - var;                   \
+    __builtin_amdgcn_sched_barrier(0)
+#else
+#define TS_WAVE_CLOCK(which, unit, n) ((void)0)
+#define TS_SEG_PARAM
+#define TS_SEG_ARG
+#define TS_WORK(i, v) ((void)0)
+#define TS_SEG_T0(var) ((void)0)
+#define TS_SEG_ADD(segs, i, var) ((void)0)
+#endif
+
+// TS_LDS_PAD=<bytes> (developer build): extra LDS per workgroup, to pin the number of resident waves per SIMD
+// (a workgroup's kWaves waves sit on different SIMDs, so waves per SIMD = workgroups per CU = 160 KiB / LDS).
+#ifndef TS_LDS_PAD
+#define TS_LDS_PAD 0
+#endif
+#if TS_LDS_PAD
+#define TS_LDS_PAD_DECL() __shared__ int lds_pad_[TS_LDS_PAD / 4]; if (threadIdx.x == 9999) lds_pad_[blockIdx.x & 7] = 1; asm volatile("" : : "v"(&lds_pad_[0]) : "memory")
+#else
+#define TS_LDS_PAD_DECL() ((void)0)
+#endif
+
+// TS_LDS_DMA: the packed records of the NEXT chunk travel from global memory straight into LDS
+// (global_load_lds_dwordx4: 16 bytes per lane to base + lane * 16) instead of through twelve VGPRs that stay live
+// across the whole chunk - the registers that kept raster_bwd at four and raster_fwd at five waves per SIMD.
+#ifndef TS_LDS_DMA
+#define TS_LDS_DMA 0
+#endif
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma_record(const float4* __restrict__ splats, int g, float4* raw) {
+    const float4* p = splats + 3 * (size_t)g;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)raw, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p + 1), (lds_ptr_t)(raw + 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p + 2), (lds_ptr_t)(raw + 128), 16, 0, 0);
+}
+#define TS_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define TS_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+#ifndef TS_SELECT_SGPR
+#define TS_SELECT_SGPR 1
+#endif
+
 #ifndef TS_NT_ROWS
 #define TS_NT_ROWS 0                    // gradient rows written (raster_bwd) / read (reduce_partials) non-temporally
 #endif
@@ -248,9 +336,11 @@ using mask64 = unsigned long long;
 template <int CH, bool GENERAL, int NBX>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
-                                          float (&acc)[2 * NBX][CH]) {
+                                          float (&acc)[2 * NBX][CH] TS_SEG_PARAM) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
+    TS_WORK(0, cnt);
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
+        TS_SEG_T0(tseg_a);
         const float4 r0 = lds[3 * j], r1 = lds[3 * j + 1], r2 = lds[3 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
         const int idx = __float_as_int(r2.z);
@@ -258,6 +348,12 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
         float col[CH];
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
+#if TS_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        TS_SEG_ADD(ts_seg_, 1, tseg_a);
+        TS_SEG_T0(tseg_b);
+        TS_WORK(1, __popc(bm & ((1 << (2 * NBX)) - 1)));
 #pragma unroll
         for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
@@ -265,23 +361,27 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k % NBX], r0.y - fpy[k / NBX]);
             float a = __builtin_amdgcn_exp2f(-sgl);
-            bool ok = a >= ts::kAlphaMin;
+            // Every decision below is ONE compare feeding ONE select, with no scalar mask arithmetic in between:
+            // a v_cmp -> s_and / s_xor -> v_cndmask chain costs a wave 36 cycles and a select on a vcc that the
+            // scalar unit wrote 19 (tools/micro/lat_bench.hip), a compare -> select pair 11.
+            float ae = a >= ts::kAlphaMin ? a : 0.0f;
             if (GENERAL) {
-                a = fminf(ts::kAlphaMax, a);
-                ok = ok & (sgl >= neg_lo);                            // sigma >= 0
+                ae = fminf(ts::kAlphaMax, ae);
+                ae = sgl >= neg_lo ? ae : 0.0f;                       // sigma >= 0
             }
-            // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, so
-            // either `stop` fires and -|T| puts T back, or ae = 0 and nT = T; vis is 0 both ways.
-            const float ae = ok ? a : 0.0f;
+            // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, `stop` fires and
+            // -|T| puts T back; vis is 0.  An unfinished pixel always has T > kTEps (it would have stopped
+            // otherwise), so with ae = 0 (Gaussian below 1/255) nT = T and `stop` cannot fire: no `& ok` needed.
             const float nT = __builtin_fmaf(-ae, T[k], T[k]);
-            const bool stop = (nT <= ts::kTEps) & ok;
-            const float Tn = stop ? -__builtin_fabsf(T[k]) : nT;   // the stopping Gaussian is not composited
+            const float Tn = nT <= ts::kTEps ? -__builtin_fabsf(T[k]) : nT;   // the stopping Gaussian is not composited
             const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
-            fidx[k] = (ok & !stop) ? idx : fidx[k];
+            // composited <=> alpha >= 1/255 and not stopped <=> vis = alpha T > 0 (alpha >= 1/255, T > 1e-4)
+            fidx[k] = vis > 0.0f ? idx : fidx[k];
             T[k] = Tn;
         }
+        TS_SEG_ADD(ts_seg_, 2, tseg_b);
     }
 }
 
@@ -308,8 +408,10 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     float* __restrict__ final_Ts, int* __restrict__ final_index, const int clamp_rgb,
     unsigned char* __restrict__ clamp_mask) {
     constexpr int NB = 2 * NBX;
+    TS_LDS_PAD_DECL();
     __shared__ float4 lds_all[kWaves][64 * 3];
     __shared__ float4 rect_all[kWaves][NB];
+    __shared__ float4 raw_all[TS_LDS_DMA ? kWaves : 1][3 * 64];      // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? NB * num_tiles : num_tiles;
     const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
@@ -346,6 +448,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
 
     const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
+    TS_WAVE_CLOCK(0, unit, range.y - range.x);
 
     if (SORT) {
         // one list per wave, or (SPLIT) per workgroup: its four waves composite the four 8x8 blocks of ONE tile,
@@ -372,22 +475,38 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     // c+1 are in flight while chunk c is composited (two dependent gathers = ~2 us of latency
     // that a wave with ~3 co-resident waves per SIMD cannot hide otherwise).
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* raw = raw_all[TS_LDS_DMA ? wave : 0];
+#if !TS_LDS_DMA
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
+#endif
     int id_next = 0;
     if (range.x + lane < range.y) {
         const int g = ids[range.x + lane];
+#if TS_LDS_DMA
+        dma_record(splats, g, raw);
+#else
         n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+#endif
     }
     if (range.x + 64 + lane < range.y) id_next = ids[range.x + 64 + lane];
 
     for (int base = range.x; base < range.y && live != 0; base += 64) {
+        TS_SEG_T0(tseg_p);
         const int i = base + lane;
         const bool have = i < range.y;
+#if TS_LDS_DMA
+        TS_DMA_WAIT();                               // this chunk's records have landed (and id_next has arrived)
+        const float4 q0 = have ? raw[lane] : zero4, q1 = have ? raw[64 + lane] : zero4,
+                     q2 = have ? raw[128 + lane] : zero4;
+        TS_LDS_WAIT();                               // read out before the next chunk's records may overwrite them
+        if (i + 64 < range.y) dma_record(splats, id_next, raw);
+#else
         const float4 q0 = n0, q1 = n1, q2 = n2;
         if (i + 64 < range.y) {
             const int g = id_next;
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
+#endif
         if (i + 128 < range.y) id_next = ids[i + 128];
         {   // rectangle of the still-unfinished pixels of each block: saturated pixels need no more
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
@@ -413,10 +532,11 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         TS_STAT(0, cnt);
         // bit NB of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
         // once per chunk so that the common case runs a loop without those tests
+        TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
-            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc);
+            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc TS_SEG_ARG);
         else
-            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc);
+            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc TS_SEG_ARG);
         TS_WAVE_SYNC();
     }
 
@@ -611,18 +731,26 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
 //   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
 // Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
 // (ra = 1, fac = 0, v_sig = 0) and changes nothing.
+// Replays the `cnt` staged Gaussians of one chunk back to front (backward).
+//   per pixel and block k: T = transmittance behind the Gaussian being replayed, R = T_final *
+//   (v_alpha - bg . v_out) - sum over the Gaussians already replayed of fac * (colour . v_out),
+//   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
+// Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
+// (ra = 1, fac = 0, v_sig = 0) and changes nothing.
 template <int CH, bool GENERAL, int NBX>
 __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], float (&R)[2 * NBX],
                                           const float (&vo)[2 * NBX][CH], const int (&fidx)[2 * NBX],
                                           float (&acc)[6 + CH], long long num_isects,
                                           float* __restrict__ partials,
-                                          unsigned char* __restrict__ row_flags, int lane) {
+                                          unsigned char* __restrict__ row_flags, int lane TS_SEG_PARAM) {
     // Every fused multiply-add below is written out; implicit contraction is switched off so that the
     // GENERAL and the lean instantiation round identically (otherwise `acc[0] += -am * v_a` fuses
     // in one and not in the other, and a gradient would depend on which chunk an entry lands in).
 #pragma clang fp contract(off)
+    TS_WORK(0, cnt);
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
+        TS_SEG_T0(tseg_a);
         const float4 r0 = lds[4 * j], r1 = lds[4 * j + 1], r2 = lds[4 * j + 2];
         const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(lds[4 * j + 3].x));
         const int idx = __float_as_int(r2.z);
@@ -630,6 +758,12 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         float col[CH];
         col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
         if (CH == 4) col[CH - 1] = r2.y;
+#if TS_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (so that the record read is timed on its own)
+#endif
+        TS_SEG_ADD(ts_seg_, 1, tseg_a);
+        TS_SEG_T0(tseg_b);
+        TS_WORK(1, __popc(bm & ((1 << (2 * NBX)) - 1)));
 
         int any = 0;
 #pragma unroll
@@ -649,7 +783,11 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             TS_STAT(4, 1);
             TS_STAT(6, __popcll(validm));
             any = 1;
-            const float am = TS_LANE(validm) ? a : 0.0f;
+            // the select takes its mask from an ordinary SGPR pair: the VOP2 form on a vcc that the SCALAR unit
+            // wrote (the s_and of the two ballots) costs a wave 19 cycles instead of 5 (tools/micro/lat_bench.hip)
+            float am;
+            if (TS_SELECT_SGPR) asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(am) : "v"(a), "s"(validm));
+            else am = TS_LANE(validm) ? a : 0.0f;
             const float ra = __builtin_amdgcn_rcpf(1.0f - am);
             const float Tk = T[k] * ra;                 // transmittance in front of the Gaussian
             const float fac = am * Tk;
@@ -676,8 +814,11 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         // (results in fresh registers) and pays for it with 10-17 register copies per entry on the
         // joining paths; kept opaque, all four bodies accumulate in place and the flush reads acc.
         asm volatile("" : "+s"(any));
+        TS_SEG_ADD(ts_seg_, 2, tseg_b);
+        TS_SEG_T0(tseg_c);
         if (any) {
             TS_STAT(5, 1);
+            TS_WORK(2, 1);
             flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
                           partials, row_flags, lane);
             // zero the accumulators two at a time (v_mov_b64 on a register pair)
@@ -689,6 +830,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             }
             if ((6 + CH) & 1) acc[5 + CH] = 0.0f;
         }
+        TS_SEG_ADD(ts_seg_, 3, tseg_c);
     }
 }
 
@@ -702,8 +844,10 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float* __restrict__ v_out_alpha, const unsigned char* __restrict__ clamp_mask,
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     constexpr int NB = 2 * NBX;
+    TS_LDS_PAD_DECL();
     __shared__ float4 lds_all[kWaves][64 * 4];
     __shared__ float4 rect_all[kWaves][NB];
+    __shared__ float4 raw_all[TS_LDS_DMA ? kWaves : 1][3 * 64];      // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? NB * num_tiles : num_tiles;
     const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
@@ -716,6 +860,7 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
     if (range.y <= range.x) return;
+    TS_WAVE_CLOCK(1, unit, range.y - range.x);
     float4* lds = lds_all[wave];
     const int px0 = tx * (8 * NBX) + (lane & 7), py0 = ty * 16 + (lane >> 3);
     // sample positions of the lane's pixel in the block columns / the upper and lower block row
@@ -778,22 +923,38 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
 
     // same software pipeline as the forward kernel, walking the list back to front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* raw = raw_all[TS_LDS_DMA ? wave : 0];
+#if !TS_LDS_DMA
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
+#endif
     int id_next = 0;
     if (last - lane >= range.x) {
         const int g = ids_sorted[last - lane];
+#if TS_LDS_DMA
+        dma_record(splats, g, raw);
+#else
         n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+#endif
     }
     if (last - 64 - lane >= range.x) id_next = ids_sorted[last - 64 - lane];
 
     for (int hi = last; hi >= range.x; hi -= 64) {
+        TS_SEG_T0(tseg_p);
         const int i = hi - lane;
         const bool have = i >= range.x;
+#if TS_LDS_DMA
+        TS_DMA_WAIT();                               // this chunk's records have landed (and id_next has arrived)
+        const float4 q0 = have ? raw[lane] : zero4, q1 = have ? raw[64 + lane] : zero4,
+                     q2 = have ? raw[128 + lane] : zero4;
+        TS_LDS_WAIT();                               // read out before the next chunk's records may overwrite them
+        if (i - 64 >= range.x) dma_record(splats, id_next, raw);
+#else
         const float4 q0 = n0, q1 = n1, q2 = n2;
         if (i - 64 >= range.x) {
             const int g = id_next;
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
+#endif
         if (i - 128 >= range.x) id_next = ids_sorted[i - 128];
         int blocks;
         {   // rectangle of the pixels whose forward list reaches into this chunk (fidx >= chunk low)
@@ -831,12 +992,13 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
         TS_WAVE_SYNC();
         TS_STAT(2, cnt);
         TS_STAT(7, min(64, hi - range.x + 1));
+        TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
             bwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
-                                     row_flags, lane);
+                                     row_flags, lane TS_SEG_ARG);
         else
             bwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
-                                      row_flags, lane);
+                                      row_flags, lane TS_SEG_ARG);
         TS_WAVE_SYNC();
     }
 }
@@ -952,6 +1114,14 @@ inline int launch_status() { return (int)hipGetLastError(); }
 }  // namespace
 
 extern "C" {
+
+#if TS_TIMELINE
+int ts_debug_timeline(unsigned long long* out_host, int which, int count) {   // developer builds only (not part of the ABI)
+    if (which < 0 || which > 1 || count < 0 || count > kTimelineMax) return TS_E_BADARG;
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ts_timeline), (size_t)count * kTimelineRow * 8,
+                                    (size_t)which * kTimelineMax * kTimelineRow * 8);
+}
+#endif
 
 #if TS_STATS
 int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer builds only (not part of the ABI)

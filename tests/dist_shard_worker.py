@@ -74,3 +74,21 @@ def run(rank, world, port, out_dir, n, sh, w, h):
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_preflight(rank, world, port, out_dir):
+    """Worker of test_preflight_agrees_over_gloo: the exchange preflight bench.py runs before its first frame, and
+    the collective timer around a count exchange (CPU: calls are counted, nothing is event-timed)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tinysplat_amd._comm import collective_timer, preflight_sharded_exchange
+        from tinysplat_amd.sharded import DistExchange
+        ok, err = preflight_sharded_exchange(torch.device("cpu"))
+        collective_timer.start()
+        send_counts, recv_counts = DistExchange().counts(torch.tensor([rank + 1] * world, dtype=torch.int32))
+        ms, calls = collective_timer.stop()
+        torch.save({"ok": ok, "err": err, "send": send_counts, "recv": recv_counts, "ms": ms, "calls": calls},
+                   Path(out_dir) / f"pre{rank}.pt")
+    finally:
+        dist.destroy_process_group()

@@ -93,9 +93,17 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--single-device", "--backend",
                         "gloo", "--config", "2", "--depth", "--steps", "3", "--warmup", "1", "--profile-steps", "1",
+                        "--shard-mode", "both",
                         "--no-cpu-baseline", "--no-pmc", "--no-bandwidth"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert "stripes x2" in line["config"]["parallelism"]
+    # the line says what ran: design, preflight / fallback, ranks the backend saw, spread over ranks, collectives
+    mg = line["multi_gpu"]
+    assert mg["shard_mode"] == "gaussians" and mg["shard_mode_requested"] == "both" and mg["shard_mode_fallback"] is False
+    assert mg["preflight"] == "ok" and mg["ranks"] == 2 and mg["backend"] == "gloo" and mg["rccl_ranks"] is None
+    assert 0 < mg["rank_ms_min"] <= mg["rank_ms_max"] and mg["collective_calls_per_step"] == 3
+    rep = mg["replicated_mode"]
+    assert rep["shard_mode"] == "replicated" and rep["value"] > 0 and rep["collective_calls_per_step"] == 1

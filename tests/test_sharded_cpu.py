@@ -83,3 +83,15 @@ def test_sharded_ranks_equal_single_process(tmp_path, world, n, sh, w, h):
                 continue
             assert torch.allclose(g, ref, rtol=1e-4, atol=1e-6 * max(1.0, ref.abs().max().item()))
         assert torch.allclose(o["xys_grad"], xys.grad[i0:i1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_preflight_agrees_over_gloo(tmp_path, world):
+    """bench.py decides its multi-GPU design before the first frame: every rank makes the same tiny all_to_all_single
+    with uneven split sizes and the ranks agree with an all-reduce (tinysplat_amd/_comm.py)."""
+    mp.spawn(dist_shard_worker.run_preflight, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"pre{r}.pt") for r in range(world)]
+    assert all(o["ok"] and o["err"] == "" for o in outs)
+    for r, o in enumerate(outs):
+        assert o["send"] == [r + 1] * world and o["recv"] == [s + 1 for s in range(world)]
+        assert o["calls"] == 1 and o["ms"] == 0.0

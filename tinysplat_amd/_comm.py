@@ -1,0 +1,76 @@
+"""Event timing of the collectives of a sharded frame (bench.py at N > 1: "how long did the ranks spend in
+RCCL"), and the preflight that decides whether the Gaussian-sharded exchange can run on this node.
+
+The timer is off unless a caller switches it on; switched on it brackets every collective of
+sharded.DistExchange, frame.py and sharding.py with a pair of events on the current stream."""
+from __future__ import annotations
+
+import contextlib
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class CollectiveTimer:
+    def __init__(self):
+        self.enabled = False
+        self._pairs: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.calls = 0
+
+    def start(self) -> None:
+        self.enabled, self._pairs, self.calls = True, [], 0
+
+    def stop(self) -> Tuple[float, int]:
+        """-> (milliseconds inside collectives since start(), number of collective calls)."""
+        self.enabled = False
+        if self._pairs:
+            self._pairs[-1][1].synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._pairs)
+        calls, self._pairs, self.calls = self.calls, [], 0
+        return ms, calls
+
+    @contextlib.contextmanager
+    def span(self, on_device: bool = True):
+        if not self.enabled or not on_device or not torch.cuda.is_available():
+            if self.enabled:
+                self.calls += 1
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        try:
+            yield
+        finally:
+            b.record()
+            self._pairs.append((a, b))
+            self.calls += 1
+
+
+collective_timer = CollectiveTimer()
+
+
+def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
+    """Every rank runs the SAME tiny ``all_to_all_single`` with uneven split sizes (the call shape of
+    sharded.DistExchange.rows) before any frame, then the ranks agree with an all-reduce: a backend that rejects the
+    call does so on all ranks in this first collective, not on one rank in the middle of a frame with its peers
+    already blocked in the next exchange.  -> (usable on ALL ranks, this rank's error text or "")."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ok, err = 1, ""
+    try:
+        via_host = dist.get_backend(group) == "gloo"
+        dev = torch.device("cpu") if via_host else device
+        send_counts = [1 + ((rank + d) % 3) for d in range(world)]               # rows to each destination
+        recv_counts = [1 + ((s + rank) % 3) for s in range(world)]               # = what source s sends to this rank
+        send = torch.full((sum(send_counts), 4), float(rank), device=dev)
+        got = torch.empty((sum(recv_counts), 4), device=dev)
+        dist.all_to_all_single(got, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        want = torch.cat([torch.full((c, 4), float(s)) for s, c in enumerate(recv_counts)])
+        if not torch.equal(got.cpu(), want):
+            ok, err = 0, "all_to_all_single with split sizes returned wrong rows"
+    except Exception as e:                                      # noqa: BLE001 - whatever the backend raises
+        ok, err = 0, f"{type(e).__name__}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) != "gloo" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item())), err

@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from ._comm import collective_timer
 from . import _lib
 from ._lib import TsFrame
 from .ops import (TileBinning, _call, _camera, _f32c, _need_hip, _ptr, _stream, _stripe_rows, _tile_bounds,
@@ -510,7 +511,8 @@ class _RenderFrame(torch.autograd.Function):
             else:
                 _lib.check(lib.ts_frame_bwd_composite(ctypes.byref(fr), s), "ts_frame_bwd_composite")
             if ctx.group is not None:                          # tile-stripe sharding: sum over ranks
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+                with collective_timer.span(on_device=flat.is_cuda and dist.get_backend(ctx.group) != "gloo"):
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
             if timed:
                 _steps_bwd_params(lib, fr, s)
             else:

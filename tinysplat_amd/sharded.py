@@ -37,6 +37,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from ._comm import collective_timer
 from . import _lib
 from . import frame as _frame
 from ._lib import TsFrame, TsStripes
@@ -128,10 +129,12 @@ class DistExchange(Exchange):
         if self.via_host:
             mine = counts_dev.cpu()
             got = torch.empty_like(mine)
-            dist.all_to_all_single(got, mine, group=self.group)
+            with collective_timer.span(on_device=False):
+                dist.all_to_all_single(got, mine, group=self.group)
             return mine.tolist(), got.tolist()
         got = torch.empty_like(counts_dev)
-        dist.all_to_all_single(got, counts_dev, group=self.group)
+        with collective_timer.span():
+            dist.all_to_all_single(got, counts_dev, group=self.group)
         both = torch.stack([counts_dev, got]).cpu()              # the frame's host read of the record counts
         return both[0].tolist(), both[1].tolist()
 
@@ -140,12 +143,14 @@ class DistExchange(Exchange):
         if self.via_host:
             src = send.cpu()
             got = torch.empty((m, send.shape[1]), dtype=send.dtype)
-            dist.all_to_all_single(got, src, output_split_sizes=list(recv_counts),
-                                   input_split_sizes=list(send_counts), group=self.group)
+            with collective_timer.span(on_device=False):
+                dist.all_to_all_single(got, src, output_split_sizes=list(recv_counts),
+                                       input_split_sizes=list(send_counts), group=self.group)
             return got.to(send.device)
         got = send.new_empty((m, send.shape[1]))
-        dist.all_to_all_single(got, send, output_split_sizes=list(recv_counts),
-                               input_split_sizes=list(send_counts), group=self.group)
+        with collective_timer.span():
+            dist.all_to_all_single(got, send, output_split_sizes=list(recv_counts),
+                                   input_split_sizes=list(send_counts), group=self.group)
         return got
 
 

@@ -16,6 +16,7 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from ._comm import collective_timer
 from .rasterizer import camera_on_device, project_args, raster_args, sh_args, tile_bounds
 
 
@@ -57,10 +58,12 @@ class _SumGradsAcrossRanks(torch.autograd.Function):
             return (None,) + grads
         base = _shared_flat_base(live)
         if base is not None:          # already one contiguous buffer (ops._RasterizeGaussians.backward)
-            dist.all_reduce(base, op=dist.ReduceOp.SUM, group=ctx.group)
+            with collective_timer.span(on_device=base.is_cuda):
+                dist.all_reduce(base, op=dist.ReduceOp.SUM, group=ctx.group)
             return (None,) + grads
         flat = torch.cat([g.reshape(-1) for g in live])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        with collective_timer.span(on_device=flat.is_cuda):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
         out, off = [], 0
         for g in grads:
             if g is None:

@@ -1,5 +1,6 @@
 import sys, json
-for line in sys.stdin:
+# usage: python tools/print_bench.py bench.json   (or the bench line on stdin)
+for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     if line.startswith("{"):
         d = json.loads(line)
         print(d["config"]["workload"][:60], "| ms", round(d["ms_per_step"], 3), "| G*px/s %.3e" % d["value"], "| I", d["config"]["intersections"],

@@ -69,18 +69,26 @@ def pytest_sessionfinish(session, exitstatus):
 
 
 def pytest_terminal_summary(terminalreporter):
-    """Worst measured error per compared gradient tensor (helpers.check_grad)."""
+    """Worst measured error per compared gradient tensor (helpers.check_grad) and per compared image
+    (helpers.report_unmasked: over the threshold-stable pixels the tests assert on, and over ALL pixels)."""
     try:
-        from helpers import PARITY_LOG
+        from helpers import IMAGE_LOG, PARITY_LOG
     except Exception:
         return
-    if not PARITY_LOG:
+    if not PARITY_LOG and not IMAGE_LOG:
         return
-    lines = ["test | tensor | max abs err | |ref|_inf | tolerance | err/tol | fraction over | fraction within 1e-5 abs"]
-    for test, what, worst, mag, tol, frac, within in PARITY_LOG:
+    lines = ["test | tensor | max abs err | |ref|_inf | tolerance | err/tol | fraction over | fraction within 1e-5 abs "
+             "| fraction within 1e-5 max(1, |ref entry|)"]
+    for test, what, worst, mag, tol, frac, within, entrywise in PARITY_LOG:
         lines.append(f"{test} | {what} | {worst:.3e} | {mag:.3e} | {tol:.3e} | {worst / tol if tol else 0:.3f} | "
-                     f"{frac:.2e} | {within:.6f}")
-    terminalreporter.write_sep("-", "measured gradient errors (helpers.check_grad)")
+                     f"{frac:.2e} | {within:.6f} | {entrywise:.6f}")
+    if IMAGE_LOG:
+        lines.append("")
+        lines.append("test | image | max err at threshold-stable pixels (asserted <= 1e-5) | max err over ALL pixels | "
+                     "fraction of pixels masked")
+        for test, what, masked, unmasked, frac in IMAGE_LOG:
+            lines.append(f"{test} | {what} | {masked:.3e} | {unmasked:.3e} | {frac:.2e}")
+    terminalreporter.write_sep("-", "measured errors (helpers.check_grad, helpers.report_unmasked)")
     for ln in lines:
         terminalreporter.write_line(ln)
     out = ROOT / "gpurun_out"

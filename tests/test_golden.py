@@ -207,3 +207,23 @@ def test_scene_funnel_proj_matrix_rescale_and_sh_helpers_match_reference():
     assert torch.equal(RGB2SH(rgb), torch.from_numpy(z["rgb2sh"]))
     assert torch.equal(SH2RGB(rgb), torch.from_numpy(z["sh2rgb"]))
     assert torch.equal(SH2RGB(RGB2SH(rgb)), torch.from_numpy(z["sh2rgb_of_rgb2sh"]))
+
+
+def test_rescale_of_a_directly_constructed_camera_and_reorder_guard():
+    """PinholeCamera.rescale on a camera built field by field derives the fov angles from its projection
+    matrix (it raised AttributeError); SplatModel.spatial_sort_ refuses a model an optimiser / densifier holds
+    per-row state for."""
+    import pytest
+    from tinysplat_amd.densify import Densifier
+    from tinysplat_amd.synthetic import PinholeCamera, make_scene
+    model, cam = make_scene(64, 1, 64, 48)
+    c = PinholeCamera(cam.view_matrix, cam.proj_matrix.clone(), cam.f_x, cam.f_y, 64, 48)
+    ref = PinholeCamera.look_at_origin_plus_z(64, 48)
+    c.rescale(0.5)
+    ref.rescale(0.5)
+    assert (c.width, c.height) == (ref.width, ref.height) == (32, 24)
+    assert abs(c.fov_x - ref.fov_x) < 1e-6 and torch.allclose(c.proj_matrix, ref.proj_matrix, atol=1e-6)
+    model.spatial_sort_()                       # a fresh model: fine
+    Densifier(model)
+    with pytest.raises(RuntimeError, match="held by"):
+        model.spatial_sort_()

@@ -137,3 +137,33 @@ def test_the_sort_inside_the_compositing_launch_changes_nothing(n, sh, w, h, mul
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
     for a, b_ in zip(got[1], ref[1]):
         assert torch.equal(a, b_)
+
+
+def test_exception_between_the_scan_and_the_count_read_does_not_poison_the_next_frame(monkeypatch):
+    """the pair count travels through ONE pinned word per device.  A frame that raises after its scan
+    was enqueued but before the count was read must not leave that scan to overwrite the word under the NEXT frame's
+    sentinel (frame.py: the `finally` waits for the scan before the word changes hands)."""
+    w, h = 320, 200
+    small, cam = make_scene(4000, 1, w, h, seed=5, scale_mult=2.0)
+    big, _ = make_scene(50000, 1, w, h, seed=6, scale_mult=3.0)
+    small, big = small.to(DEV), big.to(DEV)
+    with torch.no_grad():
+        ref, _, _ = render_stripe(small, cam, (w, h), DEV, 0, 1)
+        total_small = frame.last_binning[DEV.index].num_intersects
+        render_stripe(big, cam, (w, h), DEV, 0, 1)
+        assert frame.last_binning[DEV.index].num_intersects > 4 * total_small
+        orig = frame._lib.check
+
+        def boom(rc, what):
+            if what == "ts_frame_fwd_prepare":
+                raise RuntimeError("injected between the scan and the count read")
+            return orig(rc, what)
+
+        monkeypatch.setattr(frame._lib, "check", boom)
+        with pytest.raises(RuntimeError, match="injected"):
+            render_stripe(big, cam, (w, h), DEV, 0, 1)             # its scan is (or was) in flight
+        monkeypatch.setattr(frame._lib, "check", orig)
+        for _ in range(3):
+            again, _, _ = render_stripe(small, cam, (w, h), DEV, 0, 1)
+            assert frame.last_binning[DEV.index].num_intersects == total_small
+            assert torch.equal(again, ref)

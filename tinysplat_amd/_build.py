@@ -73,7 +73,11 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
             _stamp_path(o).write_text(" ".join(cmd[1:]))
             relink = True
         objs.append(str(o))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lrocprofiler-sdk-roctx", "-o", str(LIB_PATH)]
+    # roctx ranges (csrc/frame.hip) are optional: link the marker library only where the header it is guarded by exists
+    rocm = Path(hipcc).resolve().parent.parent
+    have_roctx = any((r / "include" / "rocprofiler-sdk-roctx" / "roctx.h").exists() for r in (rocm, Path("/opt/rocm")))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs,
+           *(["-lrocprofiler-sdk-roctx"] if have_roctx else []), "-o", str(LIB_PATH)]
     # the library records the flag sets of all its objects: a variant library is relinked by the
     # next default build even though it is newer than every source
     want = "\n".join(_stamp_path(Path(o)).read_text() for o in objs)

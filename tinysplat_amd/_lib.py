@@ -12,6 +12,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
 ABI_VERSION = 5
+PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
 
 
 class TsCamera(ctypes.Structure):

@@ -11,15 +11,25 @@
 // stores it into the caller's mapped pinned word (ts_frame_fwd_project), where the caller polls it between
 // _prepare and _composite.
 #include <hip/hip_runtime.h>
+// roctx is optional: a ROCm install without rocprofiler-sdk still builds and loads the library (ranges become no-ops)
+#if !defined(TS_NO_ROCTX) && __has_include(<rocprofiler-sdk-roctx/roctx.h>)
 #include <rocprofiler-sdk-roctx/roctx.h>
+#define TS_HAVE_ROCTX 1
+#else
+#define TS_HAVE_ROCTX 0
+#endif
 
 #include "../../include/tinysplat_hip.h"
 
 // roctx ranges around the five executor calls: `rocprofv3 --marker-trace --kernel-trace` shows which kernels a
 // call enqueued and the gaps between them (no cost without a tool attached)
 struct TsRange {
+#if TS_HAVE_ROCTX
     explicit TsRange(const char* name) { roctxRangePush(name); }
     ~TsRange() { roctxRangePop(); }
+#else
+    explicit TsRange(const char*) {}
+#endif
 };
 
 #define TS_TRY(call)                 \

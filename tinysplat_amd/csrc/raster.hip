@@ -174,6 +174,11 @@ __device__ __forceinline__ void dma_record(const float4* __restrict__ splats, in
 #endif
 constexpr int kWaves = TS_RASTER_WAVES;   // tiles (= waves) per workgroup; waves never synchronise
 constexpr int kThreads = 64 * kWaves;
+// float4s per gradient row slot.  (Round 4 tried 64-byte slots, whole-sector stores: WRITE_SIZE 218 -> 221 MB,
+// reduce_partials 57 -> 60 us - the 1.9x "write amplification" of round 3 is the row's FLAG BYTE, a 32-byte sector
+// write of its own per row (2.41 M x (64 + 32) B = 231 MB), not rows straddling lines.)
+constexpr int kRowF4 = TS_PARTIAL_ROW_FLOATS / 4;
+static_assert(TS_PARTIAL_ROW_FLOATS % 4 == 0 && TS_PARTIAL_ROW_FLOATS >= 12, "row = whole float4s, >= 10 values");
 using ts::kLog2e;
 using ts::kLog2_255;
 
@@ -1035,8 +1040,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (f & (0xffu << (8 * k))) {
-                    p0[k] = partials[3 * (4 * s + k)]; p1[k] = partials[3 * (4 * s + k) + 1];
-                    p2[k] = partials[3 * (4 * s + k) + 2];
+                    p0[k] = partials[kRowF4 * (4 * s + k)]; p1[k] = partials[kRowF4 * (4 * s + k) + 1];
+                    p2[k] = partials[kRowF4 * (4 * s + k) + 2];
                 }
             }
 #pragma unroll
@@ -1061,8 +1066,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 if (f[u]) {
-                    p0[u] = partials[3 * (s0 + u)]; p1[u] = partials[3 * (s0 + u) + 1];
-                    p2[u] = partials[3 * (s0 + u) + 2];
+                    p0[u] = partials[kRowF4 * (s0 + u)]; p1[u] = partials[kRowF4 * (s0 + u) + 1];
+                    p2[u] = partials[kRowF4 * (s0 + u) + 2];
                 }
             }
 #pragma unroll

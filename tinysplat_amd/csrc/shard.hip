@@ -160,14 +160,18 @@ __global__ __launch_bounds__(kThreads) void route_pack_kernel(
         if (lane == 0) cnt[wave][d] = __popcll(m);
     }
     __syncthreads();
+    // No lane leaves an iteration early: every ballot of this loop is executed by the whole wave (a `continue`
+    // before the next iteration's ballot would rely on the compiler reconverging the wave at the loop latch,
+    // which HIP does not promise - ADVICE r3); only the stores are predicated.
     for (int d = 0; d < st.num; ++d) {
         const bool mine = r.d0 <= d && d <= r.d1;
         const unsigned long long m = __ballot(mine);
-        if (!mine) continue;
         int pos = seg[d] + block_base[(size_t)d * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) pos += cnt[w][d];
-        float4* o = records + 4 * (size_t)pos;
-        o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+        if (mine) {
+            float4* o = records + 4 * (size_t)pos;
+            o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+        }
     }
 }
 
@@ -193,14 +197,15 @@ __global__ __launch_bounds__(kThreads) void route_accumulate_kernel(
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     for (int d = 0; d < st.num; ++d) {
         const bool mine = r.d0 <= d && d <= r.d1;
-        const unsigned long long m = __ballot(mine);
-        if (!mine) continue;
+        const unsigned long long m = __ballot(mine);          // whole wave, every iteration (see route_pack_kernel)
         int pos = seg[d] + block_base[(size_t)d * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) pos += cnt[w][d];
-        const float4 p0 = rows[3 * (size_t)pos], p1 = rows[3 * (size_t)pos + 1], p2 = rows[3 * (size_t)pos + 2];
-        a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
-        a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
-        a2.x += p2.x; a2.y += p2.y;
+        if (mine) {
+            const float4 p0 = rows[3 * (size_t)pos], p1 = rows[3 * (size_t)pos + 1], p2 = rows[3 * (size_t)pos + 2];
+            a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+            a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+            a2.x += p2.x; a2.y += p2.y;
+        }
     }
     if (i >= n) return;
     if (r.d0 <= r.d1) {

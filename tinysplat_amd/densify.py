@@ -74,6 +74,14 @@ class Densifier:
         self.means_grad_accum = torch.zeros(model.means.shape[0], dtype=torch.float32,
                                             device=model.means.device)      # :62
         self.last_counts = None      # (kept, cloned, split, new total) of the last rebuild
+        held = getattr(model, "held_by", None)          # see SplatModel.spatial_sort_: the accumulator is per row
+        if held is None:
+            try:
+                model.held_by = held = set()
+            except AttributeError:
+                held = None
+        if held is not None:
+            held.add("Densifier")
 
     # ------------------------------------------------------------------ :130-132
     @torch.no_grad()

@@ -88,7 +88,8 @@ def _mark(label):
 
 
 _pinned_total = {}      # device index -> (pinned int32[1], event): the path's one host read
-_row_flags = {}         # device index -> [uint8 tensor, generation]: ONE flag array per device, see row_flags_for
+_row_flags = {}         # (device index, stream handle) -> [uint8 tensor, generation], see row_flags_for
+_row_flags_lock = threading.Lock()
 
 # Row flags of the backward pass (1 byte per partial row: written in THIS pass?).  Instead of zeroing I bytes per
 # frame (a 5-10 us fill launch on the critical path), one array per device lives across frames and every pass
@@ -98,17 +99,24 @@ FLAG_GENERATIONS = os.environ.get("TS_FLAG_GENERATIONS", "1") != "0"
 
 
 def row_flags_for(dev: torch.device, rows: int):
-    """-> (uint8 tensor of >= rows bytes, generation).  generation 0: a fresh array the kernels zero themselves."""
+    """-> (uint8 tensor of >= rows bytes, generation).  generation 0: a fresh array the kernels zero themselves.
+
+    One array per (device, STREAM): two backward passes on different streams of a device (or from two host threads,
+    each on its own stream) never share a generation counter or race on the wrap-around zeroing; passes on ONE
+    stream are ordered by the stream.  An array much larger than a frame needs (a big frame followed by small
+    ones) is released instead of being kept for ever."""
     if not FLAG_GENERATIONS:
         return torch.empty((rows,), dtype=torch.uint8, device=dev), 0
-    slot = _row_flags.get(dev.index)
-    if slot is None or slot[0].numel() < rows:
-        slot = _row_flags[dev.index] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0]
-    slot[1] += 1
-    if slot[1] > 255:
-        slot[0].zero_()
-        slot[1] = 1
-    return slot[0], slot[1]
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    with _row_flags_lock:
+        slot = _row_flags.get(key)
+        if slot is None or slot[0].numel() < rows or slot[0].numel() > 8 * max(rows, 1 << 20):
+            slot = _row_flags[key] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0]
+        slot[1] += 1
+        if slot[1] > 255:
+            slot[0].zero_()
+            slot[1] = 1
+        return slot[0], slot[1]
 
 _bg_cache = {}          # (storage address, version, channels) -> contiguous background with the depth channel
 
@@ -482,7 +490,7 @@ class _RenderFrame(torch.autograd.Function):
                 v_xy = torch.empty((n, 2), **f32)
                 v_opac = torch.empty(tuple(ctx.opacity_shape), **f32)
             rows = max(F.total, 1) * (4 if F.split else 1)
-            partials = torch.empty((rows, 12), **f32)
+            partials = torch.empty((rows, _lib.PARTIAL_ROW_FLOATS), **f32)
             row_flags, fr.flag_gen = row_flags_for(dev, rows)
             _mark("bwd:flat+partials+flags")
             v_means = torch.empty((n, 3), **f32)

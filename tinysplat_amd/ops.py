@@ -492,7 +492,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         v_conic = flat[2 * n:5 * n].view(n, 3)
         v_colors = flat[5 * n:(5 + ch) * n].view(n, ch)
         v_opacity = flat[(5 + ch) * n:]
-        partials = torch.empty((max(total, 1), 12), **f32)
+        partials = torch.empty((max(total, 1), _lib.PARTIAL_ROW_FLOATS), **f32)
         row_flags = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
         lib = _lib.load()
         s = _stream(dev)

@@ -389,7 +389,7 @@ def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
     f32 = dict(dtype=torch.float32, device=dev)
     m, fr = S.m, S.fr
     rows_n = max(S.total, 1) * (4 if S.split else 1)
-    partials = torch.empty((rows_n, 12), **f32)
+    partials = torch.empty((rows_n, _lib.PARTIAL_ROW_FLOATS), **f32)
     row_flags, fr.flag_gen = _frame.row_flags_for(dev, rows_n)
     grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
     fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()

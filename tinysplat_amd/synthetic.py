@@ -103,6 +103,11 @@ def _rescale(self, factor: float) -> None:
     """scene.py:123-128, quirk included: width / height are truncated products, and the fov ANGLES (not
     their tangents) are multiplied by the factor before the matrix is rebuilt with the default near / far.
     f_x / f_y are left as they were, as in the reference."""
+    if not hasattr(self, "fov_x") or not hasattr(self, "fov_y"):
+        # a camera constructed field by field (not through a factory / update_proj_matrix): the angles the
+        # projection matrix was built from, proj[0,0] = 1 / tan(fov_x / 2)
+        self.fov_x = 2.0 * math.atan(1.0 / float(self.proj_matrix[0, 0]))
+        self.fov_y = 2.0 * math.atan(1.0 / float(self.proj_matrix[1, 1]))
     self.width = int(self.width * factor)
     self.height = int(self.height * factor)
     self.fov_x = self.fov_x * factor
@@ -174,6 +179,12 @@ class SplatModel:
         The six tensors are REBOUND to new tensors (not swapped through ``.data``), so identity / version keyed
         caches cannot mistake the reordered model for the old one; ``requires_grad`` is carried over.
         """
+        if getattr(self, "held_by", None):
+            # an optimiser / trainer / densifier was built on these tensors (they register themselves in
+            # ``held_by``): rebinding the six tensors would leave it updating tensors the renderer no longer
+            # reads, silently - also right after zero_grad(set_to_none=True), when no .grad gives it away
+            raise RuntimeError(f"spatial_sort_ on a model held by {sorted(self.held_by)}: use "
+                               "Densifier.reorder(optimizer), which permutes the per-row state with the rows")
         perm = morton_order(self.means)
         for name in ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities"):
             t = getattr(self, name)

@@ -164,6 +164,19 @@ def photometric_loss(image: Tensor, target: Tensor, lambda_dssim: float = 0.2):
     return _PhotometricLoss.apply(image, target, lambda_dssim)
 
 
+def _hold(model, who: str) -> None:
+    """Marks a model as having per-row state kept elsewhere (Adam moments, gradient accumulator): the in-place
+    reorder of a FRESH model, SplatModel.spatial_sort_, refuses such a model."""
+    held = getattr(model, "held_by", None)
+    if held is None:
+        held = set()
+        try:
+            model.held_by = held
+        except AttributeError:          # a foreign model class with __slots__: nothing to mark
+            return
+    held.add(who)
+
+
 class Adam:
     """torch.optim.Adam (defaults) over the six parameter tensors, one HIP launch per step."""
 
@@ -224,6 +237,7 @@ class TrainStep:
         self.rasterizer = self.scene.rasterizer
         model.requires_grad_(True)
         self.optimizer = Adam({n: getattr(model, n) for n in PARAM_ORDER}, lrs)
+        _hold(model, "TrainStep")        # per-row state now exists outside the model: see SplatModel.spatial_sort_
 
     def __call__(self, camera, target_rgb: Tensor, target_depth: Optional[Tensor] = None,
                  densifier=None, step: Optional[int] = None):

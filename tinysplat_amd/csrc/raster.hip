@@ -839,8 +839,15 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
     }
 }
 
+// Workgroups of the backward launch are ONE wave (TS_BWD_WAVES): its waves never synchronise, and a workgroup's wave
+// slots and LDS are only handed to the next workgroup when ALL its waves are done - with four tiles per workgroup a
+// wave that finished early left its slot idle until the slowest of the four was through (raster_bwd 532 -> 522 us).
+#ifndef TS_BWD_WAVES
+#define TS_BWD_WAVES 1
+#endif
+constexpr int kBwdWaves = TS_BWD_WAVES;
 template <int CH, bool SPLIT, int NBX, bool WL>
-__global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
+__global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
     const float4* __restrict__ splats, const float* __restrict__ background,
@@ -850,12 +857,12 @@ __global__ __launch_bounds__(kThreads, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     float* __restrict__ partials, unsigned char* __restrict__ row_flags) {
     constexpr int NB = 2 * NBX;
     TS_LDS_PAD_DECL();
-    __shared__ float4 lds_all[kWaves][64 * 4];
-    __shared__ float4 rect_all[kWaves][NB];
-    __shared__ float4 raw_all[TS_LDS_DMA ? kWaves : 1][3 * 64];      // landing zone of the next chunk's records
+    __shared__ float4 lds_all[kBwdWaves][64 * 4];
+    __shared__ float4 rect_all[kBwdWaves][NB];
+    __shared__ float4 raw_all[TS_LDS_DMA ? kBwdWaves : 1][3 * 64];   // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? NB * num_tiles : num_tiles;
-    const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
+    const int unit = xcd_tile_group((units + kBwdWaves - 1) / kBwdWaves) * kBwdWaves + wave;
     if (unit >= units) return;
     const int tile = SPLIT ? unit / NB : unit;
     const int only = SPLIT ? unit % NB : -1;      // SPLIT: this wave owns block `only`, row slot*NB + only
@@ -1247,10 +1254,10 @@ int ts_raster_bwd_planes(int32_t channels, int32_t flags, int64_t num_intersects
     const long long isects_tagged = (long long)(((unsigned long long)(gen ? gen : 1) << 56) |
                                                 ((unsigned long long)num_intersects & 0x00ffffffffffffffull));
     const int units = split ? (wide ? 8 : 4) * nt : nt;
-    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
+    const int grid = 8 * (((units + kBwdWaves - 1) / kBwdWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
 #define TS_LAUNCH_BWD(C, S, X, L)                                                                  \
-    hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
+    hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(64 * kBwdWaves), 0, s, *cam, nt, \
                        isects_tagged, tile_bins, gaussian_ids_sorted, sp, background,              \
                        final_Ts, final_index, v_out_img, v_out_depth, planes ? 1 : 0, v_out_alpha,  \
                        clamp_mask, partials, row_flags)

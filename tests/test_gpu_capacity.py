@@ -53,7 +53,7 @@ def test_estimated_sizes_change_nothing_and_a_small_estimate_is_survived(depth, 
 
 
 def test_row_flag_generations_wrap_and_match_zeroed_flags(monkeypatch):
-    """frame.row_flags_for: one flag array per device across backward passes, rows marked with a generation 1..255
+    """frame.row_flags_for: one flag array per (device, stream) across backward passes, rows marked with a generation 1..255
     (TS_RASTER_FLAG_GEN) instead of a zero fill per pass.  Gradients are bitwise those of the zero-per-pass mode,
     through a growth of the array, through the wrap of the generations (array zeroed, value 1 again) and with four
     rows per pair (the split mapping of small launches)."""
@@ -64,13 +64,14 @@ def test_row_flag_generations_wrap_and_match_zeroed_flags(monkeypatch):
     monkeypatch.setattr(frame, "FLAG_GENERATIONS", False)
     ref = _run(model, cam, w, h, True, w_rgb, w_d)
     monkeypatch.setattr(frame, "FLAG_GENERATIONS", True)
-    frame._row_flags.pop(DEV.index, None)
+    key = (DEV.index, torch.cuda.current_stream(DEV).cuda_stream)     # one array per (device, stream)
+    frame._row_flags.pop(key, None)
     got = [_run(model, cam, w, h, True, w_rgb, w_d)]      # fresh array, generation 1
-    assert frame._row_flags[DEV.index][1] == 1
-    frame._row_flags[DEV.index][1] = 253
+    assert frame._row_flags[key][1] == 1
+    frame._row_flags[key][1] = 253
     for _ in range(4):                                    # 254, 255, wrap -> 1, 2
         got.append(_run(model, cam, w, h, True, w_rgb, w_d))
-    assert frame._row_flags[DEV.index][1] == 2
+    assert frame._row_flags[key][1] == 2
     big, cam2 = make_scene(3 * n, sh, 2 * w, 2 * h, seed=13, scale_mult=2.0)      # a larger frame: the array grows
     big = big.to(DEV).requires_grad_(True)
     wr2, wd2 = (t.to(DEV) for t in loss_weights(2 * w, 2 * h))

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         // one list per wave, or (SPLIT) per workgroup: its four waves composite the four 8x8 blocks of ONE tile,
         // wave 0 sorts the list and the others wait at the barrier
         static_assert(!SORT || (!WL && NBX == 2), "16x16 lists");
+        TS_SEG_T0(tseg_s);                // (timeline builds: the sort is segment 3 of the forward kernel)
         const int n = range.y - range.x;
         if (n > 0 && n <= kWaveSortMax && (!SPLIT || wave == 0)) {
             const int* g = bucket_ids + range.x;
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         // the list is read back below by other lanes (SPLIT: other waves): stores done before the loads are issued
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (SPLIT) __syncthreads();       // units = 4 * tiles: the four waves of a workgroup are valid together
+        TS_SEG_ADD(ts_wave_clock_.seg, 3, tseg_s);
     }
     // (SORT: reads go through the pointer the sort wrote through; ids_sorted is the same buffer)
     const int* ids = SORT ? ids_rw : ids_sorted;

@@ -68,7 +68,8 @@ for which, name in ((0, "raster_fwd"), (1, "raster_bwd")):
     per = dur / np.maximum(ln, 1.0)
     print(f"   list length: mean {ln.mean():.0f} max {ln.max():.0f}; us per listed entry: mean {per.mean():.3f} "
           f"p5 {np.percentile(per, 5):.3f} p95 {np.percentile(per, 95):.3f}; corr(duration, length) = {np.corrcoef(dur, ln)[0, 1]:.2f}")
-    names = ("chunk prologue (stage, cull, compact)", "record read (LDS -> registers)", "block bodies", "row flush")
+    names = ("chunk prologue (stage, cull, compact)", "record read (LDS -> registers)", "block bodies",
+             "row flush" if which == 1 else "per-tile sort inside the launch")
     print(f"   shader clock over a wave's life: {np.median(tot / np.maximum(dur, 1e-9)) * 1e-3:.2f} GHz; cycles per wave {tot.mean():.0f}")
     for i, nm in enumerate(names):
         print(f"   segment {i} {nm:40s} {seg[:, i].sum() / tot.sum() * 100:5.1f} % of the wave cycles"

@@ -23,14 +23,15 @@
 //     exponent, the compositing weight is T_old - T_new (telescoping), a finished pixel is marked
 //     by the sign of T, and Gaussians that need the sigma >= 0 / 0.999-clamp tests are flagged at
 //     staging so that the common chunk runs a loop without them.  Nothing is set up per entry: a
-//     flagged block evaluates dx, dy and the exponent itself (8 issues, sigma_l2).  Both kernels
-//     are VALU-issue bound - 97 % / 89 % of the 39.3 T lane-operations/s that non-packed wave64
-//     instructions can issue (bench.py: valu_roofline) - so instruction count is what sets their
-//     time.  Packed fp32 does not help here although an isolated stream of v_pk_fma_f32 issues at
-//     twice the scalar rate (tools/micro/pk_bench.hip): packing the natural pairs of the bodies -
-//     (dx, dy), (hA dx, hC dy), (v dx, v dy), the moment and colour accumulators - removed 12 % of
-//     the instructions and none of the time.  The file is built with
-//     -fno-slp-vectorize because the SLP packer's register shuffles cost issue slots on top.
+//     flagged block evaluates dx, dy and the exponent itself (8 issues, sigma_l2).  What bounds both kernels
+//     (profiles/HISTORY.md round 4): a wave issues one instruction per ~5 cycles whatever it
+//     is, a tile is ~60 k of them, and 8 160 tiles on 4 096 - 5 120 wave slots are two rounds whose tail idles a
+//     fifth of the launch; with four waves per SIMD the vector pipe (a wave64 instruction per 2 cycles: 78.6 T
+//     lane-operations/s, of which these kernels reach 0.44 - 0.48) saturates in the full phase, so instruction
+//     count AND kind set the time.  Packed fp32 does not help (a v_pk_fma_f32 costs 3.5 pipe cycles for two FMAs
+//     and packing the natural pairs of the bodies - (dx, dy), (hA dx, hC dy), (v dx, v dy), the accumulators -
+//     removed 12 % of the instructions and none of the time).  The file is built with -fno-slp-vectorize
+//     because the SLP packer's register shuffles cost issue slots on top.
 //   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
 //     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
 //     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot

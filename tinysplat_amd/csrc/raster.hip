@@ -60,12 +60,13 @@ namespace {
 
 // TS_STATS=1 (developer build, tools/raster_stats.py; slow): dynamic work counters of the compositing kernels,
 // ts_stats = {fwd staged entries, fwd block bodies, bwd staged entries, bwd block bodies entered, bwd bodies with
-// a valid lane, bwd rows flushed, bwd valid lanes, bwd list entries walked}.
+// a valid lane, bwd rows flushed, bwd valid lanes, bwd list entries walked, bwd bodies valid in one half only,
+// bwd bodies valid in 1 / 2 / 3 of the four 4x4 quadrants}.
 #ifndef TS_STATS
 #define TS_STATS 0
 #endif
 #if TS_STATS
-__device__ unsigned long long ts_stats[8];
+__device__ unsigned long long ts_stats[12];
 #define TS_STAT(i, v)                                                                       \
     do {                                                                                    \
         if ((threadIdx.x & 63) == 0) atomicAdd(&ts_stats[i], (unsigned long long)(v));      \
@@ -790,6 +791,16 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             if (validm == 0ull) continue;                              // wave-uniform
             TS_STAT(4, 1);
             TS_STAT(6, __popcll(validm));
+            // lane packing: how many bodies have their valid pixels in ONE half (rows 0-3 / 4-7) or ONE quarter
+            // (a 4x4 quadrant: lane bits 2 and 5) of the 8x8 block - what half-wave / quarter-wave bodies could pair up
+            TS_STAT(8, ((unsigned)validm == 0u) != ((unsigned)(validm >> 32) == 0u));
+            {
+                const mask64 q0 = 0x000000000F0F0F0Full, q1 = 0x00000000F0F0F0F0ull;
+                const int quads = ((validm & q0) != 0) + ((validm & q1) != 0) + ((validm & (q0 << 32)) != 0) + ((validm & (q1 << 32)) != 0);
+                TS_STAT(9, quads == 1);
+                TS_STAT(10, quads == 2);
+                TS_STAT(11, quads == 3);
+            }
             any = 1;
             // the select takes its mask from an ordinary SGPR pair: the VOP2 form on a vcc that the SCALAR unit
             // wrote (the s_and of the two ballots) costs a wave 19 cycles instead of 5 (tools/micro/lat_bench.hip)
@@ -1142,7 +1153,7 @@ int ts_debug_timeline(unsigned long long* out_host, int which, int count) {   //
 int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer builds only (not part of the ABI)
     hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ts_stats), sizeof(ts_stats));
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[12] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(ts_stats), z, sizeof(z));
     }
     return (int)e;

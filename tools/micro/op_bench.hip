@@ -1,3 +1,5 @@
+// SUPERSEDED by op_bench2.hip (round 4): this one divides WALL time by a nominal 2.4 GHz, and the shader clock under
+// these loads is 1.9 - 2.1 GHz - its 3.2 "cycles" for v_fma_f32 are 1.94 real ones.  Kept for the round-3 tables.
 // Microbenchmark (developer tool): issue cost of the VALU instructions the compositing kernels are made of,
 // in SIMD cycles per wave64 instruction (nominal 2.4 GHz), 16 independent instances per loop iteration,
 // 16 waves per SIMD.  build: hipcc --offload-arch=gfx950 -O3 -o op_bench tools/micro/op_bench.hip

@@ -61,8 +61,12 @@ typedef struct ts_camera {
      * count 16x16 tiles; images and gradients do not depend on the shape (a Gaussian is composited only
      * into the 16x16 tiles of its tile box either way), only the number of list entries does. */
     int32_t wide_tiles;
-    int32_t reserved;
+    /* performance hints (formerly `reserved`, 0 = none); results never depend on them.
+     * TS_HINT_BALANCED_WALK: a Gaussian covers many tiles (>= ~10 bounding-box tiles on average): ts_bin_scatter
+     * expands (Gaussian, tile row) items over the lanes instead of looping per Gaussian. */
+    int32_t hints;
 } ts_camera;
+#define TS_HINT_BALANCED_WALK 1
 /* tiles (= lists) of a launch: tile_rows * tile_bounds_x, or tile_rows * ceil(tile_bounds_x / 2) when wide */
 int32_t ts_num_tiles(const ts_camera* cam_host);
 

@@ -39,7 +39,7 @@ def test_binding_covers_the_header_and_version_matches():
     assert lib.ts_abi_version() == _lib.ABI_VERSION == 5
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
-    assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + reserved (ABI 3)
+    assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + hints (ABI 3; the second word was `reserved` until round 4)
     assert ctypes.sizeof(_lib.TsStripes) == 4 * (_lib.MAX_RANKS + 2)
     assert lib.ts_frame_struct_bytes() == ctypes.sizeof(_lib.TsFrame)
     assert lib.ts_frame_fwd_project(None, None) == -1 and lib.ts_frame_bwd_params(None, None) == -1

@@ -12,6 +12,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
 ABI_VERSION = 5
+HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
 
 
@@ -23,7 +24,7 @@ class TsCamera(ctypes.Structure):
         ("tile_bounds_x", c_int32), ("tile_bounds_y", c_int32),
         ("tile_row0", c_int32), ("tile_rows", c_int32),
         ("glob_scale", c_float), ("clip_thresh", c_float),
-        ("wide_tiles", c_int32), ("reserved", c_int32),
+        ("wide_tiles", c_int32), ("hints", c_int32),
     ]
 
 

@@ -292,7 +292,110 @@ __device__ __forceinline__ void walk_chunk(int g0, int g1, const float* __restri
     }
 }
 
+// LOAD-BALANCED WALK (round 4).  walk_chunk gives every lane one Gaussian and lets it loop over
+// its tile rows and the tiles of a row: a Gaussian of the random scenes has 1-3 rows, the slowest lane of a wave ~5,
+// and the 35-instruction row_range runs at ~40 % lane use (bin_count: 670 wave instructions per 64 Gaussians).  Here
+// a batch of 1024 Gaussians (one per thread) is expanded into ITEMS = (Gaussian, tile row): phase 1 computes the box
+// and the TightTest once per Gaussian and stashes what a row needs in LDS; a workgroup scan of the row counts gives
+// every Gaussian its item range; the items are written out in windows of kItemCap and phase 2 hands consecutive
+// items to consecutive lanes.  Same decisions as walk_chunk (same TightTest members, same row_range), different
+// ORDER of the emits - which no caller depends on (LDS histogram / cursors; the per-tile sort follows).
+#ifndef TS_BIN_BALANCED
+#define TS_BIN_BALANCED 1
+#endif
+constexpr int kItemCap = 4096;                    // items per window
+constexpr int kStashWords = 11;                   // per Gaussian: 10 TightTest floats + (minx | maxx << 16)
+constexpr size_t kBalancedLds = (size_t)(kStashWords * kBinThreads + kItemCap + 32) * 4;      // static LDS it needs
+template <typename Emit>
+__device__ __forceinline__ void walk_chunk_balanced(int g0, int g1, const float* __restrict__ xys,
+                                                    const int* __restrict__ radii,
+                                                    const float4* __restrict__ splats, const ts_camera& cam,
+                                                    Emit emit) {
+    static_assert(kBinThreads == 1024, "one Gaussian per thread and batch, items packed as lt | row << 10");
+    __shared__ float stash[kStashWords][kBinThreads];
+    __shared__ int items[kItemCap];
+    __shared__ int wave_sum[kBinThreads / 64 + 1];
+    const int ws = cam.wide_tiles ? 1 : 0;
+    const int tbx = (cam.tile_bounds_x + ws) >> ws;
+    const bool tight_lists = splats != nullptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int base = g0; base < g1; base += kBinThreads) {
+        // ---- phase 1: one Gaussian per thread
+        const int i = base + tid;
+        int rows = 0, miny = 0;
+        if (i < g1) {
+            const int r = radii[i];
+            if (r > 0) {
+                const float2 xy = reinterpret_cast<const float2*>(xys)[i];
+                float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+                if (tight_lists) { q0 = splats[3 * (size_t)i]; q1 = splats[3 * (size_t)i + 1]; }
+                const ts::TileBox b = ts::tile_bbox(xy.x, xy.y, (float)r, cam.tile_bounds_x, cam.tile_bounds_y,
+                                                    cam.tile_row0, cam.tile_rows);
+                if (b.maxy > b.miny && b.maxx > b.minx) {
+                    const TightTest t(tight_lists, q0, q1, (float)r);
+                    if (!t.cull_all) {
+                        rows = b.maxy - b.miny;
+                        miny = b.miny;
+                        stash[0][tid] = t.geometric ? t.dymax : -1.0f;          // dymax >= 0 when geometric
+                        stash[1][tid] = t.gx; stash[2][tid] = t.gy; stash[3][tid] = t.B; stash[4][tid] = t.D4;
+                        stash[5][tid] = t.inv2A; stash[6][tid] = t.tau4A; stash[7][tid] = t.dxext;
+                        stash[8][tid] = t.dy_left; stash[9][tid] = __int_as_float(b.miny);
+                        stash[10][tid] = __int_as_float(b.minx | (b.maxx << 16));
+                    }
+                }
+            }
+        }
+        // ---- exclusive scan of the row counts over the workgroup
+        int incl = rows;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            int v = lane < kBinThreads / 64 ? wave_sum[lane] : 0;
+#pragma unroll
+            for (int d = 1; d < kBinThreads / 64; d <<= 1) {
+                const int u = __shfl_up(v, d, 64);
+                if (lane >= d) v += u;
+            }
+            if (lane < kBinThreads / 64) wave_sum[lane] = v;                     // inclusive over waves
+        }
+        __syncthreads();
+        const int total = wave_sum[kBinThreads / 64 - 1];
+        const int first = incl - rows + (wave > 0 ? wave_sum[wave - 1] : 0);   // this Gaussian's first item
+        // ---- items in windows of kItemCap: written by their Gaussians, consumed by consecutive lanes
+        for (int w0 = 0; w0 < total; w0 += kItemCap) {
+            const int lo_k = max(0, w0 - first), hi_k = min(rows, w0 + kItemCap - first);
+            for (int k = lo_k; k < hi_k; ++k) items[first + k - w0] = tid | (k << 10);
+            __syncthreads();
+            const int m = min(kItemCap, total - w0);
+            for (int j = tid; j < m; j += kBinThreads) {
+                const int it = items[j], lt = it & 1023, k = it >> 10;
+                TightTest t(false, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0.0f);
+                const float d0 = stash[0][lt];
+                t.geometric = d0 >= 0.0f;
+                t.dymax = d0;
+                t.gx = stash[1][lt]; t.gy = stash[2][lt]; t.B = stash[3][lt]; t.D4 = stash[4][lt];
+                t.inv2A = stash[5][lt]; t.tau4A = stash[6][lt]; t.dxext = stash[7][lt]; t.dy_left = stash[8][lt];
+                const int ty = __float_as_int(stash[9][lt]) + k;
+                const int xx = __float_as_int(stash[10][lt]);
+                int lo, hi;
+                t.row_range(ty, xx & 0xffff, xx >> 16, lo, hi);
+                if (hi <= lo) continue;
+                const int id = base + lt;
+                for (int tx = lo >> ws; tx <= (hi - 1) >> ws; ++tx) emit((ty - cam.tile_row0) * tbx + tx, id);
+            }
+            __syncthreads();
+        }
+        __syncthreads();          // wave_sum and the stash change hands (a batch without items has no barrier above)
+    }
+}
+
 // grid = (chunks, windows); counts[b * T + t]
+template <bool BAL>
 __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
     const float4* __restrict__ splats, const ts_camera cam, int num_tiles, int window,
@@ -303,10 +406,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(
     for (int j = threadIdx.x; j < tw; j += kBinThreads) hist[j] = 0;
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-    walk_chunk(g0, g1, xys, radii, splats, cam, [&](int t, int) {
+    auto emit = [&](int t, int) {
         t -= t0;
         if ((unsigned)t < (unsigned)tw) atomicAdd(&hist[t], 1);
-    });
+    };
+    if (BAL) walk_chunk_balanced(g0, g1, xys, radii, splats, cam, emit);
+    else walk_chunk(g0, g1, xys, radii, splats, cam, emit);
     __syncthreads();
     int* dst = counts + (size_t)blockIdx.x * num_tiles + t0;
     for (int j = threadIdx.x; j < tw; j += kBinThreads) dst[j] = hist[j];
@@ -454,6 +559,7 @@ constexpr int kCoarseIdBits = 32 - kCoarseShift;            // ids below 2^27
 #endif
 constexpr int kTwoHopFrom = TS_TWO_HOP_FROM;
 
+template <bool BAL>
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     int n, int chunk, const float* __restrict__ xys, const int* __restrict__ radii,
     const float4* __restrict__ splats, const ts_camera cam, int num_tiles, const int* __restrict__ bases,
@@ -472,9 +578,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_coarse_kernel(
     }
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-    walk_chunk(g0, g1, xys, radii, splats, cam, [&](int t, int i) {
+    auto emit = [&](int t, int i) {
         scratch[atomicAdd(&cursor[t >> kCoarseShift], 1)] = i | ((t & (kCoarseTiles - 1)) << kCoarseIdBits);
-    });
+    };
+    if (BAL) walk_chunk_balanced(g0, g1, xys, radii, splats, cam, emit);
+    else walk_chunk(g0, g1, xys, radii, splats, cam, emit);
 }
 
 #ifndef TS_FINE_THREADS
@@ -891,10 +999,11 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
     const int window = bin_window_tiles(n, nt);
     const int windows = (nt + window - 1) / window;
     const size_t lds = (size_t)window * sizeof(int);
+    // (the load-balanced walk does not pay for the count: 26 -> 28 us on config 3, 111 -> 149 us on config 5)
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_count_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_count_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(chunks, windows), dim3(kBinThreads), lds,
+    hipLaunchKernelGGL(bin_count_kernel<false>, dim3(chunks, windows), dim3(kBinThreads), lds,
                        (hipStream_t)stream, n, chunk, xys, radii,
                        reinterpret_cast<const float4*>(splats), *cam, nt, window, bin_ws);
     return launch_status();
@@ -933,9 +1042,16 @@ int ts_bin_scatter(int32_t n, const float* xys, const int32_t* radii, const floa
     // the second launch costs more than it saves (34 vs 12 us on a 1/8 stripe of config 3)
     if (scratch && n >= kTwoHopFrom && n < (1 << kCoarseIdBits)) {
         const int groups = (nt + kCoarseTiles - 1) >> kCoarseShift;
-        hipLaunchKernelGGL(bin_scatter_coarse_kernel, dim3(chunks), dim3(kBinThreads), (size_t)groups * sizeof(int),
-                           (hipStream_t)stream, n, chunk, xys, radii, reinterpret_cast<const float4*>(splats), *cam,
-                           nt, bin_ws, tile_start, scratch);
+        // load-balanced walk where the caller says a Gaussian covers many tiles (ts_camera.hints & TS_HINT_BALANCED_WALK):
+        // config 5 (16 bounding-box tiles per Gaussian) coarse hop 369 -> 274 us; config 3 (6 tiles) 51 -> 56 us
+        if (TS_BIN_BALANCED && (cam->hints & TS_HINT_BALANCED_WALK))
+            hipLaunchKernelGGL(bin_scatter_coarse_kernel<true>, dim3(chunks), dim3(kBinThreads),
+                               (size_t)groups * sizeof(int), (hipStream_t)stream, n, chunk, xys, radii,
+                               reinterpret_cast<const float4*>(splats), *cam, nt, bin_ws, tile_start, scratch);
+        else
+            hipLaunchKernelGGL(bin_scatter_coarse_kernel<false>, dim3(chunks), dim3(kBinThreads),
+                               (size_t)groups * sizeof(int), (hipStream_t)stream, n, chunk, xys, radii,
+                               reinterpret_cast<const float4*>(splats), *cam, nt, bin_ws, tile_start, scratch);
         hipLaunchKernelGGL(bin_scatter_fine_kernel, dim3(groups), dim3(kFineThreads), 0, (hipStream_t)stream, nt,
                            tile_start, scratch, bucket_ids);
         return launch_status();

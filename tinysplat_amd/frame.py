@@ -64,6 +64,7 @@ SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 _wt = os.environ.get("TS_WIDE_TILES", "auto")
 WIDE_TILES = _wt if _wt == "auto" else int(_wt)
 WIDE_LISTS_FROM = int(os.environ.get("TS_WIDE_LISTS_FROM", "1000"))
+BALANCED_WALK_FROM = float(os.environ.get("TS_BALANCED_WALK_FROM", "10"))     # bounding-box tiles per Gaussian
 _pairs_per_tile = {}    # device index -> bounding-box pairs per 16x16 tile of the most recent frame
 
 
@@ -194,6 +195,10 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
     mode = _list_mode(dev.index, cam.tile_rows * cam.tile_bounds_x)
     cam.wide_tiles = 1 if mode else 0
+    # hint for the scatter: the previous frame's bounding-box tiles per Gaussian (results do not depend on it)
+    prev_i = _pairs_per_tile.get(dev.index)
+    if prev_i is not None and n > 0 and prev_i * cam.tile_rows * cam.tile_bounds_x >= BALANCED_WALK_FROM * n:
+        cam.hints = _lib.HINT_BALANCED_WALK
     ch = 4 if with_depth else 3
     if with_depth:          # channel 3 is composited over background[0], as the reference's depth pass (:86)
         key = (background.data_ptr(), background._version, dev.index)

@@ -168,3 +168,28 @@ def test_exception_between_the_scan_and_the_count_read_does_not_poison_the_next_
             again, _, _ = render_stripe(small, cam, (w, h), DEV, 0, 1)
             assert frame.last_binning[DEV.index].num_intersects == total_small
             assert torch.equal(again, ref)
+
+
+@pytest.mark.parametrize("n,sh,w,h,mult", [(300000, 1, 1280, 720, 3.0), (262144, 0, 640, 360, 6.0)])
+def test_balanced_walk_hint_changes_no_result(n, sh, w, h, mult, monkeypatch):
+    """ts_camera.hints & TS_HINT_BALANCED_WALK: the scatter's coarse hop expands (Gaussian, tile row) items over the
+    lanes instead of looping per Gaussian (csrc/binning.hip: walk_chunk_balanced).  A hint must never change a
+    result: the sorted lists, the image and the gradients are bit for bit those of the per-Gaussian walk."""
+    model, cam = make_scene(n, sh, w, h, seed=31, scale_mult=mult)
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    monkeypatch.setattr(frame, "BALANCED_WALK_FROM", 1e30)
+    ref = _run(model, cam, w, h, True, w_rgb, w_d)
+    ref = _run(model, cam, w, h, True, w_rgb, w_d)               # (the hint looks at the PREVIOUS frame's pair count)
+    listed = int(frame.last_binning[DEV.index].tile_bins[:, 1].max().item())      # tight lists: fewer than I entries
+    ids_ref = frame.last_binning[DEV.index].gaussian_ids_sorted[:listed].clone()
+    bins_ref = frame.last_binning[DEV.index].tile_bins.clone()
+    assert frame.last_binning[DEV.index].cam.hints == 0
+    monkeypatch.setattr(frame, "BALANCED_WALK_FROM", 0.0)
+    got = _run(model, cam, w, h, True, w_rgb, w_d)
+    assert frame.last_binning[DEV.index].cam.hints == 1
+    assert torch.equal(frame.last_binning[DEV.index].tile_bins, bins_ref)
+    assert torch.equal(frame.last_binning[DEV.index].gaussian_ids_sorted[:listed], ids_ref)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    for a, b in zip(got[1], ref[1]):
+        assert torch.equal(a, b)

@@ -726,11 +726,13 @@ def main():
             pmc = collect_pmc(wl)
             _log("PMC passes done" if pmc else "PMC passes unavailable")
             pmc_src = "rocprofv3 --pmc passes of this run" if pmc else None
-        if pmc is None:
+        if pmc is None and not args.no_pmc:          # (the PMC passes' own child runs pass --no-pmc: no counters there)
             tf = ROOT / "profiles" / "pmc_latest.json"
             if tf.exists() and (n, sh, w, h, args.depth) == (1_000_000, 3, 1920, 1080, False):
                 try:
                     pmc = json.loads(tf.read_text())
+                    if not (isinstance(pmc, dict) and all(isinstance(v, dict) for v in pmc.values())):
+                        raise ValueError("not a pmc_per_dispatch record")
                     pmc_src = "profiles/pmc_latest.json (committed; not collected in this run)"
                 except Exception:
                     pmc = None

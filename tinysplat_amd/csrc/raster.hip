@@ -635,6 +635,9 @@ __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
 // values to three registers; the cross-row levels and the two quad levels follow on those.
 //   c0: value 2 * bit2 + bit3 | c1: value 4 + 2 * bit2 + bit3 | c2: value 8 + bit3
 // returns x with lane l holding the wave sum of value 4 * bit4 + 2 * bit2 + bit3 (l < 32) or 8 + bit3 (l >= 32).
+#ifndef TS_FLUSH_SWAP32
+#define TS_FLUSH_SWAP32 1
+#endif
 #ifndef TS_FLUSH_ASM
 #define TS_FLUSH_ASM 1
 #endif
@@ -689,11 +692,22 @@ __device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane) 
     }
     // lane bit 4: odd / even rows exchanged in one issue (v_permlane16_swap), c0 stays in the even rows
     const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0), __float_as_uint(c1), false, false);
-    float d = __uint_as_float(r.x) + __uint_as_float(r.y);
-    d += __shfl_xor(d, 32, 64);                      // lane bit 5
+    const float d = __uint_as_float(r.x) + __uint_as_float(r.y);
+#if TS_FLUSH_SWAP32
+    // c2: the same exchange with itself; lane bit 5: v_permlane32_swap hands the upper half of d and the lower half
+    // of c2 across in one issue, so lanes 0-31 end with d's total and lanes 32-63 with c2's - the same pairs of
+    // summands as the ds_bpermute form below (bit-identical rows) without three trips through the LDS crossbar
+    // (~65 cycles each, two of them dependent) on every row
+    const u2v q = __builtin_amdgcn_permlane16_swap(__float_as_uint(c2), __float_as_uint(c2), false, false);
+    const float e = __uint_as_float(q.x) + __uint_as_float(q.y);
+    const u2v h = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(e), false, false);
+    float x = __uint_as_float(h.x) + __uint_as_float(h.y);
+#else
+    float dd = d + __shfl_xor(d, 32, 64);            // lane bit 5
     c2 += __shfl_xor(c2, 16, 64);
     c2 += __shfl_xor(c2, 32, 64);
-    float x = (lane & 32) ? c2 : d;                  // one register for the two quad levels
+    float x = (lane & 32) ? c2 : dd;                 // one register for the two quad levels
+#endif
     x = dpp_add_t<0x4E, 0xF>(x);
     return dpp_add_t<0xB1, 0xF>(x);
 }
@@ -742,12 +756,6 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
     }
 }
 
-// Replays the `cnt` staged Gaussians of one chunk back to front (backward).
-//   per pixel and block k: T = transmittance behind the Gaussian being replayed, R = T_final *
-//   (v_alpha - bg . v_out) - sum over the Gaussians already replayed of fac * (colour . v_out),
-//   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
-// Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
-// (ra = 1, fac = 0, v_sig = 0) and changes nothing.
 // Replays the `cnt` staged Gaussians of one chunk back to front (backward).
 //   per pixel and block k: T = transmittance behind the Gaussian being replayed, R = T_final *
 //   (v_alpha - bg . v_out) - sum over the Gaussians already replayed of fac * (colour . v_out),

@@ -61,12 +61,23 @@ typedef struct ts_camera {
      * count 16x16 tiles; images and gradients do not depend on the shape (a Gaussian is composited only
      * into the 16x16 tiles of its tile box either way), only the number of list entries does. */
     int32_t wide_tiles;
-    /* performance hints (formerly `reserved`, 0 = none); results never depend on them.
+    /* bits 0..7: performance hints (formerly `reserved`, 0 = none); results never depend on them.
      * TS_HINT_BALANCED_WALK: a Gaussian covers many tiles (>= ~10 bounding-box tiles on average): ts_bin_scatter
-     * expands (Gaussian, tile row) items over the lanes instead of looping per Gaussian. */
+     * expands (Gaussian, tile row) items over the lanes instead of looping per Gaussian.
+     * bits 8..11: LIST SEGMENTS S of the compositing passes (TS_CAM_LIST_SEGMENTS(S), 0 / 1 = off, S <= 8; 16x16
+     * lists only).  For launches of fewer tiles than the GPU has SIMDs, instead of TS_RASTER_SPLIT_BLOCKS in the
+     * BACKWARD pass: ts_raster_fwd* under TS_RASTER_SPLIT_BLOCKS additionally stores the per-pixel state at up to S - 1 boundaries
+     * of every list of >= 256 entries behind final_Ts, which must then hold ts_final_planes(S, channels) planes of
+     * rows*W floats, and ts_raster_bwd* WITHOUT the split flag replays every list as up to S independent work items
+     * (one row per pair, the plain ts_reduce_partials; the forward launch must have been a split one).  Same image; gradients equal to the uncut pass's up to
+     * rounding (a segment starts from the forward pass's own transmittance).  With TS_RASTER_SPLIT_BLOCKS, wide
+     * tiles or narrow waves ts_raster_bwd* ignores the field. */
     int32_t hints;
 } ts_camera;
 #define TS_HINT_BALANCED_WALK 1
+#define TS_CAM_LIST_SEGMENTS(s) (((s) & 15) << 8)
+/* float planes (rows*W each) final_Ts must hold for S list segments: 1, or 1 + (S-1)(1+channels) + channels */
+int32_t ts_final_planes(int32_t list_segments, int32_t channels);
 /* tiles (= lists) of a launch: tile_rows * tile_bounds_x, or tile_rows * ceil(tile_bounds_x / 2) when wide */
 int32_t ts_num_tiles(const ts_camera* cam_host);
 

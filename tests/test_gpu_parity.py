@@ -622,6 +622,43 @@ def test_split_blocks_mapping_matches_one_wave_per_tile():
         assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
 
 
+@pytest.mark.parametrize("segs", ["auto", 3])
+def test_list_segments_replace_split_blocks_in_backward(segs, monkeypatch):
+    """TS_LIST_SEGMENTS (an option of small launches, off by default; ts_camera.hints bits 8..11): the split forward
+    pass also keeps the per-pixel state at the segment boundaries and the backward pass replays every list as up to
+    S independent one-wave work items instead of four waves per tile.  Image, depth and the sorted lists are
+    bitwise those of the default path; gradients agree with it to rounding; a frame of one-chunk lists stays split."""
+    from tinysplat_amd import frame
+    n, w, h = 120000, 400, 272          # 25 x 17 = 425 tiles, image not a multiple of 16
+    model, cam = scene_args(n, 1, w, h, seed=43, scale_mult=2.0)
+    g = torch.Generator().manual_seed(44)
+    wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    res, used = [], []
+    for opt in (1, segs):
+        monkeypatch.setattr(frame, "LIST_SEGMENTS", opt)
+        md = model.to(DEV).requires_grad_(True)
+        rgb, ex = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), 1)
+        ((rgb * wr).sum() + (ex["depth"] * wd).sum()).backward()
+        used.append(frame.last_segments[0])
+        b = frame.last_binning[0]
+        res.append([rgb.detach(), ex["depth"].detach(), b.gaussian_ids_sorted[:int(b.tile_bins[:, 1].max())].clone(), ex["xys"].grad]
+                   + [p.grad for p in md.parameters()])
+    pairs = int(frame.last_binning[0].num_intersects) / 425
+    assert pairs >= frame.LIST_SEGMENTS_FROM, pairs            # the scene is one the option applies to
+    assert used[0] == 1 and used[1] == (8 if segs == "auto" else segs), used
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][3:], res[1][3:]):
+        tol = 2e-6 * max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
+    # lists of one chunk: the backward pass stays split whatever was asked for
+    model, cam = scene_args(3000, 0, 256, 256, seed=45, scale_mult=1.0)
+    md = model.to(DEV).requires_grad_(True)
+    rgb, ex = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (256, 256), 0)
+    rgb.sum().backward()
+    assert frame.last_segments[0] == 1
+
+
 def test_tight_binning_stress_anisotropic_faint_and_opaque():
     """Needle-like and huge Gaussians, opacities from just above 1/255 to > 0.999, centres on and off
     the image: the tight lists must still give bitwise the bounding-box result."""

@@ -115,6 +115,16 @@ def test_all_ranks_in_one_process_equal_the_single_frame(world, depth, n, sh, w,
     _check_simulated(n, sh, w, h, mult, depth, world, stripes)
 
 
+def test_list_segments_in_the_stripes_of_a_sharded_frame(monkeypatch):
+    """TS_LIST_SEGMENTS=auto (frame.py; off by default): the stripes of a sharded frame - split launches - replay
+    their lists as segments in the backward pass.  Same image bit for bit, gradients to the same bar."""
+    from tinysplat_amd import frame
+    monkeypatch.setattr(frame, "LIST_SEGMENTS", "auto")
+    frame.last_segments.clear()
+    _check_simulated(150000, 2, 640, 368, 2.0, True, 4)
+    assert frame.last_segments.get(0, 1) > 1           # the stripes (230 tiles each) did take the segmented pass
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_config3_full_size_sharded_equals_single_frame(world):
     """BASELINE configs[3]: 1 M Gaussians, SH 3, 1920x1080, sharded over 2 and 8 ranks (all ranks' stages in this

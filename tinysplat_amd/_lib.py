@@ -88,6 +88,7 @@ SIGNATURES = {
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sort_tiles_above": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),
+    "ts_final_planes": (c_int32, [c_int32, c_int32]),
     "ts_colors_pack_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
                                      _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),

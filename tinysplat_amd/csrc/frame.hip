@@ -62,6 +62,13 @@ inline int32_t* mapped_pointer(int32_t* host) {
     last_dev = static_cast<int32_t*>(dev);
     return last_dev;
 }
+// list segments (ts_camera.hints bits 8..11) replace the split blocks in the BACKWARD pass of a small launch
+inline bool segmented(const ts_frame* f) {
+    return ((f->cam.hints >> 8) & 15) > 1 && !f->cam.wide_tiles && !(f->flags & TS_FRAME_NARROW_WAVES);
+}
+inline int bwd_split(const ts_frame* f) {
+    return ((f->flags & TS_FRAME_SPLIT) && !segmented(f)) ? TS_RASTER_SPLIT_BLOCKS : 0;
+}
 inline int raster_flags(const ts_frame* f) {
     return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
            ((f->flags & TS_FRAME_NARROW_WAVES) ? TS_RASTER_NARROW_WAVES : 0);
@@ -143,15 +150,15 @@ int ts_frame_bwd_composite(const ts_frame* f, void* stream) {
     if (bad(f) || f->num_intersects < 0) return TS_E_BADARG;
     const bool planes = (f->flags & TS_FRAME_PLANES) != 0;
     TS_TRY(ts_raster_bwd_planes(f->channels,
-                                (raster_flags(f) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(f->flag_gen),
+                                ((raster_flags(f) & ~(TS_RASTER_CLAMP_RGB | TS_RASTER_SPLIT_BLOCKS)) | bwd_split(f)) |
+                                    TS_RASTER_FLAG_GEN(f->flag_gen),
                                 f->num_intersects, &f->cam, f->tile_bins, f->gaussian_ids_sorted, f->splats,
                                 f->background, f->final_Ts, f->final_index, f->v_out_img,
                                 planes ? f->v_out_depth : nullptr, planes ? 1 : 0, nullptr, f->clamp_mask, f->partials,
                                 f->row_flags, stream));
     const bool stripe = (f->flags & TS_FRAME_STRIPE) != 0;
     return ts_reduce_partials(f->n, f->channels,
-                              TS_RASTER_LOGIT_OPACITY | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
-                                  TS_RASTER_FLAG_GEN(f->flag_gen),
+                              TS_RASTER_LOGIT_OPACITY | bwd_split(f) | TS_RASTER_FLAG_GEN(f->flag_gen),
                               f->num_tiles_hit, f->cum_tiles_hit, f->partials, f->row_flags, f->splats, f->v_xy,
                               f->v_conic, f->v_colors, f->v_opacity, f->channels == 4 ? f->v_depth : nullptr,
                               stripe ? f->sh_mask : nullptr, stream);
@@ -210,13 +217,14 @@ int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* s
 int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream) {
     TsRange range_("ts_shard_stripe_bwd");
     if (bad(fs) || fs->num_intersects < 0) return TS_E_BADARG;
-    TS_TRY(ts_raster_bwd(fs->channels, (raster_flags(fs) & ~TS_RASTER_CLAMP_RGB) | TS_RASTER_FLAG_GEN(fs->flag_gen),
+    TS_TRY(ts_raster_bwd(fs->channels,
+                         ((raster_flags(fs) & ~(TS_RASTER_CLAMP_RGB | TS_RASTER_SPLIT_BLOCKS)) | bwd_split(fs)) |
+                             TS_RASTER_FLAG_GEN(fs->flag_gen),
                          fs->num_intersects, &fs->cam, fs->tile_bins, fs->gaussian_ids_sorted, fs->splats,
                          fs->background, fs->final_Ts, fs->final_index, fs->v_out_img, nullptr, fs->clamp_mask,
                          fs->partials, fs->row_flags, stream));
     return ts_reduce_partials_rows(fs->n, fs->channels,
-                                   ((fs->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
-                                       TS_RASTER_FLAG_GEN(fs->flag_gen),
+                                   bwd_split(fs) | TS_RASTER_FLAG_GEN(fs->flag_gen),
                                    fs->num_tiles_hit, fs->cum_tiles_hit, fs->partials, fs->row_flags, fs->splats,
                                    grad_rows, stream);
 }

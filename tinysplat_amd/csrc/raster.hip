@@ -50,6 +50,9 @@ namespace {
 #ifndef TS_FWD_MIN_WAVES
 #define TS_FWD_MIN_WAVES 1             // __launch_bounds__ 2nd argument = min waves per SIMD
 #endif
+#ifndef TS_FWD_MIN_WAVES_RGB
+#define TS_FWD_MIN_WAVES_RGB 5         // the 16x16, three-channel forward kernel keeps its five waves per SIMD (<= 96 VGPRs)
+#endif
 #ifndef TS_BWD_MIN_WAVES
 #define TS_BWD_MIN_WAVES 1
 #endif
@@ -335,6 +338,60 @@ using mask64 = unsigned long long;
 #define TS_BALLOT(c) __builtin_amdgcn_ballot_w64(c)          // lane condition -> 64-bit scalar mask
 #define TS_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)    // scalar mask -> lane condition
 
+// LIST SEGMENTS (bits 8..11 of ts_camera.hints = S > 1; 16x16 lists).  The backward pass of a tile is a chain over
+// its sorted list.  A launch of a few hundred tiles - a rank's stripe of a sharded frame, a small image - cannot
+// fill 1 024 SIMDs with one chain per tile; four waves per tile (TS_RASTER_SPLIT_BLOCKS) fill them, but every one
+// of the four walks and stages the WHOLE list for a quarter of the pixels and writes its own gradient row.  The
+// chain can be CUT instead: the forward pass keeps, per pixel, its state at the segment boundaries b_s - the
+// transmittance T_s in front of entry b_s and the colour C_s accumulated by the entries before it - plus the final
+// colour sum C_fin, and the replay of the segment [b_s, b_s+1) starts from
+//     T = T_(s+1),   R = T_fin (v_alpha - bg . v_out) - v_out . (C_fin - C_(s+1))
+// which is what walking the entries behind it would have left (S_behind fac c . v_out = v_out . sum of their colour
+// contributions), with the forward pass's own T instead of T_fin divided back through hundreds of (1 - alpha).
+// A tile becomes up to S independent work items of ONE wave each over all four blocks; every (tile, Gaussian)
+// belongs to exactly one of them, so there is one row per pair and the reduction is the plain one.  Boundaries are
+// a function of the list range alone (equal entry counts, multiples of 64: seg_bound), so both passes - and the
+// four waves of a split forward launch - agree on them without a table.  The gradients differ from the uncut
+// pass's by rounding only (measured <= 8e-7 of the tensor's largest entry on config 3).
+// On a FULL frame (8 160 tiles) segments gain nothing (profiles/HISTORY.md, round 4: the machine is saturated and
+// every extra item re-reads its pixel state); callers enable them for launches that would otherwise be split.
+// Layout behind final_Ts (P = pixels of the launch, float planes; ts_final_planes):
+//   plane 0: T_fin | s = 1..S-1: planes 1 + (s-1)(1+CH) + {0: T_s, 1+c: C_s[c]} | planes 1 + (S-1)(1+CH) + c: C_fin[c]
+#define TS_CAM_SEGS(cam) (((cam).hints >> 8) & 15)
+#ifndef TS_SEG_MIN_LIST
+#define TS_SEG_MIN_LIST 65
+#endif
+constexpr int kSegMinList = TS_SEG_MIN_LIST;      // shorter lists (one chunk) stay one segment
+constexpr int kSegMax = 8;
+// Boundary s (1 .. S-1) of a list of `list_len` entries, in entries from its start (a multiple of 64), or a value
+// >= list_len where the list has fewer segments; boundary 0 is the start.  Integer arithmetic on the list length
+// alone: both passes (and the four waves of a split forward launch) compute the same values.  The FRONT segments are
+// the expensive ones - every pixel is still alive there, late in the list most (Gaussian, block) pairs are culled -
+// so the boundaries are not equidistant (TS_SEG_SHAPE: 0 = equal counts, 1 = halfway, 2 = quadratic).
+#ifndef TS_SEG_SHAPE
+#define TS_SEG_SHAPE 2
+#endif
+#ifndef TS_SEG_CAP_CHUNKS
+#define TS_SEG_CAP_CHUNKS 0
+#endif
+__device__ __forceinline__ int seg_bound(int list_len, int S, int s) {
+    if (S <= 1 || list_len < kSegMinList) return 0x7fffff00;
+    const int C = TS_SEG_CAP_CHUNKS > 0 ? min((list_len + 63) >> 6, TS_SEG_CAP_CHUNKS) : (list_len + 63) >> 6;
+    int b = 0;
+    for (int k = 1; k <= s; ++k) {                 // S <= 8: a few scalar operations
+        int f;
+        if (TS_SEG_SHAPE == 0) f = (C * k + S - 1) / S;
+        else if (TS_SEG_SHAPE == 1) f = (C * (k * k + k * S) + 2 * S * S - 1) / (2 * S * S);
+        else f = (C * k * k + S * S - 1) / (S * S);
+        b = max(f, b + 1);                         // strictly increasing, at least one chunk per segment
+    }
+    return b << 6;
+}
+__device__ __forceinline__ size_t seg_plane_stride(const ts_camera& cam) {
+    const int rows = min(16 * cam.tile_rows, cam.img_height - 16 * cam.tile_row0);
+    return (size_t)cam.img_width * (size_t)max(rows, 0);
+}
+
 // Composites the `cnt` staged Gaussians of one chunk into the wave's tile (forward).
 //   per pixel and block k: T > 0 = transmittance of an unfinished pixel; T < 0 = finished (or
 //   outside the image) with final transmittance |T|; fidx = list index of the last Gaussian
@@ -410,7 +467,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 // sorted by ts_sort_tiles_above before this launch).  The per-tile sort on its own is latency-bound (VALU 40 %, LDS
 // 59 % busy on config 3); inside this VALU-bound kernel its stalls are filled by other tiles' compositing.
 template <int CH, bool SPLIT, int NBX, bool WL, bool SORT = false>
-__global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
+__global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_MIN_WAVES_RGB : TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const int* __restrict__ bucket_ids, const float* __restrict__ depths,
     int* ids_rw, const float4* __restrict__ splats,
@@ -502,8 +559,41 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     }
     if (range.x + 64 + lane < range.y) id_next = ids[range.x + 64 + lane];
 
+    // list segments: this pass leaves the per-pixel state at the segment boundaries for the backward pass
+    // (only the SPLIT launches carry this: each of the four waves keeps the pixels of its block; the full-frame kernel
+    // has no registers to spare for it, and segments gain nothing there)
+    constexpr bool kSegsF = SPLIT && NBX == 2 && !WL;
+    const int S_seg = max(1, min(TS_CAM_SEGS(cam), kSegMax));
+    const bool seg_on = kSegsF && final_Ts != nullptr && S_seg > 1 && range.y - range.x >= kSegMinList;
+    const size_t plane = seg_plane_stride(cam);
+    int next_ck = seg_on ? range.x + seg_bound(range.y - range.x, S_seg, 1) : 0x7fffffff;      // list index of the next boundary
+    int ck = 1;                                                      // its number (1 .. S-1)
+    auto store_ck = [&](int number) {
+        // (the pixel addresses are derived from an opaque zero: hoisted out of the list loop they would cost the
+        // kernel eight VGPRs for three uses per tile - and its fifth wave per SIMD)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const int py_ = py0 + opaque;
+        float* base_p = final_Ts + plane * (size_t)(1 + (number - 1) * (1 + CH));
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (!inside[k]) continue;
+            const size_t pix = (size_t)(py_ + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
+            base_p[pix] = __builtin_fabsf(T[k]);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) base_p[plane * (size_t)(1 + c) + pix] = acc[k][c];
+        }
+    };
+
     for (int base = range.x; base < range.y && live != 0; base += 64) {
         TS_SEG_T0(tseg_p);
+        if constexpr (kSegsF) {
+            if (base == next_ck) {                   // wave-uniform: a segment boundary (never the list's first entry)
+                store_ck(ck);
+                ++ck;
+                next_ck = ck < S_seg ? range.x + seg_bound(range.y - range.x, S_seg, ck) : 0x7fffffff;
+            }
+        }
         const int i = base + lane;
         const bool have = i < range.y;
 #if TS_LDS_DMA
@@ -550,6 +640,23 @@ __global__ __launch_bounds__(kThreads, TS_FWD_MIN_WAVES) void raster_fwd_kernel(
         else
             fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc TS_SEG_ARG);
         TS_WAVE_SYNC();
+    }
+
+    if constexpr (kSegsF) if (seg_on) {
+        // boundaries behind the entry this wave stopped at: its pixels are finished there (no segment replays them:
+        // fidx lies in front), the planes only have to hold finite numbers
+        for (; ck < S_seg && next_ck < range.y; ++ck, next_ck = range.x + seg_bound(range.y - range.x, S_seg, min(ck, S_seg - 1)))
+            store_ck(ck);
+        {
+            float* fin = final_Ts + plane * (size_t)(1 + (S_seg - 1) * (1 + CH));      // C_fin, without the background
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (!inside[k]) continue;
+                const size_t pix = (size_t)(py0 + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
+#pragma unroll
+                for (int c = 0; c < CH; ++c) fin[plane * (size_t)c + pix] = acc[k][c];
+            }
+        }
     }
 
     float bg[CH];
@@ -894,10 +1001,17 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
     __shared__ float4 rect_all[kBwdWaves][NB];
     __shared__ float4 raw_all[TS_LDS_DMA ? kBwdWaves : 1][3 * 64];   // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int units = SPLIT ? NB * num_tiles : num_tiles;
+    // list segments (see kSegQuantum): S work items per tile, item `seg` replays the entries [sb, se) of the list
+    constexpr bool kSegs = !SPLIT && NBX == 2 && !WL;
+    const int S_seg = kSegs ? max(1, min(TS_CAM_SEGS(cam), kSegMax)) : 1;
+    const int units = SPLIT ? NB * num_tiles : num_tiles * S_seg;
     const int unit = xcd_tile_group((units + kBwdWaves - 1) / kBwdWaves) * kBwdWaves + wave;
     if (unit >= units) return;
-    const int tile = SPLIT ? unit / NB : unit;
+    const int tile = SPLIT ? unit / NB : unit / S_seg;
+    // the segment order rotates from tile to tile: the front segments are the expensive ones (every pixel is still
+    // alive there), and one-wave workgroups land on a CU's SIMDs in dispatch order - with seg = unit % S and S = 4 one
+    // SIMD of every CU would get all the front segments (raster_bwd 525 -> 856 us, measured)
+    const int seg = SPLIT ? 0 : (int)(((unsigned)(unit % S_seg) + (((unsigned)tile * 2654435761u) >> 20)) % (unsigned)S_seg);
     const int only = SPLIT ? unit % NB : -1;      // SPLIT: this wave owns block `only`, row slot*NB + only
     float4* rects = rect_all[wave];
     const int tbx = NBX == 2 ? cam.tile_bounds_x : (cam.tile_bounds_x + 1) >> 1;
@@ -905,7 +1019,23 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
     const int list = WL ? (ty - cam.tile_row0) * ((tbx + 1) >> 1) + (tx >> 1) : tile;
     const int2 range = reinterpret_cast<const int2*>(tile_bins)[list];
     if (range.y <= range.x) return;
-    TS_WAVE_CLOCK(1, unit, range.y - range.x);
+    int sb = range.x, se = range.y;
+    bool front = false;                           // entries lie behind this segment: it starts from a checkpoint
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    int id_next = 0;
+    if (kSegs && S_seg > 1) {
+        const int len = range.y - range.x;
+        if (len < kSegMinList) {
+            if (seg != 0) return;                  // a short list is one segment
+        } else {
+            sb = range.x + (seg > 0 ? seg_bound(len, S_seg, seg) : 0);
+            if (sb >= range.y) return;
+            se = seg + 1 < S_seg ? min(range.x + seg_bound(len, S_seg, seg + 1), range.y) : range.y;
+            front = se < range.y;
+        }
+    }
+    TS_WAVE_CLOCK(1, unit, se - sb);
     float4* lds = lds_all[wave];
     const int px0 = tx * (8 * NBX) + (lane & 7), py0 = ty * 16 + (lane >> 3);
     // sample positions of the lane's pixel in the block columns / the upper and lower block row
@@ -940,6 +1070,18 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
             fidx[k] = final_index[pix];
             T[k] = final_Ts[pix];
             float dotbg = 0.0f;
+            float cb[CH];                          // colour the entries BEHIND this segment contributed (front only)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) cb[c] = 0.0f;
+            float T_start = T[k];
+            if (kSegs && front) {
+                const size_t plane = seg_plane_stride(cam);
+                const float* ckp = final_Ts + plane * (size_t)(1 + seg * (1 + CH));            // boundary seg + 1
+                const float* fin = final_Ts + plane * (size_t)(1 + (S_seg - 1) * (1 + CH));
+                T_start = ckp[pix];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) cb[c] = fin[plane * (size_t)c + pix] - ckp[plane * (size_t)(1 + c) + pix];
+            }
             const int pass = clamp_mask ? clamp_mask[pix] : 7;   // backward of the fused clamp(max=1)
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -952,12 +1094,20 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
                 dotbg += bg[c] * vo[k][c];
             }
             const float va = v_out_alpha ? v_out_alpha[pix] : 0.0f;
-            R[k] = T[k] * (va - dotbg);
+            R[k] = T[k] * (va - dotbg);             // T[k] = T_final here
+            if (kSegs && front) {
+                float behind = cb[0] * vo[k][0];
+#pragma unroll
+                for (int c = 1; c < CH; ++c) behind = __builtin_fmaf(cb[c], vo[k][c], behind);
+                R[k] -= behind;
+                T[k] = T_start;                     // transmittance behind the segment's last entry
+            }
         }
         bmax[k] = wave_max_int(fidx[k]);            // last list index any pixel of block k used
         fmax = max(fmax, bmax[k]);
     }
-    const int last = min(range.y - 1, fmax);
+    const int last = min(se - 1, fmax);
+    if (last < sb) return;                          // the forward pass stopped every pixel before this segment
 
     // per-lane sums over its (up to) NB pixels for the Gaussian being replayed, updated in place
     // by the block bodies and zeroed after each row is written:
@@ -967,13 +1117,8 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
     for (int c = 0; c < 6 + CH; ++c) acc[c] = 0.0f;
 
     // same software pipeline as the forward kernel, walking the list back to front
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* raw = raw_all[TS_LDS_DMA ? wave : 0];
-#if !TS_LDS_DMA
-    float4 n0 = zero4, n1 = zero4, n2 = zero4;
-#endif
-    int id_next = 0;
-    if (last - lane >= range.x) {
+    if (last - lane >= sb) {
         const int g = ids_sorted[last - lane];
 #if TS_LDS_DMA
         dma_record(splats, g, raw);
@@ -981,26 +1126,26 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
         n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
 #endif
     }
-    if (last - 64 - lane >= range.x) id_next = ids_sorted[last - 64 - lane];
+    if (last - 64 - lane >= sb) id_next = ids_sorted[last - 64 - lane];
 
-    for (int hi = last; hi >= range.x; hi -= 64) {
+    for (int hi = last; hi >= sb; hi -= 64) {
         TS_SEG_T0(tseg_p);
         const int i = hi - lane;
-        const bool have = i >= range.x;
+        const bool have = i >= sb;
 #if TS_LDS_DMA
         TS_DMA_WAIT();                               // this chunk's records have landed (and id_next has arrived)
         const float4 q0 = have ? raw[lane] : zero4, q1 = have ? raw[64 + lane] : zero4,
                      q2 = have ? raw[128 + lane] : zero4;
         TS_LDS_WAIT();                               // read out before the next chunk's records may overwrite them
-        if (i - 64 >= range.x) dma_record(splats, id_next, raw);
+        if (i - 64 >= sb) dma_record(splats, id_next, raw);
 #else
         const float4 q0 = n0, q1 = n1, q2 = n2;
-        if (i - 64 >= range.x) {
+        if (i - 64 >= sb) {
             const int g = id_next;
             n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
         }
 #endif
-        if (i - 128 >= range.x) id_next = ids_sorted[i - 128];
+        if (i - 128 >= sb) id_next = ids_sorted[i - 128];
         int blocks;
         {   // rectangle of the pixels whose forward list reaches into this chunk (fidx >= chunk low)
             bool sel[NB];
@@ -1038,7 +1183,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
         }
         TS_WAVE_SYNC();
         TS_STAT(2, cnt);
-        TS_STAT(7, min(64, hi - range.x + 1));
+        TS_STAT(7, min(64, hi - sb + 1));
         TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
             bwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
@@ -1181,6 +1326,11 @@ int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer 
 }
 #endif
 
+int32_t ts_final_planes(int32_t list_segments, int32_t channels) {
+    if (list_segments <= 1) return 1;
+    return 1 + (min(list_segments, kSegMax) - 1) * (1 + channels) + channels;
+}
+
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
                   const int32_t* gaussian_ids_sorted, const float* splats, const float* background,
                   float* out_img, float* final_Ts, int32_t* final_index, uint8_t* clamp_mask,
@@ -1288,7 +1438,9 @@ int ts_raster_bwd_planes(int32_t channels, int32_t flags, int64_t num_intersects
     }
     const long long isects_tagged = (long long)(((unsigned long long)(gen ? gen : 1) << 56) |
                                                 ((unsigned long long)num_intersects & 0x00ffffffffffffffull));
-    const int units = split ? (wide ? 8 : 4) * nt : nt;
+    if (TS_CAM_SEGS(*cam) < 0 || TS_CAM_SEGS(*cam) > kSegMax) return TS_E_BADARG;
+    const int segs = (!split && !wide && !narrow && TS_CAM_SEGS(*cam) > 1) ? TS_CAM_SEGS(*cam) : 1;
+    const int units = split ? (wide ? 8 : 4) * nt : nt * segs;
     const int grid = 8 * (((units + kBwdWaves - 1) / kBwdWaves + 7) / 8);      // see xcd_tile_group
     const float4* sp = reinterpret_cast<const float4*>(splats);
 #define TS_LAUNCH_BWD(C, S, X, L)                                                                  \

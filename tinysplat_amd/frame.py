@@ -43,6 +43,52 @@ TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 # one wave per tile such launches cannot hide any latency.  0 disables.
 SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 
+# LIST SEGMENTS in the backward pass of such a launch (bits 8..11 of ts_camera.hints, csrc/raster.hip: LIST SEGMENTS) -
+# an OPTION, off by default (TS_LIST_SEGMENTS=auto or 2..8 switches it on): the (split) forward pass also leaves the
+# per-pixel state at up to S - 1 boundaries of every list of two chunks or more, and the backward pass replays the
+# segments as independent work items of one wave over the whole tile - instead of four waves per tile that each walk
+# and stage the WHOLE list for a quarter of the pixels and write a gradient row of their own.  "auto": as many
+# segments (2 .. 8) as bring the launch to ~8 192 work items (two rounds of raster_bwd's wave slots).
+# A list of one chunk (<= 64 entries) cannot be cut, and a launch of such lists is better off split: the BACKWARD pass
+# decides - segments when the frame averages >= LIST_SEGMENTS_FROM bounding-box pairs per tile (the frame's own pair
+# count, known by then - the same frame always takes the same path; ~0.65 of them are listed), split blocks otherwise.  Measured on MI355X, raster_bwd +
+# reduce_partials, split -> 8 segments (profiles/r04u_list_segments_small_launches.txt): a 1/8 stripe of config 3
+# (1 020 tiles, ~560 entries per list) 136 + 51 -> 96 + 30 us (raster_fwd 85 -> 91 for the boundary stores);
+# 512x512 / 200 k (295 per list) 93 + 15 -> 80 + 10; 640x360 / 100 k with depth 69 -> 65; 256x256 / 10 k (lists of
+# one chunk) 17 -> 33 - hence the threshold.
+# Why it is not the default: the image is bitwise the split pass's, but a segment starts from
+#     R = T_fin (v_alpha - bg . v_out) - v_out . (C_fin - C_s)
+# with C_fin, C_s the forward pass's running colour sums, so what lies BEHIND a segment is known to a rounding of
+# |C| instead of a rounding of itself: gradients agree with the uncut pass to <= 8e-7 of a tensor's largest entry,
+# yet on needle scenes (tools/fuzz_frame.py, seed 10) the share of entries within 1e-5 max(1, |ref entry|) of the
+# oracle drops from 99.9 % to 98.2 % - below the 99 % the checker asks for.  On a full frame segments gain nothing
+# either way (profiles/HISTORY.md, round 4) and are never used.
+_ls = os.environ.get("TS_LIST_SEGMENTS", "1")
+LIST_SEGMENTS = _ls if _ls == "auto" else max(1, min(8, int(_ls)))
+LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
+
+
+def _list_segments(tiles16: int, mode: int, split: bool) -> int:
+    """segments the (split) forward pass prepares for: 1 = none"""
+    if mode != 0 or not split or tiles16 <= 0:
+        return 1
+    if LIST_SEGMENTS != "auto":
+        return int(LIST_SEGMENTS)
+    return max(2, min(8, 8192 // tiles16))
+
+
+last_segments = {}      # device index -> list segments of the most recent backward pass (1 = none; tests, tools)
+
+
+def backward_segments(cam, segs: int, total: int, dev_index: int = 0) -> int:
+    """the backward pass's choice (see above): ``segs``, or 1 with the field of ``cam`` cleared -> split blocks"""
+    if segs > 1 and total >= LIST_SEGMENTS_FROM * cam.tile_rows * cam.tile_bounds_x:
+        last_segments[dev_index] = segs
+        return segs
+    cam.hints &= ~0xF00
+    last_segments[dev_index] = 1
+    return 1
+
 # WIDE LISTS: the frame path bins, scatters and sorts on 32x16 tiles - two horizontally adjacent 16x16 tiles
 # as one list (ts_camera.wide_tiles; 0.73x the list entries on the random scenes, longer lists for the sort
 # networks) - and composites with ONE WAVE PER 16x16 TILE as before, each wave walking the list of the wide
@@ -173,7 +219,7 @@ def _total_slot(dev: torch.device):
 
 class _Frame:
     """Buffers of one frame plus the ``ts_frame`` struct that points at them."""
-    __slots__ = ("fr", "cam", "n", "nb", "ch", "w", "h", "num_tiles", "total", "split", "keep",
+    __slots__ = ("fr", "cam", "n", "nb", "ch", "w", "h", "num_tiles", "total", "split", "segs", "keep",
                  "wf", "tile_bins", "ids", "bucket_ids", "out_img", "out_depth", "planes", "xys", "radii", "nth", "cum",
                  "inputs", "bg")
 
@@ -222,6 +268,10 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
+    segs = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else 1
+    cam.hints = (cam.hints & ~0xF00) | ((segs if segs > 1 else 0) << 8)
+    F.segs = segs
+    fin_planes = 1 + (segs - 1) * (1 + ch) + ch if segs > 1 else 1          # ts_final_planes
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()
     if cur != dev.index:
@@ -238,7 +288,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         px = rows * w
         # (the colour stage keeps the colours in registers - ts_colors_pack_fwd - so no colors[n,3] section exists)
         sizes = [48 * m, 8 * m, 12 * m, 0, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
-                 8 * max(num_tiles, 1)] + ([m, 4 * px, 4 * px, px] if keep else [])
+                 8 * max(num_tiles, 1)] + ([m, 4 * px * fin_planes, 4 * px, px] if keep else [])
         offs, off = [], 0
         for sz in sizes:
             offs.append(off)
@@ -426,8 +476,13 @@ def _steps_composite(lib, fr, s):
           fr.out_depth if fr.flags & 64 else None, fr.final_Ts, fr.final_index, fr.clamp_mask, s)
 
 
+def segmented(cam) -> bool:
+    """list segments replace the split blocks in the backward pass (csrc/frame.hip: segmented)"""
+    return ((cam.hints >> 8) & 15) > 1 and not cam.wide_tiles
+
+
 def _steps_bwd_composite(lib, fr, s):
-    split = 4 if fr.flags & 2 else 0
+    split = 4 if (fr.flags & 2 and not segmented(fr.cam)) else 0
     gen = (fr.flag_gen & 0xff) << 8
     planes = 1 if fr.flags & 64 else 0
     _call("ts_raster_bwd", lib.ts_raster_bwd_planes, fr.channels, split | (fr.flags & 8) | gen, fr.num_intersects, fr.cam,
@@ -494,7 +549,8 @@ class _RenderFrame(torch.autograd.Function):
             if single:
                 v_xy = torch.empty((n, 2), **f32)
                 v_opac = torch.empty(tuple(ctx.opacity_shape), **f32)
-            rows = max(F.total, 1) * (4 if F.split else 1)
+            F.segs = backward_segments(fr.cam, F.segs, F.total, dev.index)
+            rows = max(F.total, 1) * (4 if (F.split and F.segs <= 1) else 1)
             partials = torch.empty((rows, _lib.PARTIAL_ROW_FLOATS), **f32)
             row_flags, fr.flag_gen = row_flags_for(dev, rows)
             _mark("bwd:flat+partials+flags")

@@ -195,7 +195,7 @@ class _Owner:
 
 
 class _Stripe:
-    __slots__ = ("m", "cam", "fr", "ws", "split", "mode", "bucket", "total", "num_tiles", "tile_bins", "nth", "cum",
+    __slots__ = ("m", "cam", "fr", "ws", "split", "segs", "mode", "bucket", "total", "num_tiles", "tile_bins", "nth", "cum",
                  "bg", "records")
 
 
@@ -271,6 +271,9 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     cam.wide_tiles = 1 if S.mode else 0
     S.cam = cam
     S.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
+    S.segs = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split) if keep else 1
+    cam.hints = (cam.hints & ~0xF00) | ((S.segs if S.segs > 1 else 0) << 8)
+    fin_planes = int(lib.ts_final_planes(S.segs, ch))
     num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
     S.num_tiles = num_tiles
     rows = _stripe_rows(cam)
@@ -280,7 +283,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     nscan, nbin = int(lib.ts_scan_ws_ints(m)), int(lib.ts_bin_ws_ints(m, num_tiles))
     #   xys | depths | radii | nth | cum | splats | scan_ws | bin_ws | tile_bins | final_Ts | final_index | clamp_mask
     S.ws, ptr, offs = _carve(dev, [8 * mm, 4 * mm, 4 * mm, 4 * mm, 4 * mm, 48 * mm, 4 * nscan, 4 * nbin,
-                                   8 * max(num_tiles, 1)] + ([4 * px, 4 * px, px] if keep else []))
+                                   8 * max(num_tiles, 1)] + ([4 * px * fin_planes, 4 * px, px] if keep else []))
     S.nth = _view(S.ws, offs[3], torch.int32, m, (m,))
     S.cum = _view(S.ws, offs[4], torch.int32, m, (m,))
     S.tile_bins = _view(S.ws, offs[8], torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
@@ -388,18 +391,21 @@ def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
     """Compositing backward of the stripe -> one gradient row per imported record [m, 12]."""
     f32 = dict(dtype=torch.float32, device=dev)
     m, fr = S.m, S.fr
-    rows_n = max(S.total, 1) * (4 if S.split else 1)
+    S.segs = _frame.backward_segments(fr.cam, S.segs, S.total, dev.index)
+    S.cam.hints = fr.cam.hints
+    bwd_split = S.split and S.segs <= 1              # list segments replace the split blocks in this pass
+    rows_n = max(S.total, 1) * (4 if bwd_split else 1)
     partials = torch.empty((rows_n, _lib.PARTIAL_ROW_FLOATS), **f32)
     row_flags, fr.flag_gen = _frame.row_flags_for(dev, rows_n)
     grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
     fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
     if kernel_timer.enabled:
         gen = (fr.flag_gen & 0xff) << 8
-        rflags = (4 if S.split else 0) | (8 if S.mode == 2 else 0) | gen
+        rflags = (4 if bwd_split else 0) | (8 if S.mode == 2 else 0) | gen
         _call("ts_raster_bwd", lib.ts_raster_bwd, ch, rflags, S.total, S.cam, fr.tile_bins, fr.gaussian_ids_sorted,
               fr.splats, fr.background, fr.final_Ts, fr.final_index, fr.v_out_img, None, fr.clamp_mask, fr.partials,
               fr.row_flags, s)
-        _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, (4 if S.split else 0) | gen, fr.num_tiles_hit,
+        _call("ts_reduce_partials_rows", lib.ts_reduce_partials_rows, m, ch, (4 if bwd_split else 0) | gen, fr.num_tiles_hit,
               fr.cum_tiles_hit, fr.partials, fr.row_flags, fr.splats, grad_rows.data_ptr(), s)
     else:
         _lib.check(lib.ts_shard_stripe_bwd(ctypes.byref(fr), grad_rows.data_ptr(), s), "ts_shard_stripe_bwd")

@@ -76,7 +76,7 @@ typedef struct ts_camera {
 } ts_camera;
 #define TS_HINT_BALANCED_WALK 1
 #define TS_CAM_LIST_SEGMENTS(s) (((s) & 15) << 8)
-/* float planes (rows*W each) final_Ts must hold for S list segments: 1, or 1 + (S-1)(1+channels) + channels */
+/* float planes (rows*W each) final_Ts must hold for S list segments: 1 + (S-1)(1+channels) */
 int32_t ts_final_planes(int32_t list_segments, int32_t channels);
 /* tiles (= lists) of a launch: tile_rows * tile_bounds_x, or tile_rows * ceil(tile_bounds_x / 2) when wide */
 int32_t ts_num_tiles(const ts_camera* cam_host);

@@ -432,12 +432,15 @@ def test_one_node_frame_is_bitwise_the_fused_op_recipe():
             assert torch.equal(a, b)
 
 
-def test_tight_binning_drops_only_pairs_that_contribute_nothing():
+def test_tight_binning_drops_only_pairs_that_contribute_nothing(monkeypatch):
     """frame.TIGHT_BINNING: (Gaussian, tile) pairs that provably cannot reach alpha >= 1/255 in the
     tile never enter the lists.  Every output and every gradient is bitwise what gsplat's
     bounding-box lists give, and each tight tile list is the bounding-box list with entries
     removed (same order)."""
     from tinysplat_amd import frame
+    # (bitwise comparisons of GRADIENTS across list shapes hold for the uncut backward pass: list segments - the
+    # default of small launches - cut a list at boundaries that depend on its length)
+    monkeypatch.setattr(frame, "LIST_SEGMENTS", 1)
     n, w, h = 50000, 480, 270
     g = torch.Generator().manual_seed(4)
     w_rgb, w_d = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
@@ -471,7 +474,7 @@ def test_tight_binning_drops_only_pairs_that_contribute_nothing():
             assert all(x in it for x in b), f"tile {t}: tight list is not a subsequence"
 
 
-def test_wide_tiles_change_no_pixel():
+def test_wide_tiles_change_no_pixel(monkeypatch):
     """frame.WIDE_TILES: lists and sort (mode 2, the default) or also the compositing waves (mode 1) on 32x16
     tiles (two adjacent 16x16 tiles binned as one, a Gaussian composited only into the halves inside its
     tile box), against gsplat's 16x16 lists (mode 0).  Image, depth and - through
@@ -481,6 +484,9 @@ def test_wide_tiles_change_no_pixel():
     stripes, opaque Gaussians (general path) and the forward-only frame.  Mode 2 keeps one wave per 16x16
     tile on the wide lists (TS_RASTER_NARROW_WAVES): same pixels again."""
     from tinysplat_amd import frame
+    # (bitwise comparisons of GRADIENTS across list shapes hold for the uncut backward pass: list segments - the
+    # default of small launches - cut a list at boundaries that depend on its length)
+    monkeypatch.setattr(frame, "LIST_SEGMENTS", 1)
     dev = torch.device(DEV)
     keep_wide = frame.WIDE_TILES
     cases = [(60000, 2, 800, 450, 2.0, None), (40000, 1, 336, 208, 4.0, None), (30000, 0, 333, 211, 6.0, None),
@@ -624,10 +630,11 @@ def test_split_blocks_mapping_matches_one_wave_per_tile():
 
 @pytest.mark.parametrize("segs", ["auto", 3])
 def test_list_segments_replace_split_blocks_in_backward(segs, monkeypatch):
-    """TS_LIST_SEGMENTS (an option of small launches, off by default; ts_camera.hints bits 8..11): the split forward
+    """TS_LIST_SEGMENTS (small launches, "auto" by default; ts_camera.hints bits 8..11): the split forward
     pass also keeps the per-pixel state at the segment boundaries and the backward pass replays every list as up to
     S independent one-wave work items instead of four waves per tile.  Image, depth and the sorted lists are
-    bitwise those of the default path; gradients agree with it to rounding; a frame of one-chunk lists stays split."""
+    bitwise those of the split backward pass; gradients agree with it to rounding; a frame of one-chunk lists stays
+    split."""
     from tinysplat_amd import frame
     n, w, h = 120000, 400, 272          # 25 x 17 = 425 tiles, image not a multiple of 16
     model, cam = scene_args(n, 1, w, h, seed=43, scale_mult=2.0)
@@ -659,10 +666,13 @@ def test_list_segments_replace_split_blocks_in_backward(segs, monkeypatch):
     assert frame.last_segments[0] == 1
 
 
-def test_tight_binning_stress_anisotropic_faint_and_opaque():
+def test_tight_binning_stress_anisotropic_faint_and_opaque(monkeypatch):
     """Needle-like and huge Gaussians, opacities from just above 1/255 to > 0.999, centres on and off
     the image: the tight lists must still give bitwise the bounding-box result."""
     from tinysplat_amd import frame
+    # (bitwise comparisons of GRADIENTS across list shapes hold for the uncut backward pass: list segments - the
+    # default of small launches - cut a list at boundaries that depend on its length)
+    monkeypatch.setattr(frame, "LIST_SEGMENTS", 1)
     n, w, h = 60000, 416, 240
     model, cam = scene_args(n, 0, w, h, seed=33, scale_mult=1.0)
     g = torch.Generator().manual_seed(34)

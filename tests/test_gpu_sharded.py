@@ -116,7 +116,7 @@ def test_all_ranks_in_one_process_equal_the_single_frame(world, depth, n, sh, w,
 
 
 def test_list_segments_in_the_stripes_of_a_sharded_frame(monkeypatch):
-    """TS_LIST_SEGMENTS=auto (frame.py; off by default): the stripes of a sharded frame - split launches - replay
+    """TS_LIST_SEGMENTS=auto (frame.py, the default): the stripes of a sharded frame - split launches - replay
     their lists as segments in the backward pass.  Same image bit for bit, gradients to the same bar."""
     from tinysplat_amd import frame
     monkeypatch.setattr(frame, "LIST_SEGMENTS", "auto")

@@ -343,20 +343,22 @@ using mask64 = unsigned long long;
 // fill 1 024 SIMDs with one chain per tile; four waves per tile (TS_RASTER_SPLIT_BLOCKS) fill them, but every one
 // of the four walks and stages the WHOLE list for a quarter of the pixels and writes its own gradient row.  The
 // chain can be CUT instead: the forward pass keeps, per pixel, its state at the segment boundaries b_s - the
-// transmittance T_s in front of entry b_s and the colour C_s accumulated by the entries before it - plus the final
-// colour sum C_fin, and the replay of the segment [b_s, b_s+1) starts from
-//     T = T_(s+1),   R = T_fin (v_alpha - bg . v_out) - v_out . (C_fin - C_(s+1))
+// transmittance T_s in front of entry b_s and the colour B_s that the entries at and behind b_s contribute - and the
+// replay of the segment [b_s, b_s+1) starts from
+//     T = T_(s+1),   R = T_fin (v_alpha - bg . v_out) - v_out . B_(s+1)
 // which is what walking the entries behind it would have left (S_behind fac c . v_out = v_out . sum of their colour
 // contributions), with the forward pass's own T instead of T_fin divided back through hundreds of (1 - alpha).
+// B_s is NOT a difference of the running colour sum (that would know it only to a rounding of the whole pixel
+// colour): the forward pass sums every segment's contributions on their own and adds them up from the back.
 // A tile becomes up to S independent work items of ONE wave each over all four blocks; every (tile, Gaussian)
 // belongs to exactly one of them, so there is one row per pair and the reduction is the plain one.  Boundaries are
 // a function of the list range alone (equal entry counts, multiples of 64: seg_bound), so both passes - and the
 // four waves of a split forward launch - agree on them without a table.  The gradients differ from the uncut
-// pass's by rounding only (measured <= 8e-7 of the tensor's largest entry on config 3).
+// pass's by rounding only.
 // On a FULL frame (8 160 tiles) segments gain nothing (profiles/HISTORY.md, round 4: the machine is saturated and
 // every extra item re-reads its pixel state); callers enable them for launches that would otherwise be split.
 // Layout behind final_Ts (P = pixels of the launch, float planes; ts_final_planes):
-//   plane 0: T_fin | s = 1..S-1: planes 1 + (s-1)(1+CH) + {0: T_s, 1+c: C_s[c]} | planes 1 + (S-1)(1+CH) + c: C_fin[c]
+//   plane 0: T_fin | s = 1..S-1: planes 1 + (s-1)(1+CH) + {0: T_s, 1+c: B_s[c]}
 #define TS_CAM_SEGS(cam) (((cam).hints >> 8) & 15)
 #ifndef TS_SEG_MIN_LIST
 #define TS_SEG_MIN_LIST 65
@@ -400,10 +402,10 @@ __device__ __forceinline__ size_t seg_plane_stride(const ts_camera& cam) {
 // and for finished pixels, and makes the weights telescope (sum of vis = 1 - T_final exactly).
 // GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
 // positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
-template <int CH, bool GENERAL, int NBX>
+template <int CH, bool GENERAL, int NBX, bool LOC = false>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
-                                          float (&acc)[2 * NBX][CH] TS_SEG_PARAM) {
+                                          float (&acc)[2 * NBX][CH], float (&loc)[CH] TS_SEG_PARAM) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     TS_WORK(0, cnt);
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
@@ -444,6 +446,10 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
+            if (LOC) {       // the same contribution summed per list segment (LIST SEGMENTS; the wave owns ONE block)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) loc[c] = __builtin_fmaf(col[c], vis, loc[c]);
+            }
             // composited <=> alpha >= 1/255 and not stopped <=> vis = alpha T > 0 (alpha >= 1/255, T > 1e-4)
             fidx[k] = vis > 0.0f ? idx : fidx[k];
             T[k] = Tn;
@@ -466,7 +472,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 // ids_rw, the network of sort_tiles_small_kernel - when the list has at most kWaveSortMax entries (longer lists were
 // sorted by ts_sort_tiles_above before this launch).  The per-tile sort on its own is latency-bound (VALU 40 %, LDS
 // 59 % busy on config 3); inside this VALU-bound kernel its stalls are filled by other tiles' compositing.
-template <int CH, bool SPLIT, int NBX, bool WL, bool SORT = false>
+template <int CH, bool SPLIT, int NBX, bool WL, bool SORT = false, bool SEGS = false>
 __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_MIN_WAVES_RGB : TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const int* __restrict__ bucket_ids, const float* __restrict__ depths,
@@ -562,15 +568,23 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
     // list segments: this pass leaves the per-pixel state at the segment boundaries for the backward pass
     // (only the SPLIT launches carry this: each of the four waves keeps the pixels of its block; the full-frame kernel
     // has no registers to spare for it, and segments gain nothing there)
-    constexpr bool kSegsF = SPLIT && NBX == 2 && !WL;
+    constexpr bool kSegsF = SEGS && SPLIT && NBX == 2 && !WL;
     const int S_seg = max(1, min(TS_CAM_SEGS(cam), kSegMax));
     const bool seg_on = kSegsF && final_Ts != nullptr && S_seg > 1 && range.y - range.x >= kSegMinList;
     const size_t plane = seg_plane_stride(cam);
     int next_ck = seg_on ? range.x + seg_bound(range.y - range.x, S_seg, 1) : 0x7fffffff;      // list index of the next boundary
     int ck = 1;                                                      // its number (1 .. S-1)
+    // colour the entries of the CURRENT segment contributed (the running sum `acc` rounds at the magnitude of the whole
+    // pixel colour: differences of it would know what lies behind a boundary only to that rounding)
+    // (one set: a wave of a split launch owns one block)
+    float loc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
+    // boundary `number` is reached: T in front of it, and the finished segment's colour into the slot of the boundary
+    // it began at (the epilogue turns these into sums over everything behind a boundary)
     auto store_ck = [&](int number) {
-        // (the pixel addresses are derived from an opaque zero: hoisted out of the list loop they would cost the
-        // kernel eight VGPRs for three uses per tile - and its fifth wave per SIMD)
+        // (the pixel addresses are derived from an opaque zero: hoisted out of the list loop they would cost registers
+        // for a handful of uses per tile)
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         const int py_ = py0 + opaque;
@@ -580,9 +594,13 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
             if (!inside[k]) continue;
             const size_t pix = (size_t)(py_ + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
             base_p[pix] = __builtin_fabsf(T[k]);
+            if (number > 1) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) base_p[plane * (size_t)(1 + c) + pix] = acc[k][c];
+                for (int c = 0; c < CH; ++c) (base_p - plane * (size_t)(1 + CH))[plane * (size_t)(1 + c) + pix] = loc[c];
+            }
         }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
     };
 
     for (int base = range.x; base < range.y && live != 0; base += 64) {
@@ -636,25 +654,58 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
         // once per chunk so that the common case runs a loop without those tests
         TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
         if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
-            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc TS_SEG_ARG);
+            fwd_chunk<CH, true, NBX, kSegsF>(lds, cnt, fpx, fpy, T, fidx, acc, loc TS_SEG_ARG);
         else
-            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc TS_SEG_ARG);
+            fwd_chunk<CH, false, NBX, kSegsF>(lds, cnt, fpx, fpy, T, fidx, acc, loc TS_SEG_ARG);
         TS_WAVE_SYNC();
     }
 
     if constexpr (kSegsF) if (seg_on) {
-        // boundaries behind the entry this wave stopped at: its pixels are finished there (no segment replays them:
-        // fidx lies in front), the planes only have to hold finite numbers
-        for (; ck < S_seg && next_ck < range.y; ++ck, next_ck = range.x + seg_bound(range.y - range.x, S_seg, min(ck, S_seg - 1)))
-            store_ck(ck);
-        {
-            float* fin = final_Ts + plane * (size_t)(1 + (S_seg - 1) * (1 + CH));      // C_fin, without the background
+        const int cur = ck - 1;                    // the segment this wave's pass ended in
+        // boundaries behind it: the wave's pixels are finished there (no segment replays them: fidx lies in front);
+        // T only has to be a finite number, nothing lies behind
+        for (; ck < S_seg && next_ck < range.y; ++ck, next_ck = range.x + seg_bound(range.y - range.x, S_seg, min(ck, S_seg - 1))) {
+            float* base_p = final_Ts + plane * (size_t)(1 + (ck - 1) * (1 + CH));
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 if (!inside[k]) continue;
                 const size_t pix = (size_t)(py0 + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
+                base_p[pix] = __builtin_fabsf(T[k]);
 #pragma unroll
-                for (int c = 0; c < CH; ++c) fin[plane * (size_t)c + pix] = acc[k][c];
+                for (int c = 0; c < CH; ++c) base_p[plane * (size_t)(1 + c) + pix] = 0.0f;
+            }
+        }
+        // B_s = colour of everything at and behind boundary s = D_s + B_(s+1), summed from the back; D_cur is in `loc`,
+        // the earlier D_s were stored when their segments ended
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (!inside[k] || cur < 1) continue;
+            const size_t pix = (size_t)(py0 + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
+            float d[kSegMax - 2][CH];
+#pragma unroll
+            for (int sgm = 1; sgm <= kSegMax - 2; ++sgm) {
+                if (sgm >= cur) continue;
+                const float* bp = final_Ts + plane * (size_t)(1 + (sgm - 1) * (1 + CH));
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[sgm - 1][c] = bp[plane * (size_t)(1 + c) + pix];
+            }
+            float suf[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) suf[c] = loc[c];
+            {
+                float* bp = final_Ts + plane * (size_t)(1 + (cur - 1) * (1 + CH));
+#pragma unroll
+                for (int c = 0; c < CH; ++c) bp[plane * (size_t)(1 + c) + pix] = suf[c];
+            }
+#pragma unroll
+            for (int sgm = kSegMax - 2; sgm >= 1; --sgm) {
+                if (sgm >= cur) continue;
+                float* bp = final_Ts + plane * (size_t)(1 + (sgm - 1) * (1 + CH));
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    suf[c] = d[sgm - 1][c] + suf[c];
+                    bp[plane * (size_t)(1 + c) + pix] = suf[c];
+                }
             }
         }
     }
@@ -1077,10 +1128,9 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
             if (kSegs && front) {
                 const size_t plane = seg_plane_stride(cam);
                 const float* ckp = final_Ts + plane * (size_t)(1 + seg * (1 + CH));            // boundary seg + 1
-                const float* fin = final_Ts + plane * (size_t)(1 + (S_seg - 1) * (1 + CH));
                 T_start = ckp[pix];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) cb[c] = fin[plane * (size_t)c + pix] - ckp[plane * (size_t)(1 + c) + pix];
+                for (int c = 0; c < CH; ++c) cb[c] = ckp[plane * (size_t)(1 + c) + pix];
             }
             const int pass = clamp_mask ? clamp_mask[pix] : 7;   // backward of the fused clamp(max=1)
 #pragma unroll
@@ -1328,7 +1378,7 @@ int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer 
 
 int32_t ts_final_planes(int32_t list_segments, int32_t channels) {
     if (list_segments <= 1) return 1;
-    return 1 + (min(list_segments, kSegMax) - 1) * (1 + channels) + channels;
+    return 1 + (min(list_segments, kSegMax) - 1) * (1 + channels);
 }
 
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
@@ -1355,16 +1405,19 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-#define TS_LAUNCH_FWD(C, S, X, L)                                                                  \
-    hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
+    // list segments (ts_camera.hints bits 8..11): the split launch on 16x16 lists also keeps the boundary planes
+    const bool segs = split && !wide && !narrow && final_Ts && TS_CAM_SEGS(*cam) > 1;
+#define TS_LAUNCH_FWD(C, S, X, L, G)                                                               \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L, false, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, gaussian_ids_sorted, (const int*)nullptr, (const float*)nullptr,   \
                        (int*)nullptr, sp, background, out_img, out_depth, final_Ts,                  \
                        final_index, clamp, clamp ? clamp_mask : nullptr)
 #define TS_LAUNCH_FWD_X(C, S)                                                                      \
     do {                                                                                           \
-        if (wide) TS_LAUNCH_FWD(C, S, 4, false);                                                   \
-        else if (narrow) TS_LAUNCH_FWD(C, S, 2, true);                                             \
-        else TS_LAUNCH_FWD(C, S, 2, false);                                                        \
+        if (wide) TS_LAUNCH_FWD(C, S, 4, false, false);                                            \
+        else if (narrow) TS_LAUNCH_FWD(C, S, 2, true, false);                                      \
+        else if (S && segs) TS_LAUNCH_FWD(C, S, 2, false, S);                                      \
+        else TS_LAUNCH_FWD(C, S, 2, false, false);                                                 \
     } while (0)
     if (channels == 3) { if (split) TS_LAUNCH_FWD_X(3, true); else TS_LAUNCH_FWD_X(3, false); }
     else { if (split) TS_LAUNCH_FWD_X(4, true); else TS_LAUNCH_FWD_X(4, false); }
@@ -1391,12 +1444,20 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-#define TS_LAUNCH_FWD_SORT(C, S)                                                                               \
-    hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true>), dim3(grid), dim3(kThreads), 0, s, *cam, nt,   \
+    const bool segs = split && final_Ts && TS_CAM_SEGS(*cam) > 1;       // list segments: see ts_raster_fwd_planes
+#define TS_LAUNCH_FWD_SORT(C, S, G)                                                                            \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background, \
                        out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr)
-    if (channels == 3) { if (split) TS_LAUNCH_FWD_SORT(3, true); else TS_LAUNCH_FWD_SORT(3, false); }
-    else { if (split) TS_LAUNCH_FWD_SORT(4, true); else TS_LAUNCH_FWD_SORT(4, false); }
+    if (channels == 3) {
+        if (split && segs) TS_LAUNCH_FWD_SORT(3, true, true);
+        else if (split) TS_LAUNCH_FWD_SORT(3, true, false);
+        else TS_LAUNCH_FWD_SORT(3, false, false);
+    } else {
+        if (split && segs) TS_LAUNCH_FWD_SORT(4, true, true);
+        else if (split) TS_LAUNCH_FWD_SORT(4, true, false);
+        else TS_LAUNCH_FWD_SORT(4, false, false);
+    }
 #undef TS_LAUNCH_FWD_SORT
     return launch_status();
 }

@@ -43,27 +43,26 @@ TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 # one wave per tile such launches cannot hide any latency.  0 disables.
 SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 
-# LIST SEGMENTS in the backward pass of such a launch (bits 8..11 of ts_camera.hints, csrc/raster.hip: LIST SEGMENTS) -
-# an OPTION, off by default (TS_LIST_SEGMENTS=auto or 2..8 switches it on): the (split) forward pass also leaves the
-# per-pixel state at up to S - 1 boundaries of every list of two chunks or more, and the backward pass replays the
-# segments as independent work items of one wave over the whole tile - instead of four waves per tile that each walk
-# and stage the WHOLE list for a quarter of the pixels and write a gradient row of their own.  "auto": as many
-# segments (2 .. 8) as bring the launch to ~8 192 work items (two rounds of raster_bwd's wave slots).
-# A list of one chunk (<= 64 entries) cannot be cut, and a launch of such lists is better off split: the BACKWARD pass
-# decides - segments when the frame averages >= LIST_SEGMENTS_FROM bounding-box pairs per tile (the frame's own pair
-# count, known by then - the same frame always takes the same path; ~0.65 of them are listed), split blocks otherwise.  Measured on MI355X, raster_bwd +
-# reduce_partials, split -> 8 segments (profiles/r04u_list_segments_small_launches.txt): a 1/8 stripe of config 3
-# (1 020 tiles, ~560 entries per list) 136 + 51 -> 96 + 30 us (raster_fwd 85 -> 91 for the boundary stores);
-# 512x512 / 200 k (295 per list) 93 + 15 -> 80 + 10; 640x360 / 100 k with depth 69 -> 65; 256x256 / 10 k (lists of
-# one chunk) 17 -> 33 - hence the threshold.
-# Why it is not the default: the image is bitwise the split pass's, but a segment starts from
-#     R = T_fin (v_alpha - bg . v_out) - v_out . (C_fin - C_s)
-# with C_fin, C_s the forward pass's running colour sums, so what lies BEHIND a segment is known to a rounding of
-# |C| instead of a rounding of itself: gradients agree with the uncut pass to <= 8e-7 of a tensor's largest entry,
-# yet on needle scenes (tools/fuzz_frame.py, seed 10) the share of entries within 1e-5 max(1, |ref entry|) of the
-# oracle drops from 99.9 % to 98.2 % - below the 99 % the checker asks for.  On a full frame segments gain nothing
-# either way (profiles/HISTORY.md, round 4) and are never used.
-_ls = os.environ.get("TS_LIST_SEGMENTS", "1")
+# LIST SEGMENTS in the backward pass of such a launch (bits 8..11 of ts_camera.hints, csrc/raster.hip: LIST SEGMENTS;
+# TS_LIST_SEGMENTS = auto (default) | 1 (off: split backward) | 2..8): the split forward pass also leaves, per pixel,
+# the transmittance in front of and the colour behind up to S - 1 boundaries of every list of two chunks or more, and
+# the backward pass replays the segments as independent work items of one wave over the whole tile - instead of four
+# waves per tile that each walk and stage the WHOLE list for a quarter of the pixels and write a gradient row of
+# their own.  "auto": as many segments (2 .. 8) as bring the launch to ~8 192 work items (two rounds of raster_bwd's
+# wave slots).  A list of one chunk (<= 64 entries) cannot be cut, and a launch of such lists is better off split:
+# the BACKWARD pass decides - segments when the frame averages >= LIST_SEGMENTS_FROM bounding-box pairs per tile (the
+# frame's own pair count, known by then - the same frame always takes the same path; ~0.65 of them are listed),
+# split blocks otherwise.  Measured on MI355X, raster_fwd + raster_bwd + reduce_partials, split -> 8 segments
+# (profiles/r04u_list_segments_small_launches.txt): a 1/8 stripe of config 3 (1 020 tiles, ~560 entries per list)
+# 83 + 131 + 50 -> 95 + 95 + 30 us, with depth 85 + 137 + 56 -> 97 + 97 + 31; 512x512 / 200 k (295 per list)
+# 55 + 93 + 15 -> 65 + 79 + 10; 256x256 / 10 k (lists of one chunk) would be 17 -> 33 us in raster_bwd - hence the
+# threshold.  The image is bitwise the split pass's; gradients agree with the uncut pass to rounding (<= 8e-7 of a
+# tensor's largest entry) and with the float64 oracle as well as the uncut pass does (the colour behind a boundary is
+# summed per segment, not taken as a difference of the running sum: tools/fuzz_frame.py seed 10 keeps 99.9 % of its
+# entries within 1e-5 max(1, |ref|), where the difference form dropped to 98.2 %).  Across LIST shapes (tight vs
+# bounding-box lists, wide lists) gradients are bitwise equal only with TS_LIST_SEGMENTS=1: the boundaries depend on
+# a list's length.  On a full frame segments gain nothing (profiles/HISTORY.md, round 4) and are never used.
+_ls = os.environ.get("TS_LIST_SEGMENTS", "auto")
 LIST_SEGMENTS = _ls if _ls == "auto" else max(1, min(8, int(_ls)))
 LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
 
@@ -271,7 +270,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     segs = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else 1
     cam.hints = (cam.hints & ~0xF00) | ((segs if segs > 1 else 0) << 8)
     F.segs = segs
-    fin_planes = 1 + (segs - 1) * (1 + ch) + ch if segs > 1 else 1          # ts_final_planes
+    fin_planes = 1 + (segs - 1) * (1 + ch)                                   # ts_final_planes
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()
     if cur != dev.index:

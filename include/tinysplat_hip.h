@@ -385,6 +385,16 @@ typedef struct ts_stripes {   /* rank d renders tile rows [row[d], row[d+1]) */
 int64_t ts_route_ws_ints(int32_t n, int32_t num_ranks);
 int ts_route_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
                    const ts_stripes* stripes_host, int32_t* route_ws, int32_t* counts, void* stream);
+/* PADDED groups: group_base_host[num_ranks + 1] (ascending, host memory, read during the call) fixes where every
+ * destination's group starts in the send buffer and in the returned gradient rows - capacities the caller chose
+ * BEFORE this frame's counts exist (e.g. from the previous frame), so that the exchange can be enqueued without a
+ * host read of the counts.  The caller zeroes the send buffer (an all-zero record lists nothing at its destination:
+ * radius 0), checks counts[d] <= group_base_host[d+1] - group_base_host[d] when it reads them - e.g. together with
+ * the stripe's pair count at the end of the forward pass - and runs the frame again with exact groups if not.
+ * group_base_host = NULL: ts_route_count. */
+int ts_route_count_padded(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam_host,
+                          const ts_stripes* stripes_host, const int32_t* group_base_host, int32_t* route_ws,
+                          int32_t* counts, void* stream);
 /* records[sum(counts), 16]: grouped by destination (ascending), ascending Gaussian index inside a group;
  * splats = the owner's packed records (colours, sigmoid opacity), gid_base = global index of Gaussian 0. */
 int ts_route_pack(int32_t n, int32_t gid_base, const float* xys, const int32_t* radii, const float* depths,
@@ -420,6 +430,8 @@ int ts_route_accumulate(int32_t n, int32_t channels, const float* xys, const int
  *   ts_shard_owner_bwd          route_accumulate, sh_colors_bwd, project_bwd          (fo) */
 int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes_host, int32_t* route_ws, int32_t* counts,
                        void* stream);
+int ts_shard_owner_fwd_padded(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* group_base_host,
+                              int32_t* route_ws, int32_t* counts, void* stream);   /* see ts_route_count_padded */
 int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream);
 int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream);
 int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* route_ws,

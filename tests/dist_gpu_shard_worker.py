@@ -36,12 +36,36 @@ def main():
     del model
     layout = ShardLayout(n, world, rank, (w, h))
     w_rgb, w_d = loss_weights(w, h)
-    out, (y0, y1), xys = render_sharded(shard, cam, dev, layout, DistExchange(), with_depth=depth)
-    loss = (out[:, :, :3] * w_rgb[y0:y1].to(dev)).sum()
-    if depth:
-        loss = loss + (out[:, :, 3] * w_d[y0:y1].to(dev)).sum()
-    loss.backward()
-    torch.cuda.synchronize()
+    from tinysplat_amd import sharded
+    exchange = DistExchange()
+
+    def frame():
+        for p_ in shard.parameters():
+            p_.grad = None
+        out, (y0, y1), xys = render_sharded(shard, cam, dev, layout, exchange, with_depth=depth)
+        loss = (out[:, :, :3] * w_rgb[y0:y1].to(dev)).sum()
+        if depth:
+            loss = loss + (out[:, :, 3] * w_d[y0:y1].to(dev)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return out, (y0, y1), xys
+
+    # frame 1 sizes the exchange from this frame's counts (host read); frame 2 runs PADDED from frame 1's count matrix
+    # (no host read before the exchange); frame 3 finds capacities that are too small and every rank runs it again
+    # with exact sizes.  All three must give the same bits.
+    out, (y0, y1), xys = frame()
+    first = [out.detach().clone(), xys.grad.clone()] + [p.grad.clone() for p in shard.parameters()]
+    assert sharded.padded_frames == [0, 0]
+    out, (y0, y1), xys = frame()
+    assert sharded.padded_frames == [1, 0], sharded.padded_frames
+    for a, b in zip(first, [out.detach(), xys.grad] + [p.grad for p in shard.parameters()]):
+        assert torch.equal(a, b), "padded exchange changed a result"
+    for key in list(sharded._route_caps):
+        sharded._route_caps[key] = sharded._route_caps[key] * 0 + 64
+    out, (y0, y1), xys = frame()
+    assert sharded.padded_frames == [2, 1], sharded.padded_frames
+    for a, b in zip(first, [out.detach(), xys.grad] + [p.grad for p in shard.parameters()]):
+        assert torch.equal(a, b), "the repeated frame changed a result"
     torch.save({"img": out.detach().cpu(), "rows": (y0, y1), "owned": layout.owned, "xys_grad": xys.grad.cpu(),
                 "grads": [p.grad.cpu() for p in shard.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -38,6 +38,12 @@ def test_binding_covers_the_header_and_version_matches():
     lib = _lib.load()
     assert lib.ts_abi_version() == _lib.ABI_VERSION == 5
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
+    # list segments (ts_camera.hints bits 8..11): planes behind final_Ts, and the Python side's own formula
+    assert [lib.ts_final_planes(s_, c_) for s_, c_ in ((0, 3), (1, 4), (2, 3), (8, 3), (8, 4), (15, 4))] == [1, 1, 5, 29, 36, 36]
+    from tinysplat_amd import frame
+    assert all(frame._list_segments(t, 0, True) == max(2, min(8, 8192 // t)) for t in (1, 200, 1020, 1536, 5000)) \
+        or frame.LIST_SEGMENTS != "auto"
+    assert frame._list_segments(1020, 2, True) == 1 and frame._list_segments(1020, 0, False) == 1
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + hints (ABI 3; the second word was `reserved` until round 4)
     assert ctypes.sizeof(_lib.TsStripes) == 4 * (_lib.MAX_RANKS + 2)

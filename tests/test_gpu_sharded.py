@@ -125,6 +125,50 @@ def test_list_segments_in_the_stripes_of_a_sharded_frame(monkeypatch):
     assert frame.last_segments.get(0, 1) > 1           # the stripes (230 tiles each) did take the segmented pass
 
 
+def test_padded_exchange_changes_no_bit_and_repeats_on_overflow():
+    """sharded.PADDED_EXCHANGE with the replayed records of bench.py --emulate-ranks (one rank of four on one GPU):
+    frame 1 reads the counts, frame 2 runs padded from frame 1's count matrix - no host read before the exchange -
+    and frame 3, handed capacities that are too small, notices at the end of its forward pass and runs again with
+    exact sizes.  Image and gradients bit for bit the same in all three."""
+    from tinysplat_amd import sharded
+    from tinysplat_amd.sharded import ReplayExchange
+    n, sh, w, h, world, rank = 60000, 2, 640, 360, 4, 1
+    model, cam = make_scene(n, sh, w, h, seed=9, scale_mult=2.0)
+    parts, counts = [], []
+    for src in range(world):
+        rec, cnt = export_records(shard_model(model, world, src).to(DEV), cam, DEV, ShardLayout(n, world, src, (w, h)),
+                                  with_depth=True)
+        off = sum(cnt[:rank])
+        parts.append(rec[off:off + cnt[rank]].clone())
+        counts.append(cnt[rank])
+    exchange = ReplayExchange(rank, counts, torch.cat(parts, dim=0))
+    layout = ShardLayout(n, world, rank, (w, h))
+    shard = shard_model(model, world, rank).to(DEV).requires_grad_(True)
+    w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+    from tinysplat_amd.sharded import render_sharded
+
+    def frame():
+        for p_ in shard.parameters():
+            p_.grad = None
+        out, (y0, y1), xys = render_sharded(shard, cam, DEV, layout, exchange, with_depth=True)
+        ((out[:, :, :3] * w_rgb[y0:y1]).sum() + (out[:, :, 3] * w_d[y0:y1]).sum()).backward()
+        return [out.detach().clone(), xys.grad.clone()] + [p.grad.clone() for p in shard.parameters()]
+
+    sharded._route_caps.clear()
+    before = list(sharded.padded_frames)
+    first = frame()
+    assert sharded.padded_frames == before
+    second = frame()
+    assert sharded.padded_frames == [before[0] + 1, before[1]]
+    for key in list(sharded._route_caps):
+        sharded._route_caps[key] = sharded._route_caps[key] * 0 + 64
+    third = frame()
+    assert sharded.padded_frames == [before[0] + 2, before[1] + 1]
+    for other in (second, third):
+        for a, b in zip(first, other):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_config3_full_size_sharded_equals_single_frame(world):
     """BASELINE configs[3]: 1 M Gaussians, SH 3, 1920x1080, sharded over 2 and 8 ranks (all ranks' stages in this

@@ -52,7 +52,8 @@ collective_timer = CollectiveTimer()
 
 def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
     """Every rank runs the SAME tiny ``all_to_all_single`` with uneven split sizes (the call shape of
-    sharded.DistExchange.rows) before any frame, then the ranks agree with an all-reduce: a backend that rejects the
+    sharded.DistExchange.rows) and the ``all_gather`` of the record counts (DistExchange.gather) before any frame,
+    then the ranks agree with an all-reduce: a backend that rejects the
     call does so on all ranks in this first collective, not on one rank in the middle of a frame with its peers
     already blocked in the next exchange.  -> (usable on ALL ranks, this rank's error text or "")."""
     world = dist.get_world_size(group)
@@ -69,6 +70,18 @@ def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
         want = torch.cat([torch.full((c, 4), float(s)) for s, c in enumerate(recv_counts)])
         if not torch.equal(got.cpu(), want):
             ok, err = 0, "all_to_all_single with split sizes returned wrong rows"
+        # the count matrix of the padded exchange (sharded.DistExchange.gather): one all_gather of `world` ints
+        mine = torch.arange(world, dtype=torch.int32, device=dev) + 100 * rank
+        if via_host:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            mat = torch.stack(parts)
+        else:
+            mat = torch.empty((world, world), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(mat.view(-1), mine, group=group)
+        want_m = torch.arange(world, dtype=torch.int32)[None, :] + 100 * torch.arange(world, dtype=torch.int32)[:, None]
+        if ok and not torch.equal(mat.cpu(), want_m):
+            ok, err = 0, "all_gather returned a wrong count matrix"
     except Exception as e:                                      # noqa: BLE001 - whatever the backend raises
         ok, err = 0, f"{type(e).__name__}: {e}"
     flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) != "gloo" else "cpu")

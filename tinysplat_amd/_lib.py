@@ -118,12 +118,14 @@ SIGNATURES = {
     "ts_reduce_partials": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_route_ws_ints": (c_int64, [c_int32, c_int32]),
     "ts_route_count": (c_int32, [c_int32, _P, _P, _CAM, _STRIPES, _P, _P, _P]),
+    "ts_route_count_padded": (c_int32, [c_int32, _P, _P, _CAM, _STRIPES, _P, _P, _P, _P]),
     "ts_route_pack": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _CAM, _STRIPES, _P, _P, _P]),
     "ts_import_records": (c_int32, [c_int32, _P, _CAM, _P, _P, _P, _P, _P]),
     "ts_import_pack": (c_int32, [c_int32, _P, _P, _CAM, _P, _P]),
     "ts_reduce_partials_rows": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_route_accumulate": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _CAM, _STRIPES, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_shard_owner_fwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),
+    "ts_shard_owner_fwd_padded": (c_int32, [_FRAME, _STRIPES, _P, _P, _P, _P]),
     "ts_shard_stripe_fwd_import": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_stripe_bwd": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_owner_bwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),

@@ -181,6 +181,11 @@ int ts_frame_bwd_params(const ts_frame* f, void* stream) {
 
 int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes, int32_t* route_ws, int32_t* counts,
                        void* stream) {
+    return ts_shard_owner_fwd_padded(fo, stripes, nullptr, route_ws, counts, stream);
+}
+
+int ts_shard_owner_fwd_padded(const ts_frame* fo, const ts_stripes* stripes, const int32_t* group_base,
+                              int32_t* route_ws, int32_t* counts, void* stream) {
     TsRange range_("ts_shard_owner_fwd");
     if (bad(fo) || !stripes) return TS_E_BADARG;
     TS_TRY(ts_project_fwd(fo->n, fo->means, fo->scales, fo->quats, fo->view34, fo->projview, &fo->cam, 3, fo->xys,
@@ -192,7 +197,7 @@ int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes, int32_t* r
                               TS_RASTER_LOGIT_OPACITY, fo->xys, fo->radii, fo->conics, fo->opacities,
                               fo->num_tiles_hit, &fo->cam, fo->channels == 4 ? fo->depths : nullptr, fo->splats,
                               stream));
-    return ts_route_count(fo->n, fo->xys, fo->radii, &fo->cam, stripes, route_ws, counts, stream);
+    return ts_route_count_padded(fo->n, fo->xys, fo->radii, &fo->cam, stripes, group_base, route_ws, counts, stream);
 }
 
 int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream) {

@@ -86,11 +86,15 @@ __global__ __launch_bounds__(kThreads) void route_count_kernel(int n, const floa
 
 // single workgroup: per destination an exclusive scan over the blocks (in place), then the exclusive scan of
 // the destination totals.  counts[d] = records for destination d, seg[d] = first record of its group.
+// PADDED groups (ts_route_count_padded): seg[d] is not the running sum of the counts but a base the caller fixed
+// BEFORE the counts were known (capacities from the previous frame), so that the exchange needs no host read of this
+// frame's counts; the rows between a group's count and its capacity are the caller's (zeroed) padding.
+struct GroupBase { int padded; int base[TS_MAX_RANKS + 1]; };
 constexpr int kScanThreads = 1024;
 __global__ __launch_bounds__(kScanThreads) void route_scan_kernel(int num_blocks, int num_dest,
                                                                   int* __restrict__ block_counts,
                                                                   int* __restrict__ seg,
-                                                                  int* __restrict__ counts) {
+                                                                  int* __restrict__ counts, const GroupBase gb) {
     __shared__ int wsum[kScanThreads / 64];
     __shared__ int carry, total[TS_MAX_RANKS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -127,11 +131,11 @@ __global__ __launch_bounds__(kScanThreads) void route_scan_kernel(int num_blocks
     if (threadIdx.x == 0) {
         int run = 0;
         for (int d = 0; d < num_dest; ++d) {
-            seg[d] = run;
+            seg[d] = gb.padded ? gb.base[d] : run;
             counts[d] = total[d];
             run += total[d];
         }
-        seg[num_dest] = run;
+        seg[num_dest] = gb.padded ? gb.base[num_dest] : run;
     }
 }
 
@@ -168,7 +172,9 @@ __global__ __launch_bounds__(kThreads) void route_pack_kernel(
         const unsigned long long m = __ballot(mine);
         int pos = seg[d] + block_base[(size_t)d * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) pos += cnt[w][d];
-        if (mine) {
+        // (padded groups: a group that outgrew its capacity is cut off at the next group's base - the caller sees the
+        // count, drops the frame and runs it again with exact sizes)
+        if (mine && pos < seg[d + 1]) {
             float4* o = records + 4 * (size_t)pos;
             o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
         }
@@ -283,17 +289,32 @@ int64_t ts_route_ws_ints(int32_t n, int32_t num_ranks) {
     return (int64_t)route_blocks(n) * num_ranks + num_ranks + 1;
 }
 
-int ts_route_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
-                   const ts_stripes* stripes, int32_t* route_ws, int32_t* counts, void* stream) {
+int ts_route_count_padded(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
+                          const ts_stripes* stripes, const int32_t* group_base, int32_t* route_ws, int32_t* counts,
+                          void* stream) {
     if (n < 0 || bad_stripes(stripes, cam) || !route_ws || !counts) return TS_E_BADARG;
     if (n > 0 && (!xys || !radii)) return TS_E_BADARG;
+    GroupBase gb;
+    gb.padded = group_base != nullptr;
+    for (int d = 0; d <= TS_MAX_RANKS; ++d) gb.base[d] = 0;
+    if (group_base) {
+        for (int d = 0; d <= stripes->num; ++d) {
+            if (group_base[d] < 0 || (d > 0 && group_base[d] < group_base[d - 1])) return TS_E_BADARG;
+            gb.base[d] = group_base[d];
+        }
+    }
     const int blocks = route_blocks(n);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(route_count_kernel, dim3(blocks), dim3(kThreads), 0, s, n, xys, radii, *cam, *stripes,
                        route_ws);
     hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, blocks, (int)stripes->num, route_ws,
-                       route_ws + (size_t)blocks * stripes->num, counts);
+                       route_ws + (size_t)blocks * stripes->num, counts, gb);
     return launch_status();
+}
+
+int ts_route_count(int32_t n, const float* xys, const int32_t* radii, const ts_camera* cam,
+                   const ts_stripes* stripes, int32_t* route_ws, int32_t* counts, void* stream) {
+    return ts_route_count_padded(n, xys, radii, cam, stripes, nullptr, route_ws, counts, stream);
 }
 
 int ts_route_pack(int32_t n, int32_t gid_base, const float* xys, const int32_t* radii, const float* depths,

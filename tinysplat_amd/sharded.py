@@ -31,6 +31,7 @@ one process on one GPU (full-size functional checks and the per-stage table of a
 from __future__ import annotations
 
 import ctypes
+import numpy as np
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -48,6 +49,28 @@ from .synthetic import SplatModel
 
 RECORD_FLOATS = 16       # TS_EXPORT_RECORD_FLOATS
 ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS
+
+# PADDED EXCHANGE (TS_PADDED_EXCHANGE=0 switches it off): how many records a rank sends to every other rank is known
+# only after its owner stage has run, and sizing the all_to_all from it costs a host read in the middle of the frame -
+# the GPU idles while the host waits for the counts, allocates and enqueues the rest (~45 us of a 0.41 ms rank step
+# on config 3 at 8 ranks).  From the second frame of a layout on, every (source, destination) group instead gets the
+# CAPACITY the previous frame's count matrix suggests (+ 12.5 % + 192 rows, multiples of 64): the send buffer is zeroed
+# (an all-zero record lists nothing: radius 0), ts_route_count_padded fixes the groups' bases, the all_to_all runs with
+# the capacities as split sizes, and the whole forward pass is enqueued without looking at a count.  The counts travel
+# anyway - one all_gather of `world` ints per rank gives EVERY rank the whole matrix - and are read where the frame
+# already waits for the stripe's pair count: if any group outgrew its capacity, every rank sees it in the same matrix
+# and all of them run the forward pass again with exact sizes (no extra collective to agree on that).
+import os as _os
+PADDED_EXCHANGE = _os.environ.get("TS_PADDED_EXCHANGE", "1") != "0"
+_route_caps = {}         # layout key -> capacity matrix [world][world] derived from the previous frame's counts
+_count_slots = {}        # (device index, world) -> pinned int32[world * world] the gathered counts are copied into
+padded_frames = [0, 0]   # frames that ran padded / padded frames that had to run again (tests, tools)
+
+
+def _capacity(c):
+    """counts (numpy int array) -> capacities"""
+    c = np.asarray(c, dtype=np.int64)
+    return ((c + (c >> 3) + 192) // 64 + 1) * 64
 
 
 # --------------------------------------------------------------------------------------------------
@@ -110,7 +133,14 @@ class Exchange:
     rows(): send[sum(send_counts), F] grouped by destination -> recv[sum(recv_counts), F] grouped by source.
     ``backward=True`` marks the gradient return (same shapes with the roles of the counts swapped)."""
 
+    can_gather = False       # gather() exists: the padded exchange (module docstring of PADDED_EXCHANGE) may be used
+
     def counts(self, counts_dev: Tensor) -> Tuple[List[int], List[int]]:
+        raise NotImplementedError
+
+    def gather(self, counts_dev: Tensor) -> Tensor:
+        """device int32[world] records per destination -> device int32[world, world]: row s = the counts of rank s.
+        No host read."""
         raise NotImplementedError
 
     def rows(self, send: Tensor, send_counts: List[int], recv_counts: List[int], backward: bool = False) -> Tensor:
@@ -121,9 +151,24 @@ class DistExchange(Exchange):
     """torch.distributed: ``all_to_all_single`` with split sizes (RCCL over xGMI for backend "nccl").  gloo
     (functional tests with all ranks on one GPU) moves CUDA tensors through the host."""
 
+    can_gather = True
+
     def __init__(self, group=None):
         self.group = group
         self.via_host = dist.get_backend(group) == "gloo"
+        self.world = dist.get_world_size(group)
+
+    def gather(self, counts_dev):
+        if self.via_host:
+            mine = counts_dev.cpu()
+            got = [torch.empty_like(mine) for _ in range(self.world)]
+            with collective_timer.span(on_device=False):
+                dist.all_gather(got, mine, group=self.group)
+            return torch.stack(got).to(counts_dev.device)
+        out = torch.empty((self.world, counts_dev.shape[0]), dtype=counts_dev.dtype, device=counts_dev.device)
+        with collective_timer.span():
+            dist.all_gather_into_tensor(out.view(-1), counts_dev, group=self.group)
+        return out
 
     def counts(self, counts_dev):
         if self.via_host:
@@ -160,18 +205,47 @@ class ReplayExchange(Exchange):
     backward only the rows of the rank's own records come back (the others would travel to their owners).
     No byte crosses a link: what is timed is the rank's compute, NOT a multi-GPU measurement."""
 
+    can_gather = True
+
     def __init__(self, rank: int, recv_counts: List[int], recv_template: Tensor):
         self.rank, self.recv_counts, self.template = rank, list(recv_counts), recv_template
         self.recv_off = [0]
         for c in self.recv_counts:
             self.recv_off.append(self.recv_off[-1] + c)
         self.send_counts = None
+        # the count matrix as far as this rank can know it: column `rank` = what the others send here
+        world = len(self.recv_counts)
+        mat = torch.zeros((world, world), dtype=torch.int32)
+        mat[:, rank] = torch.tensor(self.recv_counts, dtype=torch.int32)
+        self.mat = mat.to(recv_template.device)
+        self._padded = (None, None)              # (split sizes, the template laid out for them)
 
     def counts(self, counts_dev):
         self.send_counts = counts_dev.cpu().tolist()
         if self.send_counts[self.rank] != self.recv_counts[self.rank]:
             raise RuntimeError("the replayed records do not belong to this scene / camera")
         return self.send_counts, self.recv_counts
+
+    def gather(self, counts_dev):
+        mat = self.mat.clone()
+        mat[self.rank] = counts_dev
+        return mat
+
+    def _template_for(self, splits):
+        """the remote groups at the offsets the (padded) split sizes give, zero rows in between"""
+        splits = tuple(int(c) for c in splits)
+        if splits == tuple(self.recv_counts):
+            return self.template
+        if self._padded[0] != splits:
+            t = self.template.new_zeros((sum(splits), self.template.shape[1]))
+            off = 0
+            for k, c in enumerate(splits):
+                n_k = min(self.recv_counts[k], c)     # (a group that outgrew its capacity arrives cut off, as from
+                #                                        ts_route_pack: that frame is dropped and run again)
+                t[off:off + n_k] = self.template[self.recv_off[k]:self.recv_off[k] + n_k]
+                off += c
+            self._padded = (splits, t)
+        return self._padded[1]
 
     def rows(self, send, send_counts, recv_counts, backward=False):
         so = sum(send_counts[:self.rank])
@@ -181,7 +255,7 @@ class ReplayExchange(Exchange):
             got = send.new_zeros((sum(recv_counts), send.shape[1]))
             got[ro:ro + k] = send[so:so + k]
             return got
-        got = self.template.clone()
+        got = self._template_for(recv_counts).clone()
         got[ro:ro + k] = send[so:so + k]
         return got
 
@@ -191,7 +265,7 @@ class ReplayExchange(Exchange):
 # --------------------------------------------------------------------------------------------------
 class _Owner:
     __slots__ = ("n", "nb", "ch", "cam", "fr", "ws", "xys", "radii", "send_counts", "recv_counts", "inputs",
-                 "p_route_ws")
+                 "p_route_ws", "caps", "key", "count_host", "count_event")
 
 
 class _Stripe:
@@ -214,8 +288,13 @@ def _view(ws, off, dtype, count, shape):
     return ws[off:off + count * dtype.itemsize].view(dtype).view(shape)
 
 
+def _layout_key(dev, layout: ShardLayout):
+    return (dev.index, layout.world, layout.rank, layout.dims, layout.n_total, tuple(layout.stripes))
+
+
 def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, scales, quats, opacities,
-                 colors_dc, colors_rest, view34, projview, origin, fx, fy, sh_degree, ch, keep: bool):
+                 colors_dc, colors_rest, view34, projview, origin, fx, fy, sh_degree, ch, keep: bool,
+                 padded: bool = True):
     w, h = layout.dims
     n = means.shape[0]
     nb = colors_rest.shape[1] + 1
@@ -241,6 +320,17 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
     fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, fr.splats = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5]
     fr.sh_mask = ptr[6] if keep else None
     O.fr = fr
+    # padded exchange (see PADDED_EXCHANGE): capacities from the previous frame of this layout, if there was one
+    O.key = _layout_key(dev, layout)
+    O.caps = _route_caps.get(O.key) if (padded and PADDED_EXCHANGE and exchange.can_gather) else None
+    O.count_host = O.count_event = None
+    me, world = layout.rank, layout.world
+    gb = None
+    if O.caps is not None:
+        base = [0]
+        for c in O.caps[me].tolist():
+            base.append(base[-1] + c)
+        gb = (ctypes.c_int32 * (world + 1))(*base)
     if kernel_timer.enabled:
         _call("ts_project_fwd", lib.ts_project_fwd, n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview, O.cam, 3,
               fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, None, s)
@@ -248,14 +338,35 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
         _call("ts_colors_pack_fwd", lib.ts_colors_pack_fwd, n, int(sh_degree), nb, fr.means, fr.origin, fr.colors_dc,
               fr.colors_rest if nb > 1 else None, fr.sh_mask, None, ch, 1, fr.xys, fr.radii, fr.conics,
               fr.opacities, fr.num_tiles_hit, O.cam, fr.depths if ch == 4 else None, fr.splats, s)
-        _call("ts_route_count", lib.ts_route_count, n, fr.xys, fr.radii, O.cam, layout.c_stripes, O.p_route_ws,
+        _call("ts_route_count", lib.ts_route_count_padded, n, fr.xys, fr.radii, O.cam, layout.c_stripes, gb, O.p_route_ws,
               counts.data_ptr(), s)
     else:
-        _lib.check(lib.ts_shard_owner_fwd(ctypes.byref(fr), layout.c_stripes, O.p_route_ws, counts.data_ptr(), s),
-                   "ts_shard_owner_fwd")
-    O.send_counts, O.recv_counts = exchange.counts(counts)
-    total = sum(O.send_counts)
-    send = torch.empty((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
+        _lib.check(lib.ts_shard_owner_fwd_padded(ctypes.byref(fr), layout.c_stripes, gb, O.p_route_ws,
+                                                 counts.data_ptr(), s), "ts_shard_owner_fwd")
+    if O.caps is not None:
+        # nothing of this frame's counts is looked at here: they are gathered, copied to the host behind the launches
+        # already enqueued, and checked where the frame waits for the stripe's pair count (_ShardedFrame.forward)
+        mat = exchange.gather(counts)
+        slot = _count_slots.get((dev.index, world))
+        if slot is None:
+            slot = _count_slots[(dev.index, world)] = torch.empty((world * world,), dtype=torch.int32).pin_memory()
+        slot.copy_(mat.view(-1), non_blocking=True)
+        O.count_host = slot
+        O.count_event = torch.cuda.Event()
+        O.count_event.record(torch.cuda.current_stream(dev))
+        O.send_counts = O.caps[me].tolist()
+        O.recv_counts = O.caps[:, me].tolist()
+        total = sum(O.send_counts)
+        send = torch.zeros((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
+    else:
+        if exchange.can_gather and padded and PADDED_EXCHANGE:
+            host = exchange.gather(counts).cpu()                 # the frame's host read of the record counts
+            O.send_counts, O.recv_counts = host[me].tolist(), host[:, me].tolist()
+            _route_caps[O.key] = _capacity(host.numpy())
+        else:
+            O.send_counts, O.recv_counts = exchange.counts(counts)
+        total = sum(O.send_counts)
+        send = torch.empty((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
     _call("ts_route_pack", lib.ts_route_pack, n, layout.owned[0], fr.xys, fr.radii, fr.depths, fr.splats,
           O.cam, layout.c_stripes, O.p_route_ws, send.data_ptr(), s)
     return O, send
@@ -467,6 +578,21 @@ class _ShardedFrame(torch.autograd.Function):
             O, send = _owner_stage(lib, s, dev, layout, exchange, *inputs, fx, fy, int(sh_degree), ch, keep=True)
             records = exchange.rows(send, O.send_counts, O.recv_counts)
             S, out = _stripe_stage(lib, s, dev, layout, records, background, fx, fy, ch, keep=True)
+            if O.caps is not None:
+                # the padded exchange's deferred look at the counts: every rank holds the same matrix
+                O.count_event.synchronize()
+                world = layout.world
+                mat = O.count_host.numpy().reshape(world, world)
+                fits = bool((mat <= O.caps).all())
+                _route_caps[O.key] = _capacity(mat)
+                padded_frames[0] += 1
+                if not fits:                     # a group outgrew its capacity: again, with exact sizes (all ranks)
+                    padded_frames[1] += 1
+                    del S, out, records, send
+                    O, send = _owner_stage(lib, s, dev, layout, exchange, *inputs, fx, fy, int(sh_degree), ch,
+                                           keep=True, padded=False)
+                    records = exchange.rows(send, O.send_counts, O.recv_counts)
+                    S, out = _stripe_stage(lib, s, dev, layout, records, background, fx, fy, ch, keep=True)
         O.inputs = inputs
         ctx.owner, ctx.stripe, ctx.layout, ctx.exchange = O, S, layout, exchange
         ctx.opacity_shape, ctx.rest_shape, ctx.sh_degree = opacities.shape, colors_rest.shape, int(sh_degree)

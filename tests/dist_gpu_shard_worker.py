@@ -37,6 +37,7 @@ def main():
     layout = ShardLayout(n, world, rank, (w, h))
     w_rgb, w_d = loss_weights(w, h)
     from tinysplat_amd import sharded
+    sharded.PADDED_EXCHANGE = True               # the option under test beside the default exchange (frame 1)
     exchange = DistExchange()
 
     def frame():

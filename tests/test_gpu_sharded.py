@@ -125,13 +125,14 @@ def test_list_segments_in_the_stripes_of_a_sharded_frame(monkeypatch):
     assert frame.last_segments.get(0, 1) > 1           # the stripes (230 tiles each) did take the segmented pass
 
 
-def test_padded_exchange_changes_no_bit_and_repeats_on_overflow():
-    """sharded.PADDED_EXCHANGE with the replayed records of bench.py --emulate-ranks (one rank of four on one GPU):
+def test_padded_exchange_changes_no_bit_and_repeats_on_overflow(monkeypatch):
+    """sharded.PADDED_EXCHANGE (TS_PADDED_EXCHANGE=1) with the replayed records of bench.py --emulate-ranks (one rank of four on one GPU):
     frame 1 reads the counts, frame 2 runs padded from frame 1's count matrix - no host read before the exchange -
     and frame 3, handed capacities that are too small, notices at the end of its forward pass and runs again with
     exact sizes.  Image and gradients bit for bit the same in all three."""
     from tinysplat_amd import sharded
     from tinysplat_amd.sharded import ReplayExchange
+    monkeypatch.setattr(sharded, "PADDED_EXCHANGE", True)        # an option (off by default)
     n, sh, w, h, world, rank = 60000, 2, 640, 360, 4, 1
     model, cam = make_scene(n, sh, w, h, seed=9, scale_mult=2.0)
     parts, counts = [], []

@@ -50,18 +50,23 @@ from .synthetic import SplatModel
 RECORD_FLOATS = 16       # TS_EXPORT_RECORD_FLOATS
 ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS
 
-# PADDED EXCHANGE (TS_PADDED_EXCHANGE=0 switches it off): how many records a rank sends to every other rank is known
-# only after its owner stage has run, and sizing the all_to_all from it costs a host read in the middle of the frame -
-# the GPU idles while the host waits for the counts, allocates and enqueues the rest (~45 us of a 0.41 ms rank step
-# on config 3 at 8 ranks).  From the second frame of a layout on, every (source, destination) group instead gets the
+# PADDED EXCHANGE (an option: TS_PADDED_EXCHANGE=1 switches it on): how many records a rank sends to every other rank
+# is known only after its owner stage has run, and sizing the all_to_all from it costs a host read in the middle of
+# the frame - where the GPU is what bounds a rank's step, it idles while the host waits for the counts, allocates and
+# enqueues the rest.  With the option, from the second frame of a layout on, every (source, destination) group gets the
 # CAPACITY the previous frame's count matrix suggests (+ 12.5 % + 192 rows, multiples of 64): the send buffer is zeroed
 # (an all-zero record lists nothing: radius 0), ts_route_count_padded fixes the groups' bases, the all_to_all runs with
 # the capacities as split sizes, and the whole forward pass is enqueued without looking at a count.  The counts travel
 # anyway - one all_gather of `world` ints per rank gives EVERY rank the whole matrix - and are read where the frame
 # already waits for the stripe's pair count: if any group outgrew its capacity, every rank sees it in the same matrix
 # and all of them run the forward pass again with exact sizes (no extra collective to agree on that).
+# Why it is not the default: on config 3 at 8 ranks the emulated rank step is bound by the HOST (~0.44 ms of Python per
+# step against 0.36 ms of kernels: tools/host_split_rank.py), the GPU is already waiting when the read happens, and
+# the option's own bookkeeping (zeroed buffer, pinned copy, event, the check) adds ~40 us of Python: 0.46 -> 0.56 ms
+# on the slowest box, 0.43 -> 0.44 ms on the fastest.  On config 5 (GPU-bound, 0.95 ms) it is neutral.  What the
+# blocking read costs on eight real devices cannot be measured here.
 import os as _os
-PADDED_EXCHANGE = _os.environ.get("TS_PADDED_EXCHANGE", "1") != "0"
+PADDED_EXCHANGE = _os.environ.get("TS_PADDED_EXCHANGE", "0") == "1"
 _route_caps = {}         # layout key -> capacity matrix [world][world] derived from the previous frame's counts
 _count_slots = {}        # (device index, world) -> pinned int32[world * world] the gathered counts are copied into
 padded_frames = [0, 0]   # frames that ran padded / padded frames that had to run again (tests, tools)

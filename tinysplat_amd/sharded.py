@@ -31,6 +31,8 @@ one process on one GPU (full-size functional checks and the per-stage table of a
 from __future__ import annotations
 
 import ctypes
+import os
+
 import numpy as np
 from typing import List, Optional, Sequence, Tuple
 
@@ -65,8 +67,7 @@ ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS
 # the option's own bookkeeping (zeroed buffer, pinned copy, event, the check) adds ~40 us of Python: 0.46 -> 0.56 ms
 # on the slowest box, 0.43 -> 0.44 ms on the fastest.  On config 5 (GPU-bound, 0.95 ms) it is neutral.  What the
 # blocking read costs on eight real devices cannot be measured here.
-import os as _os
-PADDED_EXCHANGE = _os.environ.get("TS_PADDED_EXCHANGE", "0") == "1"
+PADDED_EXCHANGE = os.environ.get("TS_PADDED_EXCHANGE", "0") == "1"
 _route_caps = {}         # layout key -> capacity matrix [world][world] derived from the previous frame's counts
 _count_slots = {}        # (device index, world) -> pinned int32[world * world] the gathered counts are copied into
 padded_frames = [0, 0]   # frames that ran padded / padded frames that had to run again (tests, tools)

@@ -84,6 +84,13 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_route_count(0, None, None, cam, bad, ws, ws, None) == -1
     bad.num = 17                                                                       # more than TS_MAX_RANKS
     assert lib.ts_route_count(0, None, None, cam, bad, ws, ws, None) == -1
+    # padded groups (round 4): the bases must be ascending and non-negative; NULL = ts_route_count
+    gb_bad = (ctypes.c_int32 * 3)(0, 128, 64)
+    assert lib.ts_route_count_padded(0, None, None, cam, st, gb_bad, ws, ws, None) == -1
+    gb_neg = (ctypes.c_int32 * 3)(-64, 0, 64)
+    assert lib.ts_route_count_padded(0, None, None, cam, st, gb_neg, ws, ws, None) == -1
+    assert lib.ts_route_count_padded(4, None, None, cam, st, None, None, None, None) == -1   # no workspace
+    assert lib.ts_shard_owner_fwd_padded(None, st, None, None, None, None) == -1
     assert lib.ts_route_pack(4, 0, None, None, None, None, cam, st, ws, None, None) == -1
     assert lib.ts_route_accumulate(4, 5, *([None] * 4), cam, st, ws, *([None] * 7)) == -1
     assert lib.ts_import_records(-1, None, cam, None, None, None, None, None) == -1

@@ -50,6 +50,9 @@ class CollectiveTimer:
 collective_timer = CollectiveTimer()
 
 
+gather_usable = True     # cleared by the preflight when the backend cannot all_gather the record counts
+
+
 def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
     """Every rank runs the SAME tiny ``all_to_all_single`` with uneven split sizes (the call shape of
     sharded.DistExchange.rows) and the ``all_gather`` of the record counts (DistExchange.gather) before any frame,
@@ -70,7 +73,14 @@ def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
         want = torch.cat([torch.full((c, 4), float(s)) for s, c in enumerate(recv_counts)])
         if not torch.equal(got.cpu(), want):
             ok, err = 0, "all_to_all_single with split sizes returned wrong rows"
-        # the count matrix of the padded exchange (sharded.DistExchange.gather): one all_gather of `world` ints
+    except Exception as e:                                      # noqa: BLE001 - whatever the backend raises
+        ok, err = 0, f"{type(e).__name__}: {e}"
+    # the count matrix of the OPTIONAL padded exchange (sharded.DistExchange.gather): one all_gather of `world` ints.
+    # A backend that cannot do it only loses that option (`gather_usable`), not the sharded design.
+    g_ok = 1
+    try:
+        via_host = dist.get_backend(group) == "gloo"
+        dev = torch.device("cpu") if via_host else device
         mine = torch.arange(world, dtype=torch.int32, device=dev) + 100 * rank
         if via_host:
             parts = [torch.empty_like(mine) for _ in range(world)]
@@ -80,10 +90,12 @@ def preflight_sharded_exchange(device, group=None) -> Tuple[bool, str]:
             mat = torch.empty((world, world), dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(mat.view(-1), mine, group=group)
         want_m = torch.arange(world, dtype=torch.int32)[None, :] + 100 * torch.arange(world, dtype=torch.int32)[:, None]
-        if ok and not torch.equal(mat.cpu(), want_m):
-            ok, err = 0, "all_gather returned a wrong count matrix"
-    except Exception as e:                                      # noqa: BLE001 - whatever the backend raises
-        ok, err = 0, f"{type(e).__name__}: {e}"
-    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) != "gloo" else "cpu")
+        if not torch.equal(mat.cpu(), want_m):
+            g_ok = 0
+    except Exception:                                           # noqa: BLE001
+        g_ok = 0
+    flag = torch.tensor([ok, g_ok], dtype=torch.int32, device=device if dist.get_backend(group) != "gloo" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(int(flag.item())), err
+    global gather_usable
+    gather_usable = bool(int(flag[1].item()))
+    return bool(int(flag[0].item())), err

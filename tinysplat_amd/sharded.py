@@ -40,6 +40,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from . import _comm
 from ._comm import collective_timer
 from . import _lib
 from . import frame as _frame
@@ -328,7 +329,8 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
     O.fr = fr
     # padded exchange (see PADDED_EXCHANGE): capacities from the previous frame of this layout, if there was one
     O.key = _layout_key(dev, layout)
-    O.caps = _route_caps.get(O.key) if (padded and PADDED_EXCHANGE and exchange.can_gather) else None
+    use_gather = padded and PADDED_EXCHANGE and exchange.can_gather and _comm.gather_usable
+    O.caps = _route_caps.get(O.key) if use_gather else None
     O.count_host = O.count_event = None
     me, world = layout.rank, layout.world
     gb = None
@@ -365,7 +367,7 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
         total = sum(O.send_counts)
         send = torch.zeros((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
     else:
-        if exchange.can_gather and padded and PADDED_EXCHANGE:
+        if use_gather:
             host = exchange.gather(counts).cpu()                 # the frame's host read of the record counts
             O.send_counts, O.recv_counts = host[me].tolist(), host[:, me].tolist()
             _route_caps[O.key] = _capacity(host.numpy())

@@ -45,7 +45,7 @@ from ._comm import collective_timer
 from . import _lib
 from . import frame as _frame
 from ._lib import TsFrame, TsStripes
-from .ops import TileBinning, _call, _camera, kernel_timer, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
+from .ops import _call, _camera, kernel_timer, _f32c, _need_hip, _stream, _stripe_rows, _tile_bounds, deg_from_sh
 from .rasterizer import camera_on_device
 from .sharding import stripe_rows
 from .synthetic import SplatModel
@@ -276,8 +276,31 @@ class _Owner:
 
 
 class _Stripe:
-    __slots__ = ("m", "cam", "fr", "ws", "split", "segs", "mode", "bucket", "total", "num_tiles", "tile_bins", "nth", "cum",
+    __slots__ = ("m", "cam", "fr", "ws", "split", "segs", "mode", "bucket", "total", "num_tiles", "offs",
                  "bg", "records")
+
+
+class _LazyBinning:
+    """frame.last_binning entry of a stripe: the views into the stripe's workspace (scene statistics for bench.py /
+    tools) are made when somebody asks for them, not on every frame of a training loop."""
+    __slots__ = ("cam", "n", "num_tiles", "num_intersects", "_ws", "_offs", "_bucket", "_cap")
+
+    @property
+    def tile_bins(self):
+        nt = max(self.num_tiles, 1)
+        return _view(self._ws, self._offs[8], torch.int32, 2 * nt, (nt, 2))[:self.num_tiles]
+
+    @property
+    def gaussian_ids_sorted(self):
+        return self._bucket[self._cap:self._cap + self.num_intersects]
+
+    @property
+    def cum_tiles_hit(self):
+        return _view(self._ws, self._offs[4], torch.int32, self.n, (self.n,))
+
+    @property
+    def num_tiles_hit(self):
+        return _view(self._ws, self._offs[3], torch.int32, self.n, (self.n,))
 
 
 def _carve(dev, sizes):
@@ -374,7 +397,8 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
         else:
             O.send_counts, O.recv_counts = exchange.counts(counts)
         total = sum(O.send_counts)
-        send = torch.empty((max(total, 1), RECORD_FLOATS), dtype=torch.float32, device=dev)[:total]
+        send = torch.empty((total, RECORD_FLOATS), dtype=torch.float32, device=dev) if total > 0 else \
+            torch.empty((1, RECORD_FLOATS), dtype=torch.float32, device=dev)[:0]
     _call("ts_route_pack", lib.ts_route_pack, n, layout.owned[0], fr.xys, fr.radii, fr.depths, fr.splats,
           O.cam, layout.c_stripes, O.p_route_ws, send.data_ptr(), s)
     return O, send
@@ -403,9 +427,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     #   xys | depths | radii | nth | cum | splats | scan_ws | bin_ws | tile_bins | final_Ts | final_index | clamp_mask
     S.ws, ptr, offs = _carve(dev, [8 * mm, 4 * mm, 4 * mm, 4 * mm, 4 * mm, 48 * mm, 4 * nscan, 4 * nbin,
                                    8 * max(num_tiles, 1)] + ([4 * px * fin_planes, 4 * px, px] if keep else []))
-    S.nth = _view(S.ws, offs[3], torch.int32, m, (m,))
-    S.cum = _view(S.ws, offs[4], torch.int32, m, (m,))
-    S.tile_bins = _view(S.ws, offs[8], torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
+    S.offs = offs
     out_img = torch.empty((rows, w, ch), dtype=torch.float32, device=dev)
     if ch == 4:            # channel 3 is composited over background[0], as the reference's depth pass (:86)
         S.bg = _f32c(torch.cat([background, background[:1]]))
@@ -445,7 +467,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
             _call("ts_import_records", lib.ts_import_records, m, records.data_ptr(), cam, fr.xys, fr.depths, fr.radii,
                   fr.num_tiles_hit, s)
             _call("ts_scan_tiles", lib.ts_scan_tiles, m, fr.num_tiles_hit, fr.cum_tiles_hit, fr.scan_ws, None, s)
-            host.copy_(S.cum[m - 1:m], non_blocking=True)
+            host.copy_(_view(S.ws, offs[4], torch.int32, m, (m,))[m - 1:m], non_blocking=True)
             _call("ts_import_pack", lib.ts_import_pack, m, records.data_ptr(), fr.cum_tiles_hit, cam, fr.splats, s)
         _call("ts_bin_count", lib.ts_bin_count, m, fr.xys, fr.radii, tight, cam, fr.bin_ws, s)
         _call("ts_tile_offsets", lib.ts_tile_offsets, m, num_tiles, fr.bin_ws, fr.tile_bins, fr.cum_tiles_hit,
@@ -498,10 +520,9 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
         composite()
     else:
         fr.num_intersects = total
-    b = TileBinning()                        # scene statistics of the most recent frame (bench.py / tools)
+    b = _LazyBinning()                       # scene statistics of the most recent frame (bench.py / tools)
     b.cam, b.n, b.num_tiles, b.num_intersects = cam, m, num_tiles, total
-    b.tile_bins, b.gaussian_ids_sorted, b.cum_tiles_hit, b.num_tiles_hit = (S.tile_bins[:num_tiles],
-                                                                             S.bucket[cap:cap + total], S.cum, S.nth)
+    b._ws, b._offs, b._bucket, b._cap = S.ws, offs, S.bucket, cap
     _frame.last_binning[dev.index] = b
     return S, out_img
 
@@ -516,7 +537,7 @@ def _stripe_backward(lib, s, dev, S: _Stripe, ch: int, v_img: Tensor) -> Tensor:
     rows_n = max(S.total, 1) * (4 if bwd_split else 1)
     partials = torch.empty((rows_n, _lib.PARTIAL_ROW_FLOATS), **f32)
     row_flags, fr.flag_gen = _frame.row_flags_for(dev, rows_n)
-    grad_rows = torch.empty((max(m, 1), ROW_FLOATS), **f32)[:m]
+    grad_rows = torch.empty((m, ROW_FLOATS), **f32) if m > 0 else torch.empty((1, ROW_FLOATS), **f32)[:0]
     fr.v_out_img, fr.partials, fr.row_flags = v_img.data_ptr(), partials.data_ptr(), row_flags.data_ptr()
     if kernel_timer.enabled:
         gen = (fr.flag_gen & 0xff) << 8
@@ -538,13 +559,15 @@ def _owner_backward(lib, s, dev, layout: ShardLayout, O: _Owner, back: Tensor, s
     f32 = dict(dtype=torch.float32, device=dev)
     n, ch, fr = O.n, O.ch, O.fr
     nn = max(n, 1)
-    v_xy = torch.empty((nn, 2), **f32)[:n]
-    v_opac = torch.empty((nn,) + tuple(opacity_shape[1:]), **f32)[:n]
-    v_means = torch.empty((nn, 3), **f32)[:n]
-    v_scales = torch.empty((nn, 3), **f32)[:n]
-    v_quats = torch.empty((nn, 4), **f32)[:n]
-    v_dc = torch.empty((nn, 3), **f32)[:n]
-    v_rest = torch.empty((nn,) + tuple(rest_shape[1:]), **f32)[:n]
+    def rows_of(*tail):               # [n, *tail] (a slice of one row when there are none: the pointers stay valid)
+        return torch.empty((n,) + tail, **f32) if n > 0 else torch.empty((1,) + tail, **f32)[:0]
+    v_xy = rows_of(2)
+    v_opac = rows_of(*opacity_shape[1:])
+    v_means = rows_of(3)
+    v_scales = rows_of(3)
+    v_quats = rows_of(4)
+    v_dc = rows_of(3)
+    v_rest = rows_of(*rest_shape[1:])
     tmp = torch.empty((nn * 7,), **f32)                      # v_conic | v_colors | v_depth
     fr.v_xy, fr.v_opacity = v_xy.data_ptr(), v_opac.data_ptr()
     fr.v_conic, fr.v_colors, fr.v_depth = tmp.data_ptr(), tmp.data_ptr() + 12 * nn, tmp.data_ptr() + 24 * nn

@@ -1,3 +1,9 @@
+#!/usr/bin/env python
+"""Where the HOST's time goes in one emulated rank step of the Gaussian-sharded frame (developer tool, GPU box):
+config 3, rank 4 of 8, the other ranks' records replayed (sharded.ReplayExchange, as bench.py --emulate-ranks).
+Wall-clock per step next to the time spent inside the stage functions of sharded.py, the autograd node and
+loss.backward() - with list segments the rank's kernels sum to ~0.37 ms while the step takes 0.41 - 0.46 ms: the
+step is bound by the interpreter.  TS_PADDED_EXCHANGE=1 to see the option's own cost."""
 import sys, time, functools, collections
 sys.path.insert(0, '/root/repo')
 import torch

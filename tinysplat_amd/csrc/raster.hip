@@ -33,9 +33,9 @@
 //     removed 12 % of the instructions and none of the time).  The file is built with -fno-slp-vectorize
 //     because the SLP packer's register shuffles cost issue slots on top.
 //   * Backward: per-lane partial sums over its <= 4 pixels, then a DPP butterfly that merges
-//     eight value vectors while it reduces (quad_perm / row_ror DPP inside rows of 16, ds_bpermute
-//     across rows) and lanes 48.. write one 48-byte row of raw sums per (tile, Gaussian) into a slot
-//     that is contiguous per Gaussian.  reduce_partials sums each Gaussian's rows in a fixed order
+//     the value vectors while it reduces (row_ror / row_half_mirror DPP under bank masks inside rows of 16,
+//     v_permlane16_swap / v_permlane32_swap across rows) and a few lanes write one 48-byte row of raw sums per
+//     (tile, Gaussian) into a slot that is contiguous per Gaussian.  reduce_partials sums each Gaussian's rows in a fixed order
 //     and applies the conic / opacity factors once: no float atomics, and the gradients are
 //     bit-reproducible run to run.
 #include <hip/hip_runtime.h>

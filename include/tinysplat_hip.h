@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 5
+#define TS_ABI_VERSION 6
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -65,19 +65,29 @@ typedef struct ts_camera {
      * TS_HINT_BALANCED_WALK: a Gaussian covers many tiles (>= ~10 bounding-box tiles on average): ts_bin_scatter
      * expands (Gaussian, tile row) items over the lanes instead of looping per Gaussian.
      * bits 8..11: LIST SEGMENTS S of the compositing passes (TS_CAM_LIST_SEGMENTS(S), 0 / 1 = off, S <= 8; 16x16
-     * lists only).  For launches of fewer tiles than the GPU has SIMDs, instead of TS_RASTER_SPLIT_BLOCKS in the
-     * BACKWARD pass: ts_raster_fwd* under TS_RASTER_SPLIT_BLOCKS additionally stores the per-pixel state at up to S - 1 boundaries
-     * of every list of >= 256 entries behind final_Ts, which must then hold ts_final_planes(S, channels) planes of
-     * rows*W floats, and ts_raster_bwd* WITHOUT the split flag replays every list as up to S independent work items
-     * (one row per pair, the plain ts_reduce_partials; the forward launch must have been a split one).  Same image; gradients equal to the uncut pass's up to
-     * rounding (a segment starts from the forward pass's own transmittance).  With TS_RASTER_SPLIT_BLOCKS, wide
-     * tiles or narrow waves ts_raster_bwd* ignores the field. */
+     * lists only).  The backward pass of a tile is a chain over its sorted list; with S > 1 ts_raster_fwd* additionally
+     * stores, for every CUT tile, the per-pixel state at up to S - 1 boundaries of its list (lists of >= 65 entries)
+     * behind final_Ts - which must then hold ts_final_floats(cam, channels) floats - and ts_raster_bwd* WITHOUT
+     * TS_RASTER_SPLIT_BLOCKS replays a cut tile's list as up to S independent one-wave work items (one row per pair,
+     * the plain ts_reduce_partials).  Same image; gradients equal to the uncut pass's up to rounding (a segment
+     * starts from the forward pass's own transmittance).  Both passes must see the same S and W16.  With
+     * TS_RASTER_SPLIT_BLOCKS, wide tiles or narrow waves ts_raster_bwd* ignores the field.
+     * bits 12..15: W16 (TS_CAM_WHOLE_TILES(W16), 0..15) - which tiles are cut: 0 = all of them (launches of fewer
+     * tiles than the GPU has SIMDs: instead of TS_RASTER_SPLIT_BLOCKS in the backward pass); 1..15 = a HYBRID
+     * launch for full frames: the tiles are handed out in eight bands (one per XCD) and the first W16/16 of every
+     * band stay whole, only the tiles dispatched last are cut, so that their small work items fill the wave slots
+     * the whole tiles leave behind at the end of the launch (ts_cut_tiles tells which). */
     int32_t hints;
 } ts_camera;
 #define TS_HINT_BALANCED_WALK 1
 #define TS_CAM_LIST_SEGMENTS(s) (((s) & 15) << 8)
-/* float planes (rows*W each) final_Ts must hold for S list segments: 1 + (S-1)(1+channels) */
-int32_t ts_final_planes(int32_t list_segments, int32_t channels);
+#define TS_CAM_WHOLE_TILES(w16) (((w16) & 15) << 12)
+/* floats final_Ts must hold: the rows*W transmittances, then (S > 1, 16x16 lists) one checkpoint block of
+ * S records of (1+channels) 256 floats per cut tile, from a 64-float aligned offset; < 0: bad argument */
+int64_t ts_final_floats(const ts_camera* cam_host, int32_t channels);
+/* -> number of checkpoint blocks (>= cut tiles) of a launch under cam's S / W16; *band = tiles per band (tile t lies
+ * in band t / band), *whole = the first `whole` tiles of every band are composited whole (either may be NULL) */
+int32_t ts_cut_tiles(const ts_camera* cam_host, int32_t* band, int32_t* whole);
 /* tiles (= lists) of a launch: tile_rows * tile_bounds_x, or tile_rows * ceil(tile_bounds_x / 2) when wide */
 int32_t ts_num_tiles(const ts_camera* cam_host);
 

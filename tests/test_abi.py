@@ -36,14 +36,31 @@ def test_binding_covers_the_header_and_version_matches():
     from tinysplat_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.ts_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 6
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
-    # list segments (ts_camera.hints bits 8..11): planes behind final_Ts, and the Python side's own formula
-    assert [lib.ts_final_planes(s_, c_) for s_, c_ in ((0, 3), (1, 4), (2, 3), (8, 3), (8, 4), (15, 4))] == [1, 1, 5, 29, 36, 36]
+    # list segments (ts_camera.hints bits 8..11) and the whole-tile share of a hybrid launch (bits 12..15): floats
+    # behind final_Ts = T_fin + one checkpoint block of S records of (1+channels) 256 floats per cut tile
     from tinysplat_amd import frame
-    assert all(frame._list_segments(t, 0, True) == max(2, min(8, 8192 // t)) for t in (1, 200, 1020, 1536, 5000)) \
+    from tinysplat_amd.ops import _camera, _tile_bounds
+    cam = _camera(1.0, 1.0, 960.0, 540.0, 1080, 1920, _tile_bounds(1080, 1920), 1.0)
+    px = 1920 * 1080
+    assert lib.ts_final_floats(ctypes.byref(cam), 3) == px and lib.ts_final_floats(ctypes.byref(cam), 5) < 0
+    band, whole = ctypes.c_int32(), ctypes.c_int32()
+    cam.hints = (4 << 8)                                   # every tile cut
+    assert lib.ts_cut_tiles(ctypes.byref(cam), ctypes.byref(band), ctypes.byref(whole)) == 8160
+    assert (band.value, whole.value) == (1020, 0)
+    assert lib.ts_final_floats(ctypes.byref(cam), 3) == px + 8160 * 4 * 4 * 256
+    assert lib.ts_final_floats(ctypes.byref(cam), 4) == px + 8160 * 4 * 5 * 256
+    cam.hints = (4 << 8) | (10 << 12)                      # hybrid: the first 10/16 of every band whole
+    assert lib.ts_cut_tiles(ctypes.byref(cam), ctypes.byref(band), ctypes.byref(whole)) == 8 * (1020 - 636)
+    assert (band.value, whole.value) == (1020, 636)
+    assert lib.ts_final_floats(ctypes.byref(cam), 3) == px + 8 * 384 * 4 * 4 * 256
+    cam.wide_tiles = 1
+    assert lib.ts_final_floats(ctypes.byref(cam), 3) == px
+    assert all(frame._list_segments(t, 0, True) == (max(2, min(8, 8192 // t)), 0) for t in (1, 200, 1020, 1536, 5000)) \
         or frame.LIST_SEGMENTS != "auto"
-    assert frame._list_segments(1020, 2, True) == 1 and frame._list_segments(1020, 0, False) == 1
+    assert frame._list_segments(1020, 2, True) == (1, 0) and frame._list_segments(1020, 0, False) == (1, 0)
+    assert frame._list_segments(8160, 0, False) == ((frame.HYBRID_SEGS, frame.HYBRID_WHOLE16) if frame.HYBRID_SEGS > 1 else (1, 0))
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + hints (ABI 3; the second word was `reserved` until round 4)
     assert ctypes.sizeof(_lib.TsStripes) == 4 * (_lib.MAX_RANKS + 2)

@@ -143,20 +143,30 @@ def test_frame_path_at_full_size_tight_lists_stripes_and_forward_only():
     w_rgb = torch.rand(H, W, 3, generator=g).to(DEV)
     w_d = torch.rand(H, W, generator=g).to(DEV)
     res, listed = [], []
+    hybrid = frame.HYBRID_SEGS
     try:
-        for tight in (False, True):
-            frame.TIGHT_BINNING = tight
+        # (the boundaries of list segments depend on a list's length: gradients are bitwise equal across list shapes
+        # only between uncut launches; the hybrid launch is compared with the uncut one below)
+        for tight, segs in ((False, 1), (True, 1), (True, hybrid)):
+            frame.TIGHT_BINNING, frame.HYBRID_SEGS = tight, segs
             md = model.to(DEV).requires_grad_(True)
             r = GaussianRasterizer(md, None, device=torch.device(DEV))
             rgb, ex = r(cam, (W, H), 3)
             ((rgb * w_rgb).sum() + (ex["depth"] * w_d).sum()).backward()
             listed.append(int(frame.last_binning[0].tile_bins[:, 1].max()))
             res.append([rgb.detach(), ex["depth"].detach(), ex["xys"].grad] + [p.grad for p in md.parameters()])
+            assert frame.last_segments[0] == segs
     finally:
-        frame.TIGHT_BINNING = True
-    for a, b in zip(*res):
+        frame.TIGHT_BINNING, frame.HYBRID_SEGS = True, hybrid
+    for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
     assert listed[1] < 0.75 * listed[0]
+    # the default full-frame launch (hybrid: the tiles dispatched last are cut into list segments): image and depth
+    # bitwise, gradients to rounding
+    assert hybrid > 1 and torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1])
+    for a, b in zip(res[1][2:], res[2][2:]):
+        tol = 2e-6 * max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
     rgb_full = res[1][0]
     with torch.no_grad():
         rgb_view, ex_view = r(cam, (W, H), 3)

@@ -229,14 +229,31 @@ def test_raster_bwd_deterministic():
 _ORACLE_FRAMES = {}
 
 
+def _cut_tile_mask(num_tiles: int, whole16: int) -> torch.Tensor:
+    """which tiles a hybrid launch cuts (csrc/raster.hip: cut_tiles; ts_cut_tiles reports band and whole)"""
+    band = 4 * ((num_tiles + 31) // 32)
+    whole = ((band * whole16) // 16) & ~3
+    return (torch.arange(num_tiles) % band) >= whole
+
+
 @pytest.mark.parametrize("n,sh,w,h,mult,fused", [(10000, 0, 256, 256, 2.0, False),
                                                   (30000, 3, 480, 270, 2.0, False),
                                                   (30000, 3, 480, 270, 2.0, True),
                                                   (30000, 3, 480, 270, 2.0, "one-node"),
+                                                  (30000, 3, 480, 270, 2.0, "hybrid"),
                                                   (5000, 1, 200, 120, 4.0, "one-node")])
-def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
+def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused, monkeypatch):
     """The whole adapter (project -> SH -> rasterize RGB -> rasterize depth) fwd + bwd to the six
-    parameter tensors, HIP vs the same recipe run with the oracle ops (float32, CPU autograd)."""
+    parameter tensors, HIP vs the same recipe run with the oracle ops (float32, CPU autograd).
+    "hybrid": the one-node frame with the full-frame launch shape forced on this small image - one wave per tile,
+    the last half of every band of tiles cut into list segments (csrc/raster.hip: HYBRID LAUNCH)."""
+    if fused == "hybrid":
+        from tinysplat_amd import frame
+        monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 0)
+        monkeypatch.setattr(frame, "HYBRID_FROM", 1)
+        monkeypatch.setattr(frame, "HYBRID_SEGS", 8)
+        monkeypatch.setattr(frame, "HYBRID_WHOLE16", 8)
+        monkeypatch.setattr(frame, "LIST_SEGMENTS_FROM", 1)
     model, cam = scene_args(n, sh, w, h, seed=21, scale_mult=mult)
     model.background = torch.tensor([0.2, 0.3, 0.1])
     key = (n, sh, w, h, mult)
@@ -256,10 +273,15 @@ def test_rasterizer_frame_matches_oracle_frame(n, sh, w, h, mult, fused):
 
     md = model.to(DEV).requires_grad_(True)
     r = GaussianRasterizer(md, None, device=torch.device(DEV), fused_colors=bool(fused))
-    r.single_node = fused == "one-node"          # frame.py: the fused recipe as one autograd node
+    r.single_node = fused in ("one-node", "hybrid")          # frame.py: the fused recipe as one autograd node
     rgb, extras = r(cam, (w, h), sh)
     ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
+    if fused == "hybrid":                  # the launch was a hybrid one and it did cut lists
+        assert frame.last_segments[0] == 8
+        lens = (frame.last_binning[0].tile_bins[:, 1] - frame.last_binning[0].tile_bins[:, 0]).cpu()
+        cut = _cut_tile_mask(lens.numel(), 8)
+        assert int((lens[cut] >= 65).sum()) > 50 and int((~cut).sum()) > 100
     assert torch.equal(extras["radii"].cpu(), f["radii"])
     assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb")
     assert_close_masked(extras["depth"], f["depth"], 1e-5 * 10.0, stable, what="depth")   # depth values reach 10
@@ -664,6 +686,54 @@ def test_list_segments_replace_split_blocks_in_backward(segs, monkeypatch):
     rgb, ex = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (256, 256), 0)
     rgb.sum().backward()
     assert frame.last_segments[0] == 1
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_hybrid_launch_cuts_only_the_last_tiles(depth, monkeypatch):
+    """HYBRID LAUNCH (full frames; forced here on 425 tiles): one wave per tile, and the tiles that are dispatched last
+    - the last 5/16 of every band - become 8 list-segment items each in the backward pass, from the boundary records
+    the forward pass keeps for them.  Image, depth and sorted lists are bitwise those of the uncut launch, gradients
+    agree with it to rounding, two runs agree bit for bit, and ts_cut_tiles tells the same tiles as the kernels use."""
+    import ctypes
+    from tinysplat_amd import _lib, frame
+    from tinysplat_amd.frame import render_frame
+    n, w, h = 120000, 400, 272          # 25 x 17 = 425 tiles, image not a multiple of 16
+    model, cam = scene_args(n, 1, w, h, seed=43, scale_mult=2.0)
+    g = torch.Generator().manual_seed(44)
+    wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 0)
+    monkeypatch.setattr(frame, "HYBRID_FROM", 1)
+    monkeypatch.setattr(frame, "HYBRID_WHOLE16", 11)
+    view = cam.view_matrix.to(DEV)
+    projview = (cam.proj_matrix @ cam.view_matrix).to(DEV).contiguous()
+    res, used = [], []
+    for segs in (1, 8, 8):
+        monkeypatch.setattr(frame, "HYBRID_SEGS", segs)
+        md = model.to(DEV).requires_grad_(True)
+        out, xys, _ = render_frame(md, view[:3, :].contiguous(), projview, view[:3, 3].contiguous(), cam.f_x, cam.f_y,
+                                   w, h, with_depth=depth)
+        loss = (out[:, :, :3] * wr).sum() + ((out[:, :, 3] * wd).sum() if depth else 0.0)
+        loss.backward()
+        used.append(frame.last_segments[0])
+        b = frame.last_binning[0]
+        res.append([out.detach(), b.gaussian_ids_sorted[:int(b.tile_bins[:, 1].max())].clone(), xys.grad]
+                   + [p.grad for p in md.parameters()])
+    assert used == [1, 8, 8], used
+    for a, b in zip(res[0][:2], res[1][:2]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][2:], res[1][2:]):
+        tol = 2e-6 * max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
+    assert not all(torch.equal(a, b) for a, b in zip(res[0][2:], res[1][2:]))      # (the cut did happen)
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b)
+    lib = _lib.load()
+    c = frame.last_binning[0].cam
+    band, whole = ctypes.c_int32(), ctypes.c_int32()
+    blocks = lib.ts_cut_tiles(ctypes.byref(c), ctypes.byref(band), ctypes.byref(whole))
+    assert (band.value, whole.value, blocks) == (56, 36, 8 * 20)
+    lens = (frame.last_binning[0].tile_bins[:, 1] - frame.last_binning[0].tile_bins[:, 0]).cpu()
+    assert int((lens[_cut_tile_mask(425, 11)] >= 65).sum()) > 100
 
 
 def test_tight_binning_stress_anisotropic_faint_and_opaque(monkeypatch):

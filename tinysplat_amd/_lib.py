@@ -11,7 +11,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
 
@@ -88,7 +88,8 @@ SIGNATURES = {
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sort_tiles_above": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_num_tiles": (c_int32, [_CAM]),
-    "ts_final_planes": (c_int32, [c_int32, c_int32]),
+    "ts_final_floats": (c_int64, [_CAM, c_int32]),
+    "ts_cut_tiles": (c_int32, [_CAM, _P, _P]),
     "ts_colors_pack_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
                                      _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),
     "ts_pack_splats": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _CAM, _P, _P, _P]),

@@ -40,6 +40,8 @@
 //     bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/tinysplat_hip.h"
 #include "splat_math.h"
 
@@ -52,6 +54,9 @@ namespace {
 #endif
 #ifndef TS_FWD_MIN_WAVES_RGB
 #define TS_FWD_MIN_WAVES_RGB 5         // the 16x16, three-channel forward kernel keeps its five waves per SIMD (<= 96 VGPRs)
+#endif
+#ifndef TS_FWD_MIN_WAVES_RGBD
+#define TS_FWD_MIN_WAVES_RGBD 4        // ... and the four-channel one its four (<= 128; the hybrid instantiation would take 138)
 #endif
 #ifndef TS_BWD_MIN_WAVES
 #define TS_BWD_MIN_WAVES 1
@@ -373,6 +378,15 @@ constexpr int kSegMax = 8;
 #ifndef TS_SEG_SHAPE
 #define TS_SEG_SHAPE 2
 #endif
+#ifndef TS_FWD_LATE_PREFETCH
+#define TS_FWD_LATE_PREFETCH 0
+#endif
+#ifndef TS_FWD_CUT_FIRST
+#define TS_FWD_CUT_FIRST 1
+#endif
+#ifndef TS_LOC_LDS
+#define TS_LOC_LDS 0                   // 1: the per-segment sums of a whole-tile wave in LDS (LocLds) instead of registers: slower
+#endif
 #ifndef TS_SEG_CAP_CHUNKS
 #define TS_SEG_CAP_CHUNKS 0
 #endif
@@ -389,9 +403,56 @@ __device__ __forceinline__ int seg_bound(int list_len, int S, int s) {
     }
     return b << 6;
 }
-__device__ __forceinline__ size_t seg_plane_stride(const ts_camera& cam) {
+__host__ __device__ __forceinline__ size_t seg_plane_stride(const ts_camera& cam) {
     const int rows = min(16 * cam.tile_rows, cam.img_height - 16 * cam.tile_row0);
     return (size_t)cam.img_width * (size_t)max(rows, 0);
+}
+
+// HYBRID LAUNCH (bits 12..15 of ts_camera.hints = W16 in 1..15, together with S > 1; one wave per 16x16 tile on 16x16
+// lists).  A full frame is two rounds of ~200-us waves (8 160 tiles on 4 096 / 5 120 wave slots) whose last third runs
+// half empty; cutting EVERY list costs as much as the tail it removes (profiles/HISTORY.md, round 4).  So only the tiles
+// that are dispatched LAST are cut: the tiles are handed out in eight bands (one per XCD, see xcd_tile_group), the first
+// W16/16 of a band as whole tiles exactly as without segments, the rest as S list-segment items each - the small items
+// fill the slots the whole tiles leave behind.  Which tile is cut is a function of (tile, num_tiles, W16) alone, so the
+// forward pass (which keeps the boundary state for the cut tiles only) and the backward pass agree without a table.
+// W16 = 0 with S > 1: every tile is cut (the small launches).
+// CHECKPOINTS live behind final_Ts at float offset ckpt_offset(P): one block per cut tile of S RECORDS of (1 + CH) 256
+// floats, record r = 1 .. S:  {T_r = transmittance in front of boundary r (r < S), D_(r-1) = colour the entries of
+// segment r - 1 contributed} per pixel - what the forward wave knows when it reaches boundary r, written with one
+// 16-byte store per lane and block ([block k][lane] float4 {T, D_0, D_1, D_2}; a fourth channel in a plane of 256 floats
+// behind them).  The backward item of segment s starts from T_(s+1) and the colour BEHIND it, D_(s+1) + ... + D_(S-1)
+// = records s + 2 .. S added from the back (independent loads: one round trip; a running suffix sum kept by the
+// forward wave was a chain of dependent load -> add -> store per boundary at the end of every cut tile).
+#define TS_CAM_WHOLE16(cam) (((cam).hints >> 12) & 15)
+struct CutTiles {
+    int band, whole;                                   // tiles per band | of which composited whole (multiples of 4)
+    __host__ __device__ int cut() const { return band - whole; }
+    // -> index of the tile's checkpoint block, or -1 for a whole tile
+    __host__ __device__ int block_of(int tile) const {
+        const int b = tile / band, j = tile - b * band;
+        return j < whole ? -1 : b * (band - whole) + (j - whole);
+    }
+    // work items of a band's backward launch
+    __host__ __device__ int items(int S) const { return whole + (band - whole) * S; }
+};
+__host__ __device__ __forceinline__ CutTiles cut_tiles(int num_tiles, int hints) {
+    CutTiles m;
+    const int whole16 = (hints >> 12) & 15;
+    m.band = 4 * ((num_tiles + 31) / 32);
+    m.whole = whole16 > 0 ? ((m.band * whole16) / 16) & ~3 : 0;
+    return m;
+}
+__host__ __device__ __forceinline__ size_t ckpt_offset(size_t plane) { return (plane + 63) & ~(size_t)63; }
+// float offset of record r (1 .. S) of checkpoint block b
+template <int CH>
+__host__ __device__ __forceinline__ size_t ckpt_record(int block, int S, int r) {
+    return ((size_t)block * (size_t)S + (size_t)(r - 1)) * (size_t)((1 + CH) * 256);
+}
+// record at `rec`: this lane's {T, D} of block k
+template <int CH>
+__device__ __forceinline__ void ckpt_store(float* rec, int k, int lane, float T, const float (&D)[CH]) {
+    reinterpret_cast<float4*>(rec)[64 * k + lane] = make_float4(T, D[0], D[1], D[2]);
+    if (CH == 4) rec[1024 + 64 * k + lane] = D[CH - 1];
 }
 
 // Composites the `cnt` staged Gaussians of one chunk into the wave's tile (forward).
@@ -402,11 +463,57 @@ __device__ __forceinline__ size_t seg_plane_stride(const ts_camera& cam) {
 // and for finished pixels, and makes the weights telescope (sum of vis = 1 - T_final exactly).
 // GENERAL adds the sigma >= 0 test and the 0.999 clamp, which cannot trigger for a
 // positive-definite conic with opacity <= 0.99 (bit 4 of the staged mask).
-template <int CH, bool GENERAL, int NBX, bool LOC = false>
+// Per-segment colour sums of the forward pass (LIST SEGMENTS): what the entries of the CURRENT segment contributed to
+// each pixel, kept beside the running sum.  LocRegs<CH, N>: N sets in registers (0 = none; 1 = a wave of a split
+// launch owns ONE block).  LocLds<CH>: one set per block of a whole-tile wave in LDS, accumulated with ds_add_f32 -
+// twelve more live registers cost the forward kernel its fifth wave per SIMD (122 VGPRs, or 31 spilled), the LDS
+// form costs three multiplies and three LDS atomics per body of a cut tile and no register.
+template <int CH, int N>
+struct LocRegs {
+    static constexpr bool on = N > 0;
+    float v[N > 0 ? N : 1][CH];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < (N > 0 ? N : 1); ++k)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) v[k][c] = 0.0f;
+    }
+    __device__ __forceinline__ void add(int k, const float (&col)[CH], float vis) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[N == 1 ? 0 : k][c] = __builtin_fmaf(col[c], vis, v[N == 1 ? 0 : k][c]);
+    }
+    __device__ __forceinline__ void get(int k, float (&D)[CH]) const {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) D[c] = v[N == 1 ? 0 : k][c];
+    }
+};
+template <int CH, int NB>
+struct LocLds {
+    static constexpr bool on = true;
+    float4* p;                                       // this lane's sums of block 0; block k at p[64 k] (16 bytes per lane)
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[64 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void add(int k, const float (&col)[CH], float vis) {
+        float4 v = p[64 * k];
+        v.x = __builtin_fmaf(col[0], vis, v.x); v.y = __builtin_fmaf(col[1], vis, v.y); v.z = __builtin_fmaf(col[2], vis, v.z);
+        if (CH == 4) v.w = __builtin_fmaf(col[CH - 1], vis, v.w);
+        p[64 * k] = v;
+    }
+    __device__ __forceinline__ void get(int k, float (&D)[CH]) const {
+        const float4 v = p[64 * k];
+        D[0] = v.x; D[1] = v.y; D[2] = v.z;
+        if (CH == 4) D[CH - 1] = v.w;
+    }
+};
+
+template <int CH, bool GENERAL, int NBX, class Loc>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
-                                          float (&acc)[2 * NBX][CH], float (&loc)[CH] TS_SEG_PARAM) {
+                                          float (&acc)[2 * NBX][CH], Loc& loc TS_SEG_PARAM) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
+    constexpr bool LOC = Loc::on;
     TS_WORK(0, cnt);
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         TS_SEG_T0(tseg_a);
@@ -446,10 +553,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
-            if (LOC) {       // the same contribution summed per list segment (LIST SEGMENTS; the wave owns ONE block)
-#pragma unroll
-                for (int c = 0; c < CH; ++c) loc[c] = __builtin_fmaf(col[c], vis, loc[c]);
-            }
+            if (LOC) loc.add(k, col, vis);      // the same contribution summed per list segment (LIST SEGMENTS)
             // composited <=> alpha >= 1/255 and not stopped <=> vis = alpha T > 0 (alpha >= 1/255, T > 1e-4)
             fidx[k] = vis > 0.0f ? idx : fidx[k];
             T[k] = Tn;
@@ -473,7 +577,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 // sorted by ts_sort_tiles_above before this launch).  The per-tile sort on its own is latency-bound (VALU 40 %, LDS
 // 59 % busy on config 3); inside this VALU-bound kernel its stalls are filled by other tiles' compositing.
 template <int CH, bool SPLIT, int NBX, bool WL, bool SORT = false, bool SEGS = false>
-__global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_MIN_WAVES_RGB : TS_FWD_MIN_WAVES) void raster_fwd_kernel(
+__global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_MIN_WAVES_RGB : TS_FWD_MIN_WAVES_RGBD) : TS_FWD_MIN_WAVES) void raster_fwd_kernel(
     const ts_camera cam, const int num_tiles, const int* __restrict__ tile_bins,
     const int* __restrict__ ids_sorted, const int* __restrict__ bucket_ids, const float* __restrict__ depths,
     int* ids_rw, const float4* __restrict__ splats,
@@ -487,7 +591,13 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
     __shared__ float4 raw_all[TS_LDS_DMA ? kWaves : 1][3 * 64];      // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? NB * num_tiles : num_tiles;
-    const int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
+    int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
+    if (SEGS && !SPLIT && TS_FWD_CUT_FIRST && TS_CAM_WHOLE16(cam) > 0) {
+        // hybrid launch: the cut tiles of a band - the ones that also keep their boundary state, the longest items of
+        // this launch - are handed out FIRST here (the backward launch hands them out last, as small items)
+        const int per_xcd = ((units + kWaves - 1) / kWaves + 7) >> 3;
+        unit = ((int)(blockIdx.x & 7) * per_xcd + (per_xcd - 1 - (int)(blockIdx.x >> 3))) * kWaves + wave;
+    }
     if (unit >= units) return;
     const int tile = SPLIT ? unit / NB : unit;
     const int only = SPLIT ? unit % NB : -1;
@@ -565,53 +675,60 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
     }
     if (range.x + 64 + lane < range.y) id_next = ids[range.x + 64 + lane];
 
-    // list segments: this pass leaves the per-pixel state at the segment boundaries for the backward pass
-    // (only the SPLIT launches carry this: each of the four waves keeps the pixels of its block; the full-frame kernel
-    // has no registers to spare for it, and segments gain nothing there)
-    constexpr bool kSegsF = SEGS && SPLIT && NBX == 2 && !WL;
+    // list segments: this pass leaves the per-pixel state at the segment boundaries for the backward pass - in a SPLIT
+    // launch for every tile (each of the four waves keeps the pixels of its block), with one wave per tile for the CUT
+    // tiles of a hybrid launch (or, W16 = 0, for all of them)
+    constexpr bool kSegsF = SEGS && NBX == 2 && !WL;
     const int S_seg = max(1, min(TS_CAM_SEGS(cam), kSegMax));
-    const bool seg_on = kSegsF && final_Ts != nullptr && S_seg > 1 && range.y - range.x >= kSegMinList;
-    const size_t plane = seg_plane_stride(cam);
+    int ck_block = -1;                                               // the tile's checkpoint block, -1 = none
+    if (kSegsF && final_Ts != nullptr && S_seg > 1 && range.y - range.x >= kSegMinList)
+        ck_block = cut_tiles(num_tiles, cam.hints).block_of(tile);
+    const bool seg_on = ck_block >= 0;
+    float* ckp = nullptr;                                            // record 1 of the tile's checkpoint block (see CHECKPOINTS)
+    if (kSegsF && seg_on) ckp = final_Ts + ckpt_offset(seg_plane_stride(cam)) + ckpt_record<CH>(ck_block, S_seg, 1);
     int next_ck = seg_on ? range.x + seg_bound(range.y - range.x, S_seg, 1) : 0x7fffffff;      // list index of the next boundary
     int ck = 1;                                                      // its number (1 .. S-1)
     // colour the entries of the CURRENT segment contributed (the running sum `acc` rounds at the magnitude of the whole
     // pixel colour: differences of it would know what lies behind a boundary only to that rounding)
-    // (one set: a wave of a split launch owns one block)
-    float loc[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
-    // boundary `number` is reached: T in front of it, and the finished segment's colour into the slot of the boundary
-    // it began at (the epilogue turns these into sums over everything behind a boundary)
+    constexpr bool kLocLds = kSegsF && !SPLIT && TS_LOC_LDS;
+    using LocT = std::conditional_t<kLocLds, LocLds<CH, NB>, LocRegs<CH, !kSegsF ? 0 : (SPLIT ? 1 : NB)>>;
+    LocT loc;
+    if constexpr (kLocLds) {
+        __shared__ float4 loc_all[kWaves][kLocLds ? NB * 64 : 1];
+        loc.p = loc_all[wave] + lane;
+        if (seg_on) loc.zero();
+    } else {
+        loc.zero();
+    }
+    LocRegs<CH, 0> no_loc;
+    // boundary `number` (1 .. S-1) is reached: record `number` = T in front of it and the colour of the segment that ends
     auto store_ck = [&](int number) {
-        // (the pixel addresses are derived from an opaque zero: hoisted out of the list loop they would cost registers
-        // for a handful of uses per tile)
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const int py_ = py0 + opaque;
-        float* base_p = final_Ts + plane * (size_t)(1 + (number - 1) * (1 + CH));
+        float* rec = ckp + (number - 1) * ((1 + CH) * 256);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            if (!inside[k]) continue;
-            const size_t pix = (size_t)(py_ + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
-            base_p[pix] = __builtin_fabsf(T[k]);
-            if (number > 1) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c) (base_p - plane * (size_t)(1 + CH))[plane * (size_t)(1 + c) + pix] = loc[c];
-            }
+            if (SPLIT && k != only) continue;
+            float D[CH];
+            loc.get(k, D);
+            ckpt_store<CH>(rec, k, lane, __builtin_fabsf(T[k]), D);
         }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
+        loc.zero();
     };
 
+    // the walk over the list, with (LOCP) or without the per-segment colour sums - two instantiations, so that the
+    // whole tiles of a hybrid launch run the loop they always ran
+    auto walk = [&](auto& loc_) {
+    constexpr bool LOCP = std::remove_reference_t<decltype(loc_)>::on;
     for (int base = range.x; base < range.y && live != 0; base += 64) {
         TS_SEG_T0(tseg_p);
-        if constexpr (kSegsF) {
-            if (base == next_ck) {                   // wave-uniform: a segment boundary (never the list's first entry)
+#if TS_X_STORE_TOP
+        if constexpr (LOCP) {
+            if (base == next_ck) {
                 store_ck(ck);
                 ++ck;
                 next_ck = ck < S_seg ? range.x + seg_bound(range.y - range.x, S_seg, ck) : 0x7fffffff;
             }
         }
+#endif
         const int i = base + lane;
         const bool have = i < range.y;
 #if TS_LDS_DMA
@@ -621,13 +738,36 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
         TS_LDS_WAIT();                               // read out before the next chunk's records may overwrite them
         if (i + 64 < range.y) dma_record(splats, id_next, raw);
 #else
+        // (LOCP: the per-segment sums need twelve registers more; there the next chunk's records are requested AFTER
+        // this chunk's have been staged, so that the two sets are never live together - the chunk's bodies still
+        // cover the round trip)
+        constexpr bool kLate = LOCP && TS_FWD_LATE_PREFETCH;
         const float4 q0 = n0, q1 = n1, q2 = n2;
-        if (i + 64 < range.y) {
-            const int g = id_next;
-            n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
-        }
+        auto prefetch = [&]() {
+            if (i + 64 < range.y) {
+                const int g = id_next;
+                n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+            }
+            if (i + 128 < range.y) id_next = ids[i + 128];
+        };
+        if constexpr (!kLate) prefetch();
 #endif
+#if TS_LDS_DMA
         if (i + 128 < range.y) id_next = ids[i + 128];
+#endif
+#if TS_X_STORE_TOP
+        if constexpr (false) {
+#else
+        if constexpr (LOCP) {
+#endif
+            // a segment boundary (wave-uniform; never the list's first entry).  The record's stores are issued BEHIND the
+            // loads of the next chunk's records: the wait for those loads then leaves the stores in flight
+            if (base == next_ck) {
+                store_ck(ck);
+                ++ck;
+                next_ck = ck < S_seg ? range.x + seg_bound(range.y - range.x, S_seg, ck) : 0x7fffffff;
+            }
+        }
         {   // rectangle of the still-unfinished pixels of each block: saturated pixels need no more
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
             bool sel[NB];
@@ -650,64 +790,32 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && CH == 3 && !SPLIT) ? TS_FWD_
         }
         TS_WAVE_SYNC();
         TS_STAT(0, cnt);
+        const bool general = __ballot(keep && (s.mask & (1 << NB))) != 0ull;
+#if !TS_LDS_DMA
+        if constexpr (kLate) prefetch();
+#endif
         // bit NB of a staged mask = that Gaussian needs the general per-pixel code; the choice is made
         // once per chunk so that the common case runs a loop without those tests
         TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
-        if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
-            fwd_chunk<CH, true, NBX, kSegsF>(lds, cnt, fpx, fpy, T, fidx, acc, loc TS_SEG_ARG);
+        if (general)
+            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_ TS_SEG_ARG);
         else
-            fwd_chunk<CH, false, NBX, kSegsF>(lds, cnt, fpx, fpy, T, fidx, acc, loc TS_SEG_ARG);
+            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_ TS_SEG_ARG);
         TS_WAVE_SYNC();
     }
+    };
+    if constexpr (!kSegsF) walk(no_loc);
+    else if constexpr (SPLIT) walk(loc);
+    else if (seg_on) walk(loc);
+    else walk(no_loc);
 
     if constexpr (kSegsF) if (seg_on) {
-        const int cur = ck - 1;                    // the segment this wave's pass ended in
-        // boundaries behind it: the wave's pixels are finished there (no segment replays them: fidx lies in front);
-        // T only has to be a finite number, nothing lies behind
-        for (; ck < S_seg && next_ck < range.y; ++ck, next_ck = range.x + seg_bound(range.y - range.x, S_seg, min(ck, S_seg - 1))) {
-            float* base_p = final_Ts + plane * (size_t)(1 + (ck - 1) * (1 + CH));
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (!inside[k]) continue;
-                const size_t pix = (size_t)(py0 + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
-                base_p[pix] = __builtin_fabsf(T[k]);
-#pragma unroll
-                for (int c = 0; c < CH; ++c) base_p[plane * (size_t)(1 + c) + pix] = 0.0f;
-            }
-        }
-        // B_s = colour of everything at and behind boundary s = D_s + B_(s+1), summed from the back; D_cur is in `loc`,
-        // the earlier D_s were stored when their segments ended
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            if (!inside[k] || cur < 1) continue;
-            const size_t pix = (size_t)(py0 + 8 * (k / NBX) - cam.tile_row0 * 16) * W + (px0 + 8 * (k % NBX));
-            float d[kSegMax - 2][CH];
-#pragma unroll
-            for (int sgm = 1; sgm <= kSegMax - 2; ++sgm) {
-                if (sgm >= cur) continue;
-                const float* bp = final_Ts + plane * (size_t)(1 + (sgm - 1) * (1 + CH));
-#pragma unroll
-                for (int c = 0; c < CH; ++c) d[sgm - 1][c] = bp[plane * (size_t)(1 + c) + pix];
-            }
-            float suf[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) suf[c] = loc[c];
-            {
-                float* bp = final_Ts + plane * (size_t)(1 + (cur - 1) * (1 + CH));
-#pragma unroll
-                for (int c = 0; c < CH; ++c) bp[plane * (size_t)(1 + c) + pix] = suf[c];
-            }
-#pragma unroll
-            for (int sgm = kSegMax - 2; sgm >= 1; --sgm) {
-                if (sgm >= cur) continue;
-                float* bp = final_Ts + plane * (size_t)(1 + (sgm - 1) * (1 + CH));
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    suf[c] = d[sgm - 1][c] + suf[c];
-                    bp[plane * (size_t)(1 + c) + pix] = suf[c];
-                }
-            }
-        }
+        // the pass ended in segment ck - 1: its colour goes into record ck; the records behind hold no colour (the
+        // wave's pixels are finished there - no segment replays them, fidx lies in front - or the list is shorter),
+        // and their T only has to be a finite number
+        store_ck(ck);
+#pragma unroll 1
+        for (int r = ck + 1; r <= S_seg; ++r) store_ck(r);          // (the sums are zero by now)
     }
 
     float bg[CH];
@@ -1052,18 +1160,37 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
     __shared__ float4 rect_all[kBwdWaves][NB];
     __shared__ float4 raw_all[TS_LDS_DMA ? kBwdWaves : 1][3 * 64];   // landing zone of the next chunk's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // list segments (see kSegQuantum): S work items per tile, item `seg` replays the entries [sb, se) of the list
+    // list segments: S work items per cut tile, item `seg` replays the entries [sb, se) of the list; whole tiles (hybrid
+    // launch: the first `whole` of every band) are one item.  Work items are handed out band by band: workgroup b
+    // runs on XCD b % 8 and takes item b / 8 of band b % 8 - whole tiles first, the small items last
     constexpr bool kSegs = !SPLIT && NBX == 2 && !WL;
-    const int S_seg = kSegs ? max(1, min(TS_CAM_SEGS(cam), kSegMax)) : 1;
-    const int units = SPLIT ? NB * num_tiles : num_tiles * S_seg;
-    const int unit = xcd_tile_group((units + kBwdWaves - 1) / kBwdWaves) * kBwdWaves + wave;
-    if (unit >= units) return;
-    const int tile = SPLIT ? unit / NB : unit / S_seg;
-    // the segment order rotates from tile to tile: the front segments are the expensive ones (every pixel is still
-    // alive there), and one-wave workgroups land on a CU's SIMDs in dispatch order - with seg = unit % S and S = 4 one
-    // SIMD of every CU would get all the front segments (raster_bwd 525 -> 856 us, measured)
-    const int seg = SPLIT ? 0 : (int)(((unsigned)(unit % S_seg) + (((unsigned)tile * 2654435761u) >> 20)) % (unsigned)S_seg);
-    const int only = SPLIT ? unit % NB : -1;      // SPLIT: this wave owns block `only`, row slot*NB + only
+    const int S_cam = kSegs ? max(1, min(TS_CAM_SEGS(cam), kSegMax)) : 1;
+    int S_seg = S_cam, tile, seg = 0, only = -1, ck_block = -1;
+    if (kSegs && S_cam > 1) {
+        const CutTiles m = cut_tiles(num_tiles, cam.hints);
+        const int j = (int)(blockIdx.x >> 3) * kBwdWaves + wave;
+        if (j >= m.items(S_cam)) return;
+        int local = j;
+        S_seg = 1;
+        if (j >= m.whole) {
+            S_seg = S_cam;
+            local = m.whole + (j - m.whole) / S_cam;
+            seg = (j - m.whole) % S_cam;
+        }
+        tile = (int)(blockIdx.x & 7) * m.band + local;
+        if (tile >= num_tiles) return;
+        // the segment order rotates from tile to tile: the front segments are the expensive ones (every pixel is still
+        // alive there), and one-wave workgroups land on a CU's SIMDs in dispatch order - with seg = unit % S and S = 4 one
+        // SIMD of every CU would get all the front segments (raster_bwd 525 -> 856 us, measured)
+        if (S_seg > 1) seg = (int)(((unsigned)seg + (((unsigned)tile * 2654435761u) >> 20)) % (unsigned)S_seg);
+        ck_block = m.block_of(tile);
+    } else {
+        const int units = SPLIT ? NB * num_tiles : num_tiles;
+        const int unit = xcd_tile_group((units + kBwdWaves - 1) / kBwdWaves) * kBwdWaves + wave;
+        if (unit >= units) return;
+        tile = SPLIT ? unit / NB : unit;
+        only = SPLIT ? unit % NB : -1;            // SPLIT: this wave owns block `only`, row slot*NB + only
+    }
     float4* rects = rect_all[wave];
     const int tbx = NBX == 2 ? cam.tile_bounds_x : (cam.tile_bounds_x + 1) >> 1;
     const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
@@ -1086,7 +1213,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
             front = se < range.y;
         }
     }
-    TS_WAVE_CLOCK(1, unit, se - sb);
+    TS_WAVE_CLOCK(1, (int)blockIdx.x * kBwdWaves + wave, se - sb);
     float4* lds = lds_all[wave];
     const int px0 = tx * (8 * NBX) + (lane & 7), py0 = ty * 16 + (lane >> 3);
     // sample positions of the lane's pixel in the block columns / the upper and lower block row
@@ -1125,12 +1252,27 @@ __global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_k
 #pragma unroll
             for (int c = 0; c < CH; ++c) cb[c] = 0.0f;
             float T_start = T[k];
-            if (kSegs && front) {
-                const size_t plane = seg_plane_stride(cam);
-                const float* ckp = final_Ts + plane * (size_t)(1 + seg * (1 + CH));            // boundary seg + 1
-                T_start = ckp[pix];
+            if (kSegs && front) {                 // records seg + 1 (T) and seg + 2 .. S (colour behind) of the tile's block
+                const float* ckp = final_Ts + ckpt_offset(seg_plane_stride(cam)) + ckpt_record<CH>(ck_block, S_cam, 1);
+                T_start = ckp[(size_t)seg * ((1 + CH) * 256) + 4 * (64 * k + lane)];
+                // all the records are requested before the first addition (one round trip, not one per record); the
+                // bounds are wave-uniform, a record that is not wanted stays zero, and the sum runs from the back
+                float4 d[kSegMax - 1];
+                float d3[kSegMax - 1];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) cb[c] = ckp[plane * (size_t)(1 + c) + pix];
+                for (int r = 2; r <= kSegMax; ++r) {
+                    d[r - 2] = zero4;
+                    d3[r - 2] = 0.0f;
+                    if (r > S_seg || r < seg + 2) continue;
+                    const float* rec = ckp + (size_t)(r - 1) * ((1 + CH) * 256);
+                    d[r - 2] = reinterpret_cast<const float4*>(rec)[64 * k + lane];
+                    if (CH == 4) d3[r - 2] = rec[1024 + 64 * k + lane];
+                }
+#pragma unroll
+                for (int r = kSegMax; r >= 2; --r) {
+                    cb[0] += d[r - 2].y; cb[1] += d[r - 2].z; cb[2] += d[r - 2].w;
+                    if (CH == 4) cb[CH - 1] += d3[r - 2];
+                }
             }
             const int pass = clamp_mask ? clamp_mask[pix] : 7;   // backward of the fused clamp(max=1)
 #pragma unroll
@@ -1376,9 +1518,21 @@ int ts_debug_stats(unsigned long long* out_host, int reset) {      // developer 
 }
 #endif
 
-int32_t ts_final_planes(int32_t list_segments, int32_t channels) {
-    if (list_segments <= 1) return 1;
-    return 1 + (min(list_segments, kSegMax) - 1) * (1 + channels);
+int64_t ts_final_floats(const ts_camera* cam, int32_t channels) {
+    if (!cam || (channels != 3 && channels != 4)) return TS_E_BADARG;
+    const size_t plane = seg_plane_stride(*cam);
+    const int S = min(TS_CAM_SEGS(*cam), kSegMax);
+    if (S <= 1 || cam->wide_tiles) return (int64_t)plane;
+    const CutTiles m = cut_tiles(ts_num_tiles(cam), cam->hints);
+    return (int64_t)(ckpt_offset(plane) + (size_t)8 * (size_t)m.cut() * (size_t)(S * (1 + channels) * 256));
+}
+
+int32_t ts_cut_tiles(const ts_camera* cam, int32_t* band, int32_t* whole) {
+    if (!cam) return TS_E_BADARG;
+    const CutTiles m = cut_tiles(ts_num_tiles(cam), cam->hints);
+    if (band) *band = m.band;
+    if (whole) *whole = m.whole;
+    return 8 * m.cut();
 }
 
 int ts_raster_fwd(int32_t channels, int32_t flags, const ts_camera* cam, const int32_t* tile_bins,
@@ -1405,8 +1559,8 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-    // list segments (ts_camera.hints bits 8..11): the split launch on 16x16 lists also keeps the boundary planes
-    const bool segs = split && !wide && !narrow && final_Ts && TS_CAM_SEGS(*cam) > 1;
+    // list segments (ts_camera.hints bits 8..11): a launch on 16x16 lists also keeps the boundary state of the cut tiles
+    const bool segs = !wide && !narrow && final_Ts && TS_CAM_SEGS(*cam) > 1;
 #define TS_LAUNCH_FWD(C, S, X, L, G)                                                               \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L, false, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, gaussian_ids_sorted, (const int*)nullptr, (const float*)nullptr,   \
@@ -1416,7 +1570,7 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     do {                                                                                           \
         if (wide) TS_LAUNCH_FWD(C, S, 4, false, false);                                            \
         else if (narrow) TS_LAUNCH_FWD(C, S, 2, true, false);                                      \
-        else if (S && segs) TS_LAUNCH_FWD(C, S, 2, false, S);                                      \
+        else if (segs) TS_LAUNCH_FWD(C, S, 2, false, true);                                        \
         else TS_LAUNCH_FWD(C, S, 2, false, false);                                                 \
     } while (0)
     if (channels == 3) { if (split) TS_LAUNCH_FWD_X(3, true); else TS_LAUNCH_FWD_X(3, false); }
@@ -1444,7 +1598,7 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
-    const bool segs = split && final_Ts && TS_CAM_SEGS(*cam) > 1;       // list segments: see ts_raster_fwd_planes
+    const bool segs = final_Ts && TS_CAM_SEGS(*cam) > 1;                // list segments: see ts_raster_fwd_planes
 #define TS_LAUNCH_FWD_SORT(C, S, G)                                                                            \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background, \
@@ -1452,10 +1606,12 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
     if (channels == 3) {
         if (split && segs) TS_LAUNCH_FWD_SORT(3, true, true);
         else if (split) TS_LAUNCH_FWD_SORT(3, true, false);
+        else if (segs) TS_LAUNCH_FWD_SORT(3, false, true);
         else TS_LAUNCH_FWD_SORT(3, false, false);
     } else {
         if (split && segs) TS_LAUNCH_FWD_SORT(4, true, true);
         else if (split) TS_LAUNCH_FWD_SORT(4, true, false);
+        else if (segs) TS_LAUNCH_FWD_SORT(4, false, true);
         else TS_LAUNCH_FWD_SORT(4, false, false);
     }
 #undef TS_LAUNCH_FWD_SORT
@@ -1501,8 +1657,14 @@ int ts_raster_bwd_planes(int32_t channels, int32_t flags, int64_t num_intersects
                                                 ((unsigned long long)num_intersects & 0x00ffffffffffffffull));
     if (TS_CAM_SEGS(*cam) < 0 || TS_CAM_SEGS(*cam) > kSegMax) return TS_E_BADARG;
     const int segs = (!split && !wide && !narrow && TS_CAM_SEGS(*cam) > 1) ? TS_CAM_SEGS(*cam) : 1;
-    const int units = split ? (wide ? 8 : 4) * nt : nt * segs;
-    const int grid = 8 * (((units + kBwdWaves - 1) / kBwdWaves + 7) / 8);      // see xcd_tile_group
+    int grid;
+    if (segs > 1) {                       // band by band, whole tiles first (see raster_bwd_kernel)
+        const CutTiles m = cut_tiles(nt, cam->hints);
+        grid = 8 * ((m.items(segs) + kBwdWaves - 1) / kBwdWaves);
+    } else {
+        const int units = split ? (wide ? 8 : 4) * nt : nt;
+        grid = 8 * (((units + kBwdWaves - 1) / kBwdWaves + 7) / 8);            // see xcd_tile_group
+    }
     const float4* sp = reinterpret_cast<const float4*>(splats);
 #define TS_LAUNCH_BWD(C, S, X, L)                                                                  \
     hipLaunchKernelGGL((raster_bwd_kernel<C, S, X, L>), dim3(grid), dim3(64 * kBwdWaves), 0, s, *cam, nt, \

@@ -67,13 +67,25 @@ LIST_SEGMENTS = _ls if _ls == "auto" else max(1, min(8, int(_ls)))
 LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
 
 
-def _list_segments(tiles16: int, mode: int, split: bool) -> int:
-    """segments the (split) forward pass prepares for: 1 = none"""
-    if mode != 0 or not split or tiles16 <= 0:
-        return 1
+# HYBRID LAUNCHES (bits 12..15 of ts_camera.hints, csrc/raster.hip: HYBRID LAUNCH): a full frame - at least HYBRID_FROM
+# 16x16 tiles, one wave per tile - is two rounds of long waves whose last third runs half empty.  Cutting EVERY list
+# gains nothing there (above); cutting only the tiles that are dispatched LAST does: the first HYBRID_WHOLE16 / 16 of
+# every band of tiles stay whole, the rest become HYBRID_SEGS one-wave items each in the backward pass, and the forward
+# pass keeps the boundary state for those tiles only.  TS_HYBRID_SEGS=1 switches it off.
+HYBRID_FROM = int(os.environ.get("TS_HYBRID_FROM", "4096"))
+HYBRID_SEGS = max(1, min(8, int(os.environ.get("TS_HYBRID_SEGS", "8"))))
+HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
+
+
+def _list_segments(tiles16: int, mode: int, split: bool):
+    """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch"""
+    if mode != 0 or tiles16 <= 0:
+        return 1, 0
+    if not split:
+        return (HYBRID_SEGS, HYBRID_WHOLE16) if (HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM) else (1, 0)
     if LIST_SEGMENTS != "auto":
-        return int(LIST_SEGMENTS)
-    return max(2, min(8, 8192 // tiles16))
+        return int(LIST_SEGMENTS), 0
+    return max(2, min(8, 8192 // tiles16)), 0
 
 
 last_segments = {}      # device index -> list segments of the most recent backward pass (1 = none; tests, tools)
@@ -84,7 +96,7 @@ def backward_segments(cam, segs: int, total: int, dev_index: int = 0) -> int:
     if segs > 1 and total >= LIST_SEGMENTS_FROM * cam.tile_rows * cam.tile_bounds_x:
         last_segments[dev_index] = segs
         return segs
-    cam.hints &= ~0xF00
+    cam.hints &= ~0xFF00
     last_segments[dev_index] = 1
     return 1
 
@@ -267,10 +279,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
-    segs = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else 1
-    cam.hints = (cam.hints & ~0xF00) | ((segs if segs > 1 else 0) << 8)
+    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
+    cam.hints = (cam.hints & ~0xFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
     F.segs = segs
-    fin_planes = 1 + (segs - 1) * (1 + ch)                                   # ts_final_planes
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()
     if cur != dev.index:
@@ -285,9 +296,10 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         nscan = int(lib.ts_scan_ws_ints(n))
         nbin = int(lib.ts_bin_ws_ints(n, num_tiles))
         px = rows * w
+        fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch)) if keep else px      # T_fin + the cut tiles' checkpoints
         # (the colour stage keeps the colours in registers - ts_colors_pack_fwd - so no colors[n,3] section exists)
         sizes = [48 * m, 8 * m, 12 * m, 0, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
-                 8 * max(num_tiles, 1)] + ([m, 4 * px * fin_planes, 4 * px, px] if keep else [])
+                 8 * max(num_tiles, 1)] + ([m, 4 * fin_floats, 4 * px, px] if keep else [])
         offs, off = [], 0
         for sz in sizes:
             offs.append(off)

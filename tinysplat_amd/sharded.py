@@ -414,9 +414,9 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     cam.wide_tiles = 1 if S.mode else 0
     S.cam = cam
     S.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
-    S.segs = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split) if keep else 1
-    cam.hints = (cam.hints & ~0xF00) | ((S.segs if S.segs > 1 else 0) << 8)
-    fin_planes = int(lib.ts_final_planes(S.segs, ch))
+    S.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split) if keep else (1, 0)
+    cam.hints = (cam.hints & ~0xFF00) | (((S.segs << 8) | (w16 << 12)) if S.segs > 1 else 0)
+    fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch))
     num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
     S.num_tiles = num_tiles
     rows = _stripe_rows(cam)
@@ -426,7 +426,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     nscan, nbin = int(lib.ts_scan_ws_ints(m)), int(lib.ts_bin_ws_ints(m, num_tiles))
     #   xys | depths | radii | nth | cum | splats | scan_ws | bin_ws | tile_bins | final_Ts | final_index | clamp_mask
     S.ws, ptr, offs = _carve(dev, [8 * mm, 4 * mm, 4 * mm, 4 * mm, 4 * mm, 48 * mm, 4 * nscan, 4 * nbin,
-                                   8 * max(num_tiles, 1)] + ([4 * px * fin_planes, 4 * px, px] if keep else []))
+                                   8 * max(num_tiles, 1)] + ([4 * fin_floats, 4 * px, px] if keep else []))
     S.offs = offs
     out_img = torch.empty((rows, w, ch), dtype=torch.float32, device=dev)
     if ch == 4:            # channel 3 is composited over background[0], as the reference's depth pass (:86)

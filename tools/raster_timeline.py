@@ -38,10 +38,11 @@ tiles = int(frame.last_binning[0].num_tiles)
 saved = {}
 for which, name in ((0, "raster_fwd"), (1, "raster_bwd")):
     ROW = 12
-    buf = (ctypes.c_ulonglong * (ROW * tiles))()
-    rc = lib.ts_debug_timeline(buf, which, tiles)
+    rows_ = tiles if which == 0 else 1 << 17           # backward: a hybrid launch has more work items than tiles
+    buf = (ctypes.c_ulonglong * (ROW * rows_))()
+    rc = lib.ts_debug_timeline(buf, which, rows_)
     assert rc == 0, rc
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(tiles, ROW)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(rows_, ROW)
     a = a[a[:, 1] > 0]
     seg = a[:, 4:8].astype(np.float64)
     tot = a[:, 8].astype(np.float64)

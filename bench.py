@@ -82,6 +82,22 @@ def stage_alg_bytes(stage: str, n: int, i: int, p: int, t: int, k: int, ch: int 
     }[stage]
 
 
+def entry_alg_bytes(entry: str, stage: str, n: int, i: int, p: int, t: int, k: int, ch: int = 3):
+    """The share of its D5 stage that ONE C-ABI entry moves, where a stage has several entries; None = the stage is
+    not split here (then only the stage as a whole is priced).  raster_bwd: the compositing kernel reads the pixel
+    state and the pairs' records and writes the per-pair gradient rows (D5's scatter); the reduction writes the
+    per-Gaussian results."""
+    extra = 4.0 * (ch - 3)
+    if stage == "raster_bwd":
+        if entry == "ts_raster_bwd":
+            return (24.0 + extra) * p + (76.0 + 2 * extra) * i
+        if entry in ("ts_reduce_partials", "ts_reduce_partials_rows"):
+            return (36.0 + extra) * n
+    if stage in ("raster_fwd", "project_fwd", "project_bwd", "sh_fwd", "sh_bwd"):       # one entry per stage
+        return stage_alg_bytes(stage, n, i, p, t, k, ch)
+    return None
+
+
 def frame_alg_bytes(n, i, p, t, k, depth):
     """D5's whole-frame figures.  RGB only: 736 N + 160 I + 44 P (+16 T).  With the depth output the
     reference composites twice (772 N + 276 I + 88 P); this build composites RGB + depth in ONE
@@ -407,8 +423,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduce even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--shard-mode", default="gaussians", choices=("gaussians", "replicated", "both"),
-                    help="N > 1 (and --emulate-ranks): 'gaussians' = every rank owns N/G Gaussians and one stripe, "
+    ap.add_argument("--shard-mode", default=None, choices=("gaussians", "replicated", "both"),
+                    help="default: 'both' with more than one rank (so that a scaling run measures the north star's "
+                         "stripes + all-reduce design beside the Gaussian-sharded one), 'gaussians' otherwise.  "
+                         "N > 1 (and --emulate-ranks): 'gaussians' = every rank owns N/G Gaussians and one stripe, "
                          "records / gradient rows travel by all_to_all (sharded.py); 'replicated' = the north star's "
                          "design: parameters on every rank, tile-row stripes, one dense all-reduce of the 2-D "
                          "gradients (sharding.py); 'both' = time the second beside the first (sub-record "
@@ -440,6 +458,8 @@ def main():
         args.n, args.width, args.height, args.depth = 5_000_000, 3840, 2160, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.shard_mode is None:
+        args.shard_mode = "both" if (world > 1 or args.gpus > 1) else "gaussians"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -709,7 +729,6 @@ def main():
         n_local = int(binning.n)              # Gaussians (or imported records) this rank's stages run over
         a_bytes = stage_alg_bytes(dom_stage, n_local, isects_listed, p_local, tiles, k, ch)
         a_bytes_bbox = stage_alg_bytes(dom_stage, n_local, isects, p_local, tiles, k, ch)
-        achieved = a_bytes / (dom_ms * 1e-3) / 1e9
         full_tiles = (w + 15) // 16 * ((h + 15) // 16)
         frame_bytes = frame_alg_bytes(n, isects_total, p, full_tiles, k, args.depth)
         frame_bytes_listed = frame_alg_bytes(n, listed_total, p, full_tiles, k, args.depth)
@@ -767,27 +786,44 @@ def main():
         _log(f"timed: {ms:.3f} ms/step")
         bw_meas = None if args.no_bandwidth else measure_read_bandwidth(dev)
 
-        # ---- roofline of the DOMINANT KERNEL, SURVEY 8(d): algorithmic bytes of its D5 stage with I = sum of
-        # num_tiles_hit (the pairs gsplat's lists hold), over the kernel's own launch duration (HIP events on the
-        # stream it runs on), against the 8 TB/s HBM peak.  The stage's second entry, the figure priced on the
-        # pairs the launch really lists, and the vector-ALU view are sub-records.
+        # ---- roofline of the DOMINANT KERNEL, SURVEY 8(d).  Numerator and denominator cover the SAME scope (ADVICE
+        # r4): the bytes that kernel itself moves - its share of the D5 stage - priced on the pairs the launch really
+        # lists, over that kernel's own launch duration (HIP events on the stream it runs on), against the 8 TB/s HBM
+        # peak.  Sub-records: the whole D5 stage (all its entries: stage bytes over stage time) and the same two
+        # figures priced on gsplat's bounding-box pair count I = sum of num_tiles_hit - pairs this build never
+        # scatters, sorts or composites included -, labelled as such.
         dom_kernel_ms = per_step[dom_entry]
-        achieved_kernel = a_bytes_bbox / (dom_kernel_ms * 1e-3) / 1e9
-        achieved_stage = a_bytes_bbox / (dom_ms * 1e-3) / 1e9
+        k_bytes = entry_alg_bytes(dom_entry, dom_stage, n_local, isects_listed, p_local, tiles, k, ch)
+        k_bytes_bbox = entry_alg_bytes(dom_entry, dom_stage, n_local, isects, p_local, tiles, k, ch)
+        kernel_scope = k_bytes is not None
+        if not kernel_scope:                  # a stage whose entries are not priced one by one: the stage is the scope
+            k_bytes, k_bytes_bbox, scope_ms = a_bytes, a_bytes_bbox, dom_ms
+        else:
+            scope_ms = dom_kernel_ms
+        achieved_kernel = k_bytes / (scope_ms * 1e-3) / 1e9
+        achieved_stage = a_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "kernel": dom_entry, "stage": dom_stage, "kernel_ms": dom_kernel_ms,
-            "alg_bytes": a_bytes_bbox, "pairs": isects,
+            "scope": "the kernel's own bytes over the kernel's own time" if kernel_scope else
+                     "the D5 stage's bytes over the time of all its entries",
+            "alg_bytes": k_bytes, "pairs": isects_listed,
             "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_kernel / HBM_PEAK_GBS,
-            "traffic": traffic_of([dom_entry]), "traffic_source": pmc_src,
+            "traffic": traffic_of([dom_entry] if kernel_scope else stage_entries[dom_stage]), "traffic_source": pmc_src,
             "peak_read_measured": bw_meas,
             "frac_of_measured": None if bw_meas is None else achieved_kernel / bw_meas,
-            "stage_entries": {"entries": sorted(stage_entries[dom_stage]), "ms": dom_ms,
+            "stage_entries": {"entries": sorted(stage_entries[dom_stage]), "ms": dom_ms, "alg_bytes": a_bytes,
                               "achieved": achieved_stage, "frac": achieved_stage / HBM_PEAK_GBS,
                               "traffic": traffic_of(stage_entries[dom_stage])},
-            "listed_pairs": {"pairs": isects_listed, "alg_bytes": a_bytes,
-                             "achieved": a_bytes / (dom_kernel_ms * 1e-3) / 1e9,
-                             "frac": a_bytes / (dom_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "tight tile lists: the pairs this build scatters, sorts and composites"},
+            "gsplat_pairs": {"pairs": isects,
+                             "note": "the same D5 formulas priced on gsplat's bounding-box pair count (sum of "
+                                     "num_tiles_hit); this build's tight lists hold `pairs` of the parent record",
+                             "kernel_alg_bytes": k_bytes_bbox,
+                             "kernel_frac": k_bytes_bbox / (scope_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "stage_alg_bytes": a_bytes_bbox,
+                             "stage_frac": a_bytes_bbox / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "stage_bytes_over_kernel_time_frac": a_bytes_bbox / (dom_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "stage_bytes_over_kernel_time_note": "round 4's top-level figure (numerator: two "
+                                                                  "entries, denominator: one) - kept for comparison only"},
             "fetch_correction": {"streaming": 2.0, "gather_kernels": gather_factor,
                                  "gather48_raw_fetch_bytes_per_record": gather_raw,
                                  "gather48_expected_bytes_per_record": 160.0,
@@ -795,12 +831,13 @@ def main():
         }
         frame_gbs = frame_bytes / (ms * 1e-3) / 1e9
         frame_gbs_listed = frame_bytes_listed / (ms * 1e-3) / 1e9
-        frame_roofline = {"alg_bytes": frame_bytes, "achieved": frame_gbs, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS,
-                          "alg_bytes_listed_pairs": frame_bytes_listed,
-                          "frac_listed_pairs": frame_gbs_listed / HBM_PEAK_GBS,
+        # whole frame: D5's frame bytes priced on the listed pairs over the driver-timed step; gsplat's pair count beside it
+        frame_roofline = {"alg_bytes": frame_bytes_listed, "pairs": listed_total, "achieved": frame_gbs_listed,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs_listed / HBM_PEAK_GBS,
+                          "gsplat_pairs": {"pairs": isects_total, "alg_bytes": frame_bytes, "achieved": frame_gbs,
+                                           "frac": frame_gbs / HBM_PEAK_GBS},
                           "peak_read_measured": bw_meas,
-                          "frac_of_measured": None if bw_meas is None else frame_gbs / bw_meas}
+                          "frac_of_measured": None if bw_meas is None else frame_gbs_listed / bw_meas}
         # the compositing kernels against the vector ALUs (D4's second figure)
         valu = {}
         for e in ("ts_raster_fwd", "ts_raster_bwd"):

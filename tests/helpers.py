@@ -91,7 +91,7 @@ ENTRYWISE_NUMEL = 1000   # ... asserted on tensors with at least this many entri
 
 
 def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0, mask=None,
-               entrywise_min: float = ENTRYWISE_MIN):
+               entrywise_min: float = ENTRYWISE_MIN, entrywise_scale: float = 1.0):
     """What is enforced, per tensor:
       * |ref|_inf <= 1: the north_star's literal bar, |got - ref| <= 1e-5 ABSOLUTE for every entry
         (whatever ``rel`` says);
@@ -116,7 +116,9 @@ def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0
     worst = err.max().item() if err.numel() else 0.0
     frac = (err > tol).double().mean().item() if err.numel() else 0.0
     within = (err <= ABS_BAR).double().mean().item() if err.numel() else 1.0
-    entrywise = (err <= ABS_BAR * ref.abs().clamp_min(1.0)).double().mean().item() if err.numel() else 1.0
+    # (entrywise_scale > 1: randomised scenes whose measured float32 conditioning allows more than the plain bar - the
+    # entry-wise bar grows with the tolerance instead of being dropped, tools/fuzz_frame.py)
+    entrywise = (err <= entrywise_scale * ABS_BAR * ref.abs().clamp_min(1.0)).double().mean().item() if err.numel() else 1.0
     import os
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     PARITY_LOG.append((test, what, worst, mag, tol, frac, within, entrywise))
@@ -126,6 +128,6 @@ def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0
                                   f"(max err {worst:.3e}, |ref|_inf {mag:.3e}); allowed {max_bad_frac:.1e}")
     # (asserted on tensors of >= ENTRYWISE_NUMEL entries: in a 14-Gaussian fuzz scene one entry is 2 % of a tensor)
     assert entrywise >= entrywise_min or err.numel() < ENTRYWISE_NUMEL, (
-        f"{what}: only {entrywise:.4f} of the entries are within 1e-5 * max(1, |ref entry|) "
+        f"{what}: only {entrywise:.4f} of the entries are within {entrywise_scale:g} x 1e-5 * max(1, |ref entry|) "
         f"(required {entrywise_min}; max err {worst:.3e}, |ref|_inf {mag:.3e})")
     return worst / tol if tol > 0 else 0.0

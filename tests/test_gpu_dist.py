@@ -93,8 +93,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--single-device", "--backend",
                         "gloo", "--config", "2", "--depth", "--steps", "3", "--warmup", "1", "--profile-steps", "1",
-                        "--shard-mode", "both",
-                        "--no-cpu-baseline", "--no-pmc", "--no-bandwidth"],
+                        "--no-cpu-baseline", "--no-pmc", "--no-bandwidth"],      # (no --shard-mode: N > 1 defaults to 'both')
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

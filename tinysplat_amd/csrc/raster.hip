@@ -720,15 +720,6 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
     constexpr bool LOCP = std::remove_reference_t<decltype(loc_)>::on;
     for (int base = range.x; base < range.y && live != 0; base += 64) {
         TS_SEG_T0(tseg_p);
-#if TS_X_STORE_TOP
-        if constexpr (LOCP) {
-            if (base == next_ck) {
-                store_ck(ck);
-                ++ck;
-                next_ck = ck < S_seg ? range.x + seg_bound(range.y - range.x, S_seg, ck) : 0x7fffffff;
-            }
-        }
-#endif
         const int i = base + lane;
         const bool have = i < range.y;
 #if TS_LDS_DMA
@@ -755,11 +746,7 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
 #if TS_LDS_DMA
         if (i + 128 < range.y) id_next = ids[i + 128];
 #endif
-#if TS_X_STORE_TOP
-        if constexpr (false) {
-#else
         if constexpr (LOCP) {
-#endif
             // a segment boundary (wave-uniform; never the list's first entry).  The record's stores are issued BEHIND the
             // loads of the next chunk's records: the wait for those loads then leaves the stores in flight
             if (base == next_ck) {

@@ -41,6 +41,7 @@ import torch
 from helpers import check_grad, oracle_frame, scene_args     # oracle = checker
 
 REL_CAP = 1e-3           # no gradient tolerance above 1e-3 |ref|_inf, whatever the scene's conditioning says
+ENTRYWISE_FLOOR = 0.95   # share of the entries inside the (scaled) entry-wise bar where the tolerance exceeds 2e-5
 
 
 class IllConditioned(Exception):
@@ -243,12 +244,18 @@ def run_case(case):
             ((f64["rgb"] * w_rgb.double()).sum() + (f64["depth"] * w_d.double()).sum()).backward()
             exact = r64
             floor = vjp_float32_floor(model, cam, (w, h), f64, r64)
-    # The tolerance is derived from the measured conditioning of the scene, but it is CAPPED: a case whose float32
-    # bound exceeds REL_CAP of the gradient's magnitude is not allowed to pass on a tolerance computed from the
-    # data under test - it is reported as beyond what float32 can be checked to (IllConditioned -> xfail in
-    # tests/test_gpu_fuzz.py, "xfail" in this tool's tally), with the measured figures in the message.
-    # The entry-wise 99 % rule of helpers.check_grad assumes float32-resolvable entries; on scenes with a
-    # conditioning-derived tolerance it is relaxed in proportion.
+    # The tolerance is derived from the measured conditioning of the scene - from the ORACLE's own figures (the per-pixel
+    # float32 bound, the +-1 ulp nudge of the log-scales, the float32 floor of the projection VJP evaluated on the host
+    # with exact inputs), never from the HIP results under test - but it is CAPPED at REL_CAP of the gradient's
+    # magnitude.  A tensor whose measured bound exceeds the cap is CHECKED AT THE CAP first:
+    #   * passes there                        -> the case is reported as "checked only to the cap" (IllConditioned ->
+    #                                            xfail in tests/test_gpu_fuzz.py, "xfail" in this tool's tally);
+    #   * fails there, within its measured bound -> "beyond what float32 can be checked to" (xfail, with both figures);
+    #   * fails beyond its measured bound      -> the case FAILS: a regression on a needle scene is a regression
+    #                                            (the old form swallowed every failure of a capped tensor).
+    # The entry-wise 99 % rule of helpers.check_grad is stated for the plain bar (1e-5 of the entry's own magnitude);
+    # where the conditioning-derived tolerance is larger, the entry-wise bar grows in the same proportion
+    # (allow / 2e-5) and the required share is ENTRYWISE_FLOOR - it is never switched off.
     needs = {}
     for nm in names:
         a, b = getattr(md, nm), getattr(ref, nm)
@@ -259,25 +266,30 @@ def run_case(case):
         want = getattr(exact, nm).grad if (exact is not None and nm in floor) else b.grad
         if exact is not None and nm in floor:
             allow = max(allow, 4.0 * floor[nm])
-        capped = allow > REL_CAP
-        if capped:
-            needs[nm] = [allow, None]
-            allow = REL_CAP
+
+        def check(at):
+            check_grad(nm, a.grad, want, rel=at, entrywise_min=0.99 if at <= 2e-5 else ENTRYWISE_FLOOR,
+                       entrywise_scale=max(1.0, at / 2e-5))
+        if allow <= REL_CAP:
+            check(allow)
+            continue
         try:
-            check_grad(nm, a.grad, want, rel=allow, entrywise_min=0.99 if allow <= 2e-5 else 0.0)
+            check(REL_CAP)
+            needs[nm] = [allow, None]
         except AssertionError as e:
-            if not capped:
-                raise
-            needs[nm][1] = str(e)[:160]          # beyond the cap on a tensor whose measured bound is beyond it too
+            check(allow)                                   # beyond the measured bound too: FAIL
+            needs[nm] = [allow, str(e)[:120]]
     if f["xys"].grad is not None:
-        check_grad("xys.grad", extras["xys"].grad, f["xys"].grad, rel=min(rel, REL_CAP),
-                   entrywise_min=0.99 if rel <= 2e-5 else 0.0)
+        rel_xy = min(rel, REL_CAP)
+        check_grad("xys.grad", extras["xys"].grad, f["xys"].grad, rel=rel_xy,
+                   entrywise_min=0.99 if rel_xy <= 2e-5 else ENTRYWISE_FLOOR, entrywise_scale=max(1.0, rel_xy / 2e-5))
     if needs:
         cond_max = float(aux["cond"][stable].max()) if stable.any() else 0.0
+        beyond = any(v[1] for v in needs.values())
         raise IllConditioned(
-            f"not checkable to the bar: the measured float32 bound of this scene exceeds the cap {REL_CAP:g} |ref|_inf "
-            f"(largest exponent term {mag:.0f}, cond_max {cond_max:.2e}); per tensor [bound, failure at the cap or None]: "
-            f"{ {k_: [round(v[0], 5), v[1]] for k_, v in needs.items()} }")
+            ("within the measured float32 bound of this scene but NOT within the cap" if beyond else "passes at the cap")
+            + f" {REL_CAP:g} |ref|_inf (largest exponent term {mag:.0f}, cond_max {cond_max:.2e}); per tensor "
+            f"[measured bound, failure at the cap or None]: { {k_: [round(v[0], 5), v[1]] for k_, v in needs.items()} }")
     return dict(visible=int(vis.sum()), stable=round(float(stable.float().mean()), 4), mag_max=round(mag, 1),
                 grad_rel_tol=rel, cond_max=float(aux["cond"][stable].max()) if stable.any() else 0.0)
 

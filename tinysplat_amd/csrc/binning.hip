@@ -934,6 +934,22 @@ __global__ __launch_bounds__(kThreads) void sort_tiles_large_kernel(
     }
 }
 
+// ts_sort_tiles_above in ONE launch (the companion of ts_raster_fwd_sort, which sorts the lists of up to kWaveSortMax
+// entries itself): one workgroup per tile, which leaves at once unless its list is longer - then the register
+// network with LDS stages (up to kSortCap keys) or the sample sort, on the same 48 KiB.  On frames that take this path
+// (16x16 lists: fewer than ~1 000 pairs per tile on average) long lists are the exception, so the sample sort's LDS
+// footprint costs nothing here, and the queue of oversized tiles with its second launch is gone.
+__global__ __launch_bounds__(kThreads) void sort_tiles_above_kernel(
+    const int* __restrict__ tile_bins, const float* __restrict__ depths,
+    const int* __restrict__ bucket_ids, int* __restrict__ ids_sorted) {
+    __shared__ unsigned long long lds_u64[kLargeLdsU64 > kSortCap / 2 ? kLargeLdsU64 : kSortCap / 2];
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[blockIdx.x];
+    const int n = range.y - range.x;
+    if (n <= kWaveSortMax) return;
+    if (n <= kSortCap) sort_bucket_block(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_u64);
+    else sort_tile_sample(bucket_ids + range.x, depths, ids_sorted + range.x, n, lds_u64);
+}
+
 __global__ __launch_bounds__(kThreads) void pack_splats_kernel(int n, const ts::PackArgs a,
                                                               const float* __restrict__ colors) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -1100,19 +1116,10 @@ int ts_sort_tiles_above(int32_t num_tiles, const int32_t* tile_bins, const float
                         int32_t* zeroed_counter, void* stream) {
     if (num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
-    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted || !sort_ws) return TS_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    int32_t* counter = zeroed_counter ? zeroed_counter : sort_ws;
-    int32_t* list = zeroed_counter ? sort_ws : sort_ws + 1;
-    if (!zeroed_counter) {
-        hipError_t e = hipMemsetAsync(sort_ws, 0, sizeof(int32_t), s);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(sort_tiles_mid_kernel, dim3(num_tiles), dim3(kThreads), 0, s, tile_bins, depths,
-                       bucket_ids, gaussian_ids_sorted, counter, list);
-    const int grid = num_tiles < 768 ? num_tiles : 768;
-    hipLaunchKernelGGL(sort_tiles_large_kernel, dim3(grid), dim3(kThreads), 0, s, tile_bins, depths,
-                       bucket_ids, gaussian_ids_sorted, counter, list);
+    if (!tile_bins || !depths || !bucket_ids || !gaussian_ids_sorted) return TS_E_BADARG;
+    (void)sort_ws; (void)zeroed_counter;        // (no queue of oversized tiles any more: every tile has its workgroup)
+    hipLaunchKernelGGL(sort_tiles_above_kernel, dim3(num_tiles), dim3(kThreads), 0, (hipStream_t)stream, tile_bins,
+                       depths, bucket_ids, gaussian_ids_sorted);
     return launch_status();
 }
 

@@ -178,7 +178,6 @@ def row_flags_for(dev: torch.device, rows: int):
 
 _bg_cache = {}          # (storage address, version, channels) -> contiguous background with the depth channel
 
-
 # One stripe of a multi-GPU frame (tile_rows narrower than the frame, training frame): the colour stage
 # runs only for the Gaussians the stripe lists and the clamp mask is applied before the all-reduce
 # (TS_FRAME_STRIPE, csrc/frame.hip).  Same gradients, bit for bit, as the dense order

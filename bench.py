@@ -439,6 +439,12 @@ def main():
                          "only stripe --emulate-rank of that many (with --force-dist the 1-rank all-reduce "
                          "runs too); the printed value is NOT a multi-GPU measurement")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--top-third", type=float, default=0.0,
+                    help="skewed scene: this share of the Gaussians lies in the top third of the image (make_scene)")
+    ap.add_argument("--balance-stripes", action="store_true",
+                    help="Gaussian-sharded frame: tile-row stripes balanced by the lists' work (pairs + a cost per "
+                         "tile) instead of equal row counts - from the whole frame's lists with --emulate-ranks, from "
+                         "the warm-up frames' own lists (all-reduced over the ranks) at N > 1")
     ap.add_argument("--config", type=int, default=None,
                     help="BASELINE.json config shortcut: 2 = 100k/1080p, 3 = 1M/1080p (default), "
                          "5 = 5M/4K with depth")
@@ -492,7 +498,7 @@ def main():
     from tinysplat_amd.synthetic import loss_weights, make_scene
 
     n, w, h, sh = args.n, args.width, args.height, args.sh_degree
-    model, cam = make_scene(n, sh, w, h, seed=0, scale_mult=args.scale_mult)
+    model, cam = make_scene(n, sh, w, h, seed=0, scale_mult=args.scale_mult, top_third=args.top_third)
     model = model.to(dev)
     if args.spatial_sort:
         model.spatial_sort_()
@@ -526,7 +532,19 @@ def main():
             g_rank, g_world = rank, world
         else:
             g_rank, g_world = args.emulate_rank, args.emulate_ranks
-        layout = ShardLayout(n, g_world, g_rank, (w, h))
+        stripes_ = None
+        if args.balance_stripes and world == 1:
+            # emulation: the whole model is here - one forward frame of it gives every tile row's work
+            from tinysplat_amd import frame as _fr
+            from tinysplat_amd.sharded import balanced_stripes, row_work
+            with torch.no_grad():
+                adapter(cam, (w, h), sh)
+            b_ = _fr.last_binning[dev.index]
+            if b_.cam.wide_tiles:
+                raise SystemExit("--balance-stripes: the probe frame used wide lists (set TS_WIDE_TILES=0)")
+            stripes_ = balanced_stripes(row_work(b_.tile_bins, b_.cam.tile_bounds_x), g_world)
+            _log(f"work-balanced stripes (tile rows): {stripes_}")
+        layout = ShardLayout(n, g_world, g_rank, (w, h), stripes_)
         shard = shard_model(model, g_world, g_rank).requires_grad_(True)
         if world > 1:
             exchange = DistExchange()
@@ -538,7 +556,7 @@ def main():
                 parts.append(rec[o:o + cnt[g_rank]].clone())
                 counts.append(cnt[g_rank])
             exchange = ReplayExchange(g_rank, counts, torch.cat(parts, dim=0))
-        gshard = (shard, layout, exchange)
+        gshard = [shard, layout, exchange]
     both_modes = args.shard_mode == "both" and gshard is not None and world > 1
     if gshard is not None and not both_modes:
         model_params = list(gshard[0].parameters())
@@ -638,6 +656,24 @@ def main():
         ms_, calls_ = collective_timer.stop()
         return ms_ / k_steps, calls_ // k_steps
 
+    balanced = None
+    if args.balance_stripes and gshard is not None and world > 1 and step_mode[0] == "gaussians":
+        # real ranks: a few frames with equal rows, every rank hands in the work of its own tile rows, all ranks
+        # derive the same balanced stripes and re-cut (outside the timed region)
+        from tinysplat_amd import frame as _fr
+        from tinysplat_amd.sharded import StripeBalancer, row_work
+        bal = StripeBalancer(gshard[1])
+        for _ in range(2):
+            step()
+            b_ = _fr.last_binning[dev.index]
+            if b_.cam.wide_tiles:
+                break
+            gshard[1] = bal.update(row_work(b_.tile_bins, b_.cam.tile_bounds_x))
+        balanced = list(gshard[1].stripes)
+        if rank == 0:
+            _log(f"work-balanced stripes (tile rows): {balanced}")
+    elif args.balance_stripes and gshard is not None:
+        balanced = list(gshard[1].stripes)
     if rank == 0:
         _log(f"timing {args.steps} steps ({step_mode[0] if world > 1 else 'single GPU'})")
     dt, dt_ranks = time_steps()
@@ -900,6 +936,8 @@ def main():
                                       + (" (auto)" if _frame.WIDE_TILES == "auto" else ""),
                        "gaussian_order": "Morton curve of the means (--spatial-sort)" if args.spatial_sort
                                          else "as generated (i.i.d.)",
+                       **({"stripes": balanced, "stripes_policy": "balanced by the lists' work"} if balanced else {}),
+                       **({"top_third": args.top_third} if args.top_third else {}),
                        **({"emulated_stripe": f"{args.emulate_rank} of {args.emulate_ranks} on ONE GPU "
                                               "(per-rank estimate, not a multi-GPU measurement), shard mode "
                                               + args.shard_mode}

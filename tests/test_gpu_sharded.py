@@ -115,6 +115,41 @@ def test_all_ranks_in_one_process_equal_the_single_frame(world, depth, n, sh, w,
     _check_simulated(n, sh, w, h, mult, depth, world, stripes)
 
 
+def test_work_balanced_stripes_on_a_skewed_scene():
+    """SURVEY 8(e) E2's option: stripes balanced by the previous frame's per-row work.  On a scene with 70 % of its
+    Gaussians in the top third of the image, equal rows leave one rank with ~2.5x the mean work; the balanced cut
+    brings max / mean of the stripes' work below 1.10, the stripes still tile the single-GPU image bit for bit and
+    the gradients keep their bar."""
+    from tinysplat_amd import frame
+    from tinysplat_amd.sharded import balanced_stripes, row_work
+    n, sh, w, h, world = 150000, 1, 960, 544, 8
+    model, cam = make_scene(n, sh, w, h, seed=9, scale_mult=2.0, top_third=0.7)
+    model.background = torch.tensor((0.2, 0.1, 0.3))
+    model = model.to(DEV).requires_grad_(True)
+    w_rgb, _ = (t.to(DEV) for t in loss_weights(w, h))
+    full, _, xys = render_stripe(model, cam, (w, h), DEV, 0, 1, with_depth=False)
+    b = frame.last_binning[0]
+    assert not b.cam.wide_tiles
+    work = row_work(b.tile_bins, b.cam.tile_bounds_x)
+    (full * w_rgb).sum().backward()
+    st = balanced_stripes(work, world)
+    eq = ShardLayout(n, world, 0, (w, h)).stripes
+
+    def spread(stripes):
+        c = [sum(work[a:b_]) for a, b_ in zip(stripes, stripes[1:])]
+        return max(c) / (sum(c) / world)
+    assert spread(st) < 1.10 and spread(eq) > 1.5, (spread(st), spread(eq))
+
+    def v_img_of(k, img, rows):
+        return w_rgb[rows[0]:rows[1]].contiguous()
+    with torch.no_grad():
+        images, rows_px, grads, v_xy, _ = simulate_frame(model, cam, (w, h), DEV, world, v_img_of, stripes=st)
+    assert torch.equal(torch.cat(images, dim=0), full.detach())
+    for nm, g, p in zip(NAMES, grads, model.parameters()):
+        check_grad(f"balanced stripes {nm}", g, p.grad, rel=1e-5)
+    check_grad("balanced stripes xys", v_xy, xys.grad, rel=1e-5)
+
+
 def test_list_segments_in_the_stripes_of_a_sharded_frame(monkeypatch):
     """TS_LIST_SEGMENTS=auto (frame.py, the default): the stripes of a sharded frame - split launches - replay
     their lists as segments in the backward pass.  Same image bit for bit, gradients to the same bar."""

@@ -34,6 +34,63 @@ def test_shard_ranges_and_layout():
     assert torch.equal(sh.means, model.means[4:7]) and sh.colors_rest.shape == (3, 3, 3)
 
 
+def test_work_balanced_stripes_are_the_optimal_contiguous_cut():
+    """sharded.balanced_stripes (stripes balanced by per-row work): contiguous, covering, and with the
+    smallest possible bottleneck - against brute force over all cuts on small inputs; empty input, more ranks than
+    rows, all the work in one row."""
+    import itertools
+    import random
+    from tinysplat_amd.sharded import balanced_stripes, row_work
+    rnd = random.Random(7)
+
+    def bottleneck(w, st):
+        return max(sum(w[a:b]) for a, b in zip(st, st[1:]))
+    for _ in range(300):
+        rows, world = rnd.randint(0, 9), rnd.randint(1, 4)
+        w = [rnd.randint(0, 9) for _ in range(rows)]
+        st = balanced_stripes(w, world)
+        assert len(st) == world + 1 and st[0] == 0 and st[-1] == rows and all(a <= b for a, b in zip(st, st[1:]))
+        best = min(bottleneck(w, [0] + list(c) + [rows])
+                   for c in itertools.combinations_with_replacement(range(rows + 1), world - 1))
+        assert bottleneck(w, st) == best, (w, world, st)
+    assert balanced_stripes([], 3) == [0, 0, 0, 0]
+    assert balanced_stripes([1, 1, 1], 8)[:4] == [0, 1, 2, 3]
+    skew = [100.0] * 20 + [10.0] * 48                       # 1080p: 68 tile rows, most of the work in the top third
+    st = balanced_stripes(skew, 8)
+    cost = [sum(skew[a:b]) for a, b in zip(st, st[1:])]
+    equal = [sum(skew[a:b]) for a, b in zip(ShardLayout(1, 8, 0, (1920, 1080)).stripes, ShardLayout(1, 8, 0, (1920, 1080)).stripes[1:])]
+    assert max(cost) / (sum(cost) / 8) < 1.10 < max(equal) / (sum(equal) / 8)
+    bins = torch.tensor([[0, 3], [3, 3], [3, 10], [10, 11]], dtype=torch.int32)          # 2 rows of 2 tiles
+    rw = row_work(bins, 2)
+    from tinysplat_amd import sharded
+    assert rw == [3 + 2 * sharded.TILE_COST_PAIRS, 8 + 2 * sharded.TILE_COST_PAIRS]
+
+
+def _balancer_rank(rank, world, port, out):
+    import torch.distributed as dist
+    from tinysplat_amd.sharded import StripeBalancer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lay = ShardLayout(1000, world, rank, (640, 360))            # 23 tile rows
+    bal = StripeBalancer(lay, every=1, hysteresis=0.03)
+    work = [50.0 if r < 6 else 5.0 for r in range(23)]          # what every rank would measure on its own rows
+    r0, r1 = lay.tile_rows
+    new = bal.update(work[r0:r1])
+    again = bal.update(work[new.tile_rows[0]:new.tile_rows[1]])   # already balanced: nothing moves
+    torch.save({"stripes": new.stripes, "again": again.stripes, "owned": new.owned}, f"{out}/bal{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_stripe_balancer_all_ranks_derive_the_same_stripes(tmp_path):
+    world = 3
+    mp.spawn(_balancer_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"bal{r}.pt") for r in range(world)]
+    from tinysplat_amd.sharded import balanced_stripes
+    want = balanced_stripes([50.0 if r < 6 else 5.0 for r in range(23)], world)
+    assert all(o["stripes"] == want and o["again"] == want for o in outs)
+    assert want != ShardLayout(1000, world, 0, (640, 360)).stripes
+    assert [o["owned"] for o in outs] == [ShardLayout(1000, world, r, (640, 360)).owned for r in range(world)]    # ownership stays
+
+
 def test_route_oracle_lists():
     from oracle import route_oracle as R
     xys = torch.tensor([[8.0, 8.0], [8.0, 40.0], [8.0, 24.0], [100.0, 8.0], [8.0, 8.0], [8.0, 60.0]])

@@ -125,6 +125,95 @@ class ShardLayout:
         return ShardLayout(self.n_total, self.world, rank, self.dims, self.stripes)
 
 
+# --------------------------------------------------------------------------------------------------
+# stripes balanced by WORK, not by rows ("optionally balanced by per-row intersection counts from
+# the previous frame")
+# --------------------------------------------------------------------------------------------------
+TILE_COST_PAIRS = float(os.environ.get("TS_TILE_COST_PAIRS", "48"))     # fixed cost of a tile, in listed pairs
+
+
+def row_work(tile_bins: Tensor, tile_bounds_x: int, row0: int = 0) -> List[float]:
+    """Work of every tile row of a launch from its lists: listed pairs + TILE_COST_PAIRS per tile (the per-tile
+    prologue / epilogue of the compositing kernels, pixel state, image stores).  ``tile_bins``: [tiles, 2] of 16x16
+    lists, row-major.  -> one float per tile row of the launch (the caller knows they start at ``row0``)."""
+    lens = (tile_bins[:, 1] - tile_bins[:, 0]).to(torch.float64)
+    rows = lens.numel() // int(tile_bounds_x)
+    per_row = lens[:rows * tile_bounds_x].view(rows, tile_bounds_x).sum(dim=1) + TILE_COST_PAIRS * tile_bounds_x
+    return per_row.cpu().tolist()
+
+
+def balanced_stripes(work: Sequence[float], world: int) -> List[int]:
+    """Cuts the tile rows 0 .. len(work) into ``world`` CONTIGUOUS stripes (some may be empty) such that the largest
+    stripe's work is minimal -> world + 1 ascending row indices (ShardLayout's ``stripes``).  Exact: dynamic
+    programme over (row, stripe), O(rows^2 world) on a few dozen rows."""
+    rows = len(work)
+    pre = [0.0]
+    for v in work:
+        pre.append(pre[-1] + float(v))
+    INF = float("inf")
+    best = [[INF] * (rows + 1) for _ in range(world + 1)]     # best[k][r]: rows 0..r in k stripes, minimal bottleneck
+    cut = [[0] * (rows + 1) for _ in range(world + 1)]
+    best[0][0] = 0.0
+    for k in range(1, world + 1):
+        for r in range(rows + 1):
+            for q in range(r + 1):                            # the last stripe = rows q .. r
+                if best[k - 1][q] == INF:
+                    continue
+                v = max(best[k - 1][q], pre[r] - pre[q])
+                if v < best[k][r] or (v == best[k][r] and q > cut[k][r]):
+                    best[k][r], cut[k][r] = v, q
+    out, r = [rows], rows
+    for k in range(world, 0, -1):
+        r = cut[k][r]
+        out.append(r)
+    return out[::-1]
+
+
+class StripeBalancer:
+    """Keeps a sharded frame's stripes balanced by the previous frame's work.  After a frame, every rank hands in the
+    work of ITS tile rows (``row_work`` of its stripe's lists); ``update`` all_gathers them (a few dozen floats per
+    rank; every ``every`` frames) and all ranks derive the same new stripes - a new ShardLayout for the next frame.
+    Stripes only move when the bottleneck would shrink by more than ``hysteresis`` (re-cutting costs the capacity
+    estimates of the padded exchange one exact frame)."""
+
+    def __init__(self, layout: ShardLayout, every: int = 1, hysteresis: float = 0.03):
+        self.layout, self.every, self.hysteresis, self.frames = layout, max(1, int(every)), float(hysteresis), 0
+        self.tby = _tile_bounds(layout.dims[1], layout.dims[0])[1]
+
+    def stripes_from(self, work_all: Sequence[float]) -> List[int]:
+        lay = self.layout
+        new = balanced_stripes(work_all, lay.world)
+        pre = [0.0]
+        for v in work_all:
+            pre.append(pre[-1] + float(v))
+        cost = lambda st: max(pre[b] - pre[a] for a, b in zip(st, st[1:]))
+        return new if cost(new) < (1.0 - self.hysteresis) * cost(lay.stripes) else list(lay.stripes)
+
+    def update(self, my_rows: Sequence[float], group=None) -> ShardLayout:
+        """my_rows: work of this rank's tile rows (len = its stripe's rows) -> the layout for the next frame"""
+        lay = self.layout
+        self.frames += 1
+        if self.frames % self.every:
+            return lay
+        r0, r1 = lay.tile_rows
+        if len(my_rows) != r1 - r0:
+            raise ValueError("one work figure per tile row of this rank's stripe")
+        mine = torch.zeros((self.tby,), dtype=torch.float64)
+        mine[r0:r1] = torch.tensor(list(my_rows), dtype=torch.float64)
+        if lay.world > 1:
+            if dist.get_backend(group) == "gloo":
+                dist.all_reduce(mine, group=group)
+            else:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                t = mine.to(dev)
+                dist.all_reduce(t, group=group)
+                mine = t.cpu()
+        st = self.stripes_from(mine.tolist())
+        if st != list(lay.stripes):
+            self.layout = ShardLayout(lay.n_total, lay.world, lay.rank, lay.dims, st)
+        return self.layout
+
+
 def shard_model(model, world: int, rank: int) -> SplatModel:
     """Rank's rows of the six parameter tensors as a model of its own (fresh leaf tensors)."""
     i0, i1 = shard_range(model.means.shape[0], world, rank)

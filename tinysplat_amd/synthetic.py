@@ -212,8 +212,10 @@ def morton_order(points: torch.Tensor) -> torch.Tensor:
 
 
 def make_scene(n: int, sh_degree: int, width: int, height: int, seed: int = 0,
-               scale_mult: float = 1.0, fov_x_deg: float = 60.0):
+               scale_mult: float = 1.0, fov_x_deg: float = 60.0, top_third: float = 0.0):
     """Seeded random-Gaussian scene of SURVEY.md 8(d) D2.  Generated on CPU in float32.
+    ``top_third`` > 0: that share of the Gaussians is moved into the top third of the image (a SKEWED scene for the
+    work-balanced stripes of a multi-GPU frame; 0 = the uniform scene, unchanged).
 
     z ~ U(2,10); x,y = z*tan_fov*U(-1.1,1.1) (~17 % off-screen); per-axis log-scale =
     log z + U(log 8e-4, log 4e-3) (+ log scale_mult: the high-overlap stress variant uses 4);
@@ -231,6 +233,11 @@ def make_scene(n: int, sh_degree: int, width: int, height: int, seed: int = 0,
     z = U((n,), 2.0, 10.0)
     x = z * tan_x * U((n,), -1.1, 1.1)
     y = z * tan_y * U((n,), -1.1, 1.1)
+    if top_third > 0.0:         # (drawn from a generator of its own: the uniform scene's stream stays what it was)
+        g2 = torch.Generator(device="cpu").manual_seed(seed + 7919)
+        move = torch.rand((n,), generator=g2) < top_third
+        y_top = z * tan_y * (-1.1 + (1.1 - 1.0 / 3.0) * torch.rand((n,), generator=g2))      # image rows 0 .. H/3
+        y = torch.where(move, y_top, y)
     means = torch.stack([x, y, z], dim=-1)
     scales = torch.log(z)[:, None] + U((n, 3), math.log(8e-4), math.log(4e-3)) + math.log(scale_mult)
     quats = torch.randn((n, 4), generator=g, dtype=torch.float32)

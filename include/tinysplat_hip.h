@@ -447,6 +447,36 @@ int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream);
 int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* route_ws,
                        const float* grad_rows, void* stream);
 
+/* ABI 6 - the WHOLE STEP of one rank in four calls, split only where the two collectives sit:
+ *   ts_shard_rank_fwd_a   owner stage: project_fwd, colors_pack_fwd, route_count (padded groups), the send buffer zeroed,
+ *                         route_pack                                  -> send[send_rows, 16], counts[ranks]
+ *      (caller: all_to_all of the records with the groups' capacities as split sizes, all_gather of the counts)
+ *   ts_shard_rank_fwd_b   stripe stage: import_records, scan_tiles (total -> fs->total_host), import_pack, bin_count,
+ *                         tile_offsets (capacity guard), bin_scatter, sort_tiles, raster_fwd   <- recv[recv_rows, 16]
+ *   ts_shard_rank_bwd_a   raster_bwd, reduce_partials_rows            -> grad_rows[recv_rows, 12]
+ *      (caller: the reverse all_to_all)
+ *   ts_shard_rank_bwd_b   route_accumulate, sh_colors_bwd, project_bwd <- back[send_rows, 12]
+ * Nothing of a frame is looked at by the host between the calls: the groups of the exchange have the CAPACITIES the
+ * caller derived from an earlier frame (group_base_host: ranks + 1 ascending offsets into send / back), the lists of the
+ * stripe the capacity fs->capacity (ts_tile_offsets' guard).  The caller reads the counts and the stripe's pair count
+ * once the forward pass is enqueued and runs the frame again with exact sizes (the separate entries above) if a group
+ * or the lists outgrew their capacity.  fo / fs as for the entries above; fs->n = recv_rows. */
+typedef struct ts_rank_step {
+    ts_stripes stripes;
+    int32_t group_base[TS_MAX_RANKS + 1];      /* HOST: offsets of the destination groups in send / back */
+    int32_t gid_base;                           /* global index of the rank's first Gaussian */
+    int32_t send_rows, recv_rows;               /* = group_base[ranks]; sum of the capacities of the groups received */
+    int32_t* route_ws;                          /* >= ts_route_ws_ints(fo->n, ranks) */
+    int32_t* counts;                            /* device, ranks int32: records per destination of THIS frame */
+    float *send, *recv;                         /* [send_rows, 16], [recv_rows, 16] */
+    float *grad_rows, *back;                    /* [recv_rows, 12], [send_rows, 12] */
+} ts_rank_step;
+int32_t ts_rank_step_struct_bytes(void);
+int ts_shard_rank_fwd_a(const ts_frame* fo, const ts_rank_step* r, void* stream);
+int ts_shard_rank_fwd_b(const ts_frame* fs, const ts_rank_step* r, void* stream);
+int ts_shard_rank_bwd_a(const ts_frame* fs, const ts_rank_step* r, void* stream);
+int ts_shard_rank_bwd_b(const ts_frame* fo, const ts_rank_step* r, void* stream);
+
 /* ============ training-step ops around the path (scripts/train.py:58-63,97) ===== */
 
 /* Photometric loss of the training step and its gradient w.r.t. the rendered image:

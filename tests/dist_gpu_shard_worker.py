@@ -67,6 +67,40 @@ def main():
     assert sharded.padded_frames == [2, 1], sharded.padded_frames
     for a, b in zip(first, [out.detach(), xys.grad] + [p.grad for p in shard.parameters()]):
         assert torch.equal(a, b), "the repeated frame changed a result"
+    # ---- the rank executor (sharded._RankState; the default): frame 4 runs through the stage functions once more and
+    # sizes the state from its counts (one all_gather), frame 5 runs from the state - four native calls, capacities as
+    # split sizes, no count read in the middle -, frame 6 finds group capacities that are too small (every rank sees
+    # that in the gathered matrix and repeats the frame with exact sizes), frame 7 finds only THIS rank's lists too
+    # small and repeats its stripe stage alone.  Same bits every time.
+    sharded.PADDED_EXCHANGE = False
+    import ctypes
+    from tinysplat_amd import _lib
+    lib = _lib.load()
+
+    def same(tag):
+        for a, b in zip(first, [out.detach(), xys.grad] + [p.grad for p in shard.parameters()]):
+            assert torch.equal(a, b), tag
+    base = list(sharded.rank_executor_frames)
+    out, (y0, y1), xys = frame()
+    same("frame 4")
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [0, 0, 1]
+    (st,) = [v for v in sharded._rank_states.values()]
+    assert st.caps is not None and not st.busy
+    out, (y0, y1), xys = frame()
+    same("the executor's frame changed a result")
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [1, 0, 1]
+    st.size(lib, st.caps * 0 + 64, st.list_cap)
+    out, (y0, y1), xys = frame()
+    same("the frame repeated after a group overflow changed a result")
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [2, 1, 2]
+    assert int(st.caps.min()) > 64
+    st.size(lib, st.caps, 64)
+    out, (y0, y1), xys = frame()
+    same("the stripe stage repeated after a list overflow changed a result")
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [3, 1, 2] and st.list_cap > 64
+    with torch.no_grad():                       # a frame without a backward pass does not leave the state busy
+        out2, _, _ = render_sharded(shard, cam, dev, layout, exchange, with_depth=depth)
+    assert torch.equal(out2, first[0]) and not st.busy
     torch.save({"img": out.detach().cpu(), "rows": (y0, y1), "owned": layout.owned, "xys_grad": xys.grad.cpu(),
                 "grads": [p.grad.cpu() for p in shard.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -115,6 +115,42 @@ def test_all_ranks_in_one_process_equal_the_single_frame(world, depth, n, sh, w,
     _check_simulated(n, sh, w, h, mult, depth, world, stripes)
 
 
+def test_rank_executor_with_replayed_records():
+    """The rank executor in one process (the mode bench.py --emulate-ranks times): rank 1 of 3 with the other ranks'
+    records replayed.  Frame 1 goes through the stage functions, the following ones run from the persistent state
+    (four native calls, padded groups, capacity-sized lists); image, xys.grad and the six parameter gradients are
+    bitwise the same in every frame, with and without the depth channel."""
+    from tinysplat_amd import sharded
+    from tinysplat_amd.sharded import ReplayExchange, render_sharded
+    n, sh, w, h, world, rank = 40000, 2, 640, 360, 3, 1
+    for depth in (False, True):
+        model, cam = make_scene(n, sh, w, h, seed=3, scale_mult=2.0)
+        lay = ShardLayout(n, world, rank, (w, h))
+        parts, counts = [], []
+        for src in range(world):
+            rec, cnt = export_records(shard_model(model, world, src).to(DEV), cam, DEV, lay.for_rank(src), depth)
+            off = sum(cnt[:rank])
+            parts.append(rec[off:off + cnt[rank]].clone())
+            counts.append(cnt[rank])
+        ex = ReplayExchange(rank, counts, torch.cat(parts, dim=0))
+        shard = shard_model(model, world, rank).to(DEV).requires_grad_(True)
+        w_rgb, w_d = (t.to(DEV) for t in loss_weights(w, h))
+        base = list(sharded.rank_executor_frames)
+        res = []
+        for _ in range(4):
+            for p in shard.parameters():
+                p.grad = None
+            out, (y0, y1), xys = render_sharded(shard, cam, DEV, lay, ex, with_depth=depth)
+            loss = (out[:, :, :3] * w_rgb[y0:y1]).sum() + ((out[:, :, 3] * w_d[y0:y1]).sum() if depth else 0.0)
+            loss.backward()
+            res.append([out.detach().clone(), xys.grad.clone()] + [p.grad.clone() for p in shard.parameters()])
+        assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [3, 0, 1]
+        for r in res[1:]:
+            for a, b in zip(res[0], r):
+                assert torch.equal(a, b)
+        assert float(res[0][2].abs().max()) > 0
+
+
 def test_work_balanced_stripes_on_a_skewed_scene():
     """SURVEY 8(e) E2's option: stripes balanced by the previous frame's per-row work.  On a scene with 70 % of its
     Gaussians in the top third of the image, equal rows leave one rank with ~2.5x the mean work; the balanced cut

@@ -70,6 +70,16 @@ class TsStripes(ctypes.Structure):
 
 _STRIPES = POINTER(TsStripes)
 
+
+class TsRankStep(ctypes.Structure):
+    """struct ts_rank_step: what the four ts_shard_rank_* calls of one rank's step share."""
+    _fields_ = [("stripes", TsStripes), ("group_base", c_int32 * (MAX_RANKS + 1)), ("gid_base", c_int32),
+                ("send_rows", c_int32), ("recv_rows", c_int32), ("route_ws", c_void_p), ("counts", c_void_p),
+                ("send", c_void_p), ("recv", c_void_p), ("grad_rows", c_void_p), ("back", c_void_p)]
+
+
+_RANK = POINTER(TsRankStep)
+
 # name -> (restype, argtypes); mirrors include/tinysplat_hip.h declaration by declaration
 SIGNATURES = {
     "ts_abi_version": (c_int32, []),
@@ -130,6 +140,11 @@ SIGNATURES = {
     "ts_shard_stripe_fwd_import": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_stripe_bwd": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_owner_bwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),
+    "ts_rank_step_struct_bytes": (c_int32, []),
+    "ts_shard_rank_fwd_a": (c_int32, [_FRAME, _RANK, _P]),
+    "ts_shard_rank_fwd_b": (c_int32, [_FRAME, _RANK, _P]),
+    "ts_shard_rank_bwd_a": (c_int32, [_FRAME, _RANK, _P]),
+    "ts_shard_rank_bwd_b": (c_int32, [_FRAME, _RANK, _P]),
     "ts_frame_struct_bytes": (c_int32, []),
     "ts_frame_fwd_project": (c_int32, [_FRAME, _P]),
     "ts_frame_fwd_prepare": (c_int32, [_FRAME, _P]),
@@ -172,6 +187,8 @@ def load() -> ctypes.CDLL:
         raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
     if lib.ts_frame_struct_bytes() != ctypes.sizeof(TsFrame):
         raise HipLibraryError("struct ts_frame: the ctypes mirror does not match the library's layout")
+    if lib.ts_rank_step_struct_bytes() != ctypes.sizeof(TsRankStep):
+        raise HipLibraryError("struct ts_rank_step: the ctypes mirror does not match the library's layout")
     _lib = lib
     return lib
 

@@ -248,4 +248,38 @@ int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes, const int3
                           fo->v_scales, fo->v_quats, stream);
 }
 
+// ---- the whole step of one rank in four calls (ts_rank_step): the entries above composed, nothing new -------------
+int32_t ts_rank_step_struct_bytes(void) { return (int32_t)sizeof(ts_rank_step); }
+
+int ts_shard_rank_fwd_a(const ts_frame* fo, const ts_rank_step* r, void* stream) {
+    if (bad(fo) || !r || r->send_rows < 0 || r->stripes.num < 1 || r->stripes.num > TS_MAX_RANKS) return TS_E_BADARG;
+    if (r->group_base[r->stripes.num] != r->send_rows || (r->send_rows > 0 && !r->send)) return TS_E_BADARG;
+    TS_TRY(ts_shard_owner_fwd_padded(fo, &r->stripes, r->group_base, r->route_ws, r->counts, stream));
+    if (r->send_rows > 0) {
+        // an all-zero record lists nothing at its destination (radius 0): the padding of every group
+        const hipError_t e = hipMemsetAsync(r->send, 0, (size_t)r->send_rows * TS_EXPORT_RECORD_FLOATS * sizeof(float),
+                                            (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    TsRange range_("ts_route_pack");
+    return ts_route_pack(fo->n, r->gid_base, fo->xys, fo->radii, fo->depths, fo->splats, &fo->cam, &r->stripes,
+                         r->route_ws, r->send, stream);
+}
+
+int ts_shard_rank_fwd_b(const ts_frame* fs, const ts_rank_step* r, void* stream) {
+    if (bad(fs) || !r || fs->n != r->recv_rows || fs->capacity < 0) return TS_E_BADARG;
+    TS_TRY(ts_shard_stripe_fwd_import(fs, fs->n > 0 ? r->recv : nullptr, stream));
+    return ts_frame_fwd_composite(fs, stream);
+}
+
+int ts_shard_rank_bwd_a(const ts_frame* fs, const ts_rank_step* r, void* stream) {
+    if (!r) return TS_E_BADARG;
+    return ts_shard_stripe_bwd(fs, r->grad_rows, stream);
+}
+
+int ts_shard_rank_bwd_b(const ts_frame* fo, const ts_rank_step* r, void* stream) {
+    if (!r) return TS_E_BADARG;
+    return ts_shard_owner_bwd(fo, &r->stripes, r->route_ws, r->back, stream);
+}
+
 }  // extern "C"

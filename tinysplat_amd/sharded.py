@@ -107,6 +107,7 @@ class ShardLayout:
                 or stripes[-1] > tby:
             raise ValueError("stripes must be world + 1 ascending tile rows inside the frame")
         self.stripes = stripes
+        self.key = (self.world, self.rank, self.dims, self.n_total, tuple(stripes))
         st = TsStripes()
         st.num = world
         for k, v in enumerate(stripes):
@@ -239,7 +240,9 @@ class Exchange:
         No host read."""
         raise NotImplementedError
 
-    def rows(self, send: Tensor, send_counts: List[int], recv_counts: List[int], backward: bool = False) -> Tensor:
+    def rows(self, send: Tensor, send_counts: List[int], recv_counts: List[int], backward: bool = False,
+             out: Optional[Tensor] = None) -> Tensor:
+        """``out``: a [sum(recv_counts), F] buffer to receive into instead of a fresh tensor (the rank executor's)"""
         raise NotImplementedError
 
 
@@ -279,7 +282,7 @@ class DistExchange(Exchange):
         both = torch.stack([counts_dev, got]).cpu()              # the frame's host read of the record counts
         return both[0].tolist(), both[1].tolist()
 
-    def rows(self, send, send_counts, recv_counts, backward=False):
+    def rows(self, send, send_counts, recv_counts, backward=False, out=None):
         m = int(sum(recv_counts))
         if self.via_host:
             src = send.cpu()
@@ -287,8 +290,11 @@ class DistExchange(Exchange):
             with collective_timer.span(on_device=False):
                 dist.all_to_all_single(got, src, output_split_sizes=list(recv_counts),
                                        input_split_sizes=list(send_counts), group=self.group)
+            if out is not None:
+                out.copy_(got)
+                return out
             return got.to(send.device)
-        got = send.new_empty((m, send.shape[1]))
+        got = send.new_empty((m, send.shape[1])) if out is None else out
         with collective_timer.span():
             dist.all_to_all_single(got, send, output_split_sizes=list(recv_counts),
                                    input_split_sizes=list(send_counts), group=self.group)
@@ -343,15 +349,15 @@ class ReplayExchange(Exchange):
             self._padded = (splits, t)
         return self._padded[1]
 
-    def rows(self, send, send_counts, recv_counts, backward=False):
+    def rows(self, send, send_counts, recv_counts, backward=False, out=None):
         so = sum(send_counts[:self.rank])
         ro = sum(recv_counts[:self.rank])
         k = send_counts[self.rank]
         if backward:        # send = gradient rows of the imported records; own rows return, the rest is remote
-            got = send.new_zeros((sum(recv_counts), send.shape[1]))
+            got = send.new_zeros((sum(recv_counts), send.shape[1])) if out is None else out.zero_()
             got[ro:ro + k] = send[so:so + k]
             return got
-        got = self._template_for(recv_counts).clone()
+        got = self._template_for(recv_counts).clone() if out is None else out.copy_(self._template_for(recv_counts))
         got[ro:ro + k] = send[so:so + k]
         return got
 
@@ -361,7 +367,7 @@ class ReplayExchange(Exchange):
 # --------------------------------------------------------------------------------------------------
 class _Owner:
     __slots__ = ("n", "nb", "ch", "cam", "fr", "ws", "xys", "radii", "send_counts", "recv_counts", "inputs",
-                 "p_route_ws", "caps", "key", "count_host", "count_event")
+                 "p_route_ws", "caps", "key", "count_host", "count_event", "counts")
 
 
 class _Stripe:
@@ -429,6 +435,7 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
     O.xys = _view(O.ws, offs[0], torch.float32, 2 * n, (n, 2))
     O.radii = _view(O.ws, offs[2], torch.int32, n, (n,))
     counts = _view(O.ws, offs[8], torch.int32, layout.world, (layout.world,))
+    O.counts = counts
     O.p_route_ws = ptr[7]
     fr = TsFrame()
     fr.n, fr.num_bases, fr.sh_degree, fr.channels, fr.flags = n, nb, int(sh_degree), ch, 0
@@ -682,10 +689,282 @@ def _inputs(model, view, projview, origin):
                                     model.colors_rest, view[:3, :], projview, origin))
 
 
+# --------------------------------------------------------------------------------------------------
+# RANK EXECUTOR: the step of a rank with nothing rebuilt per frame
+# --------------------------------------------------------------------------------------------------
+# The stage functions above describe a frame from scratch every time: two cameras, two ts_frame structs, two carved
+# workspaces, a dozen tensors, two host reads (the record counts in the middle of the forward pass, the stripe's pair
+# count) - ~0.25 ms of Python in forward and ~0.19 ms in backward for 0.37 ms of kernels on one rank of 8 of config 3
+# (tools/host_profile_rank.py).  From the SECOND frame of a layout on, the step runs from a _RankState instead:
+#   * everything whose size follows the layout lives across frames (owner workspace, structs, cameras, route buffers);
+#   * what follows the DATA is sized by CAPACITIES derived from the previous frame - the groups of the record exchange
+#     (the padded exchange above: zeroed send buffer, ts_route_count_padded, capacities as split sizes, the counts
+#     all_gathered and looked at once the whole forward pass is enqueued) and the stripe's lists (ts_tile_offsets'
+#     capacity guard) - so no count is waited for in the middle of a frame;
+#   * the launches are issued by four native calls split only at the two collectives (ts_shard_rank_fwd_a / _fwd_b /
+#     _bwd_a / _bwd_b, csrc/frame.hip).
+# A frame whose counts outgrow a capacity (every rank sees the same count matrix) or whose lists outgrow theirs is run
+# again through the stage functions with exact sizes, which also renews the capacities; so is the first frame of a
+# layout, a frame that starts while the previous one still waits for its backward pass, and every frame while
+# ops.kernel_timer records.  Same kernels, same order, same buffers' contents: results are bitwise those of the stage
+# functions (tests/test_gpu_sharded.py).  TS_RANK_EXECUTOR=0 switches it off.
+RANK_EXECUTOR = os.environ.get("TS_RANK_EXECUTOR", "1") != "0"
+_rank_states = {}        # (layout key, n, nb, ch, dims) -> _RankState
+rank_executor_frames = [0, 0, 0]   # frames run from the state / of those repeated with exact sizes / frames via the stage functions
+
+
+class _RankState:
+    __slots__ = ("key", "dev", "layout", "n", "nb", "ch", "o_cam", "owner_ws", "o_offs", "fo", "R", "xys", "radii",
+                 "counts", "caps", "send_caps", "recv_caps", "send", "recv", "grad_rows", "back", "list_cap",
+                 "s_cam", "hints0", "split", "segs", "mode", "num_tiles", "rows", "fin_floats", "stripe_ws", "s_offs", "fs",
+                 "bucket", "partials", "busy", "count_host", "count_event", "total", "bg", "bg_key", "m", "tiles16", "fxy",
+                 "frames", "count_np")
+
+    def __init__(self, lib, dev, layout: ShardLayout, n: int, nb: int, ch: int, fx, fy):
+        w, h = layout.dims
+        self.dev, self.layout, self.n, self.nb, self.ch = dev, layout, n, nb, ch
+        self.busy, self.caps, self.list_cap, self.partials, self.bg_key, self.frames = False, None, 0, None, None, 0
+        world = layout.world
+        # ---- owner side (sizes follow the layout only)
+        self.o_cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0)
+        m = max(n, 1)
+        n_route = int(lib.ts_route_ws_ints(n, world))
+        self.owner_ws, ptr, offs = _carve(dev, [8 * m, 4 * m, 4 * m, 12 * m, 4 * m, 48 * m, m, 4 * n_route, 4 * world])
+        self.o_offs = offs
+        self.xys = _view(self.owner_ws, offs[0], torch.float32, 2 * n, (n, 2))
+        self.radii = _view(self.owner_ws, offs[2], torch.int32, n, (n,))
+        self.counts = _view(self.owner_ws, offs[8], torch.int32, world, (world,))
+        fo = TsFrame()
+        fo.n, fo.num_bases, fo.channels, fo.flags = n, nb, ch, 0
+        fo.cam, fo.capacity = self.o_cam, -1
+        fo.xys, fo.depths, fo.radii, fo.conics, fo.num_tiles_hit, fo.splats = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5]
+        fo.sh_mask = ptr[6]
+        self.fo = fo
+        R = _lib.TsRankStep()
+        R.stripes = layout.c_stripes
+        R.gid_base = layout.owned[0]
+        R.route_ws, R.counts = ptr[7], ptr[8]
+        self.R = R
+        # ---- stripe side: made by size() (its buffers follow the data, its list shape the previous frame)
+        self.tiles16 = (layout.tile_rows[1] - layout.tile_rows[0]) * _tile_bounds(h, w)[0]
+        self.fxy = (fx, fy)
+        self.mode = None
+        self.count_host = torch.empty((world * world,), dtype=torch.int32).pin_memory()
+        self.count_np = self.count_host.numpy().reshape(world, world)        # (a view of the pinned words)
+        self.count_event = torch.cuda.Event()
+
+    def size(self, lib, caps, list_cap: int):
+        """buffers for the capacities ``caps`` (the [world, world] matrix every rank derives alike) and ``list_cap``"""
+        dev, lay, ch = self.dev, self.layout, self.ch
+        me, world = lay.rank, lay.world
+        w, h = lay.dims
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        # the stripe's list shape and launch mapping, decided as _stripe_stage decides them
+        self.mode = _frame._list_mode(dev.index, self.tiles16)
+        cam = _camera(self.fxy[0], self.fxy[1], w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=lay.tile_rows)
+        cam.wide_tiles = 1 if self.mode else 0
+        self.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
+        self.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, self.mode, self.split)
+        cam.hints = (cam.hints & ~0xFF00) | (((self.segs << 8) | (w16 << 12)) if self.segs > 1 else 0)
+        self.hints0 = cam.hints
+        self.s_cam = cam
+        self.fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch))
+        self.num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
+        self.rows = _stripe_rows(cam)
+        self.bg_key = None
+        self.caps = caps
+        self.send_caps, self.recv_caps = [int(c) for c in caps[me]], [int(c) for c in caps[:, me]]
+        send_rows, m = sum(self.send_caps), sum(self.recv_caps)
+        self.m = m
+        self.send = torch.empty((send_rows, RECORD_FLOATS), **f32)
+        self.recv = torch.empty((m, RECORD_FLOATS), **f32)
+        self.grad_rows = torch.empty((m, ROW_FLOATS), **f32)
+        self.back = torch.empty((send_rows, ROW_FLOATS), **f32)
+        R = self.R
+        base = 0
+        for d in range(world):
+            R.group_base[d] = base
+            base += self.send_caps[d]
+        R.group_base[world] = base
+        R.send_rows, R.recv_rows = send_rows, m
+        R.send, R.recv, R.grad_rows, R.back = (self.send.data_ptr(), self.recv.data_ptr(), self.grad_rows.data_ptr(),
+                                               self.back.data_ptr())
+        # the stripe's workspace, as _stripe_stage lays it out (m = the capacity: padding rows are all-zero records)
+        px = self.rows * w
+        nscan, nbin = int(lib.ts_scan_ws_ints(m)), int(lib.ts_bin_ws_ints(m, self.num_tiles))
+        self.stripe_ws, ptr, offs = _carve(dev, [8 * m, 4 * m, 4 * m, 4 * m, 4 * m, 48 * m, 4 * nscan, 4 * nbin,
+                                                 8 * max(self.num_tiles, 1), 4 * self.fin_floats, 4 * px, px])
+        self.s_offs = offs
+        self.list_cap = (max(int(list_cap), 1) + 63) & ~63
+        self.bucket = torch.empty((2 * self.list_cap,), **i32)
+        fs = TsFrame()
+        fs.n, fs.num_bases, fs.sh_degree, fs.channels = m, 1, 0, ch
+        fs.flags = ((1 if _frame.TIGHT_BINNING else 0) | (2 if self.split else 0) | (8 if self.mode == 2 else 0)
+                    | (0 if _frame.TWO_HOP_SCATTER else 32))
+        fs.cam = self.s_cam
+        fs.xys, fs.depths, fs.radii, fs.num_tiles_hit, fs.cum_tiles_hit, fs.splats = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5]
+        fs.scan_ws, fs.bin_ws, fs.tile_bins = ptr[6], ptr[7], ptr[8]
+        fs.final_Ts, fs.final_index, fs.clamp_mask = ptr[9], ptr[10], ptr[11]
+        fs.total_host = _frame._total_slot(dev)[0].data_ptr()
+        fs.bucket_ids, fs.gaussian_ids_sorted = self.bucket.data_ptr(), self.bucket.data_ptr() + 4 * self.list_cap
+        fs.capacity, fs.num_intersects = self.list_cap, self.list_cap
+        self.fs = fs
+        self.partials = None
+
+    def renew(self, lib, mat, total: int):
+        """Capacities for the next frame from this frame's counts, kept while they still fit with room to spare (a
+        change re-allocates the buffers).  The groups' capacities are a function of the count matrix and the previous
+        capacities alone - identical on every rank -, the lists' capacity and their shape are this rank's own."""
+        caps = self.caps
+        self.frames += 1
+        shrink = self.frames % 32 == 0                # (looked at now and then: capacities that have become far too large)
+        if caps is None or int((caps - mat).min()) < 0 or (shrink and not bool((_capacity(mat) * 2 >= caps).all())):
+            caps = _capacity(mat)
+        need = int(total * _frame.CAPACITY_GROWTH) + 4096
+        list_cap = self.list_cap if (total <= self.list_cap and (not shrink or self.list_cap <= 2 * need)) else need
+        if caps is not self.caps or list_cap != self.list_cap or self.mode != _frame._list_mode(self.dev.index, self.tiles16):
+            self.size(lib, caps, list_cap)
+
+
+def _rank_state(lib, dev, layout: ShardLayout, n, nb, ch, fx, fy, stream_handle) -> Optional["_RankState"]:
+    key = (layout.key, dev.index, n, nb, ch, float(fx), float(fy), stream_handle)
+    st = _rank_states.get(key)
+    if st is None:
+        if len(_rank_states) > 16:                    # layouts come and go with densification: no unbounded growth
+            for k in [k for k, v in _rank_states.items() if not v.busy]:
+                del _rank_states[k]
+        st = _rank_states[key] = _RankState(lib, dev, layout, n, nb, ch, fx, fy)
+        st.key = key
+    return st
+
+
+def _fast_forward(lib, cur, dev, st: "_RankState", exchange: Exchange, inputs, background, sh_degree: int):
+    """The forward pass from a sized _RankState -> (out image, total) or None (a capacity was outgrown: the caller
+    runs the frame again through the stage functions, which renews the capacities)."""
+    _frame._mark("rank fwd: enter")
+    s = cur.cuda_stream                               # (cur: torch's current stream on dev, looked up once per pass)
+    lay, ch = st.layout, st.ch
+    world, me = lay.world, lay.rank
+    fo, fs, R = st.fo, st.fs, st.R
+    means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin = inputs
+    fo.sh_degree = int(sh_degree)
+    fo.means, fo.scales, fo.quats, fo.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
+    fo.colors_dc, fo.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
+    fo.view34, fo.projview, fo.origin = view34.data_ptr(), projview.data_ptr(), origin.data_ptr()
+    bkey = (background.data_ptr(), background._version)
+    if st.bg_key != bkey:
+        st.bg = _f32c(torch.cat([background, background[:1]])) if ch == 4 else _f32c(background)
+        st.bg_key = bkey
+        fs.background = st.bg.data_ptr()
+    fs.cam.hints = st.hints0                          # (the backward pass may have cleared the segment bits)
+    out_img = torch.empty((st.rows, lay.dims[0], ch), dtype=torch.float32, device=dev)
+    fs.out_img = out_img.data_ptr()
+    # xys / radii are handed to the caller (extras['xys'], whose .grad the backward pass sets): a frame's own tensors
+    n = st.n
+    xr = torch.empty((max(3 * n, 1),), dtype=torch.float32, device=dev)
+    st.xys, st.radii = xr[:2 * n].view(n, 2), xr[2 * n:3 * n].view(torch.int32)
+    fo.xys, fo.radii = xr.data_ptr(), xr.data_ptr() + 8 * n
+    host, event, lock = _frame._total_slot(dev)
+    with lock:
+        word = ctypes.c_int32.from_address(host.data_ptr())
+        word.value = -(1 << 31)
+        _frame._mark("rank fwd: structs set, image allocated")
+        _lib.check(lib.ts_shard_rank_fwd_a(ctypes.byref(fo), ctypes.byref(R), s), "ts_shard_rank_fwd_a")
+        _frame._mark("rank fwd: fwd_a issued")
+        mat_dev = exchange.gather(st.counts)
+        st.count_host.copy_(mat_dev.view(-1), non_blocking=True)
+        st.count_event.record(cur)
+        exchange.rows(st.send, st.send_caps, st.recv_caps, out=st.recv)
+        _frame._mark("rank fwd: counts gathered, records exchanged")
+        _lib.check(lib.ts_shard_rank_fwd_b(ctypes.byref(fs), ctypes.byref(R), s), "ts_shard_rank_fwd_b")
+        _frame._mark("rank fwd: fwd_b issued")
+        # the frame's one look at its counts, with the whole forward pass enqueued
+        total = 0
+        if st.m > 0:
+            event.record(cur)
+            k = 0
+            while word.value == -(1 << 31):
+                k += 1
+                if k > _frame._SPIN_LIMIT:
+                    event.synchronize()
+                    break
+            total = int(word.value)
+        st.count_event.synchronize()
+    _frame._mark("rank fwd: waited for the counts (GPU time)")
+    if total < 0:
+        raise OverflowError("more than 2^31-1 tile intersections in one stripe")
+    mat = st.count_np.astype(np.int64)
+    st.total = total
+    if int((st.caps - mat).min()) < 0:
+        return None, mat, total                       # a group outgrew its capacity: EVERY rank sees that and repeats
+    if total > st.list_cap:
+        # this rank's lists outgrew theirs (the device left them empty): its own affair - larger lists, the stripe
+        # stage again on the records it already holds, no collective
+        st.list_cap = (int(total * _frame.CAPACITY_GROWTH) + 4096 + 63) & ~63
+        st.bucket = torch.empty((2 * st.list_cap,), dtype=torch.int32, device=dev)
+        fs.bucket_ids, fs.gaussian_ids_sorted = st.bucket.data_ptr(), st.bucket.data_ptr() + 4 * st.list_cap
+        fs.capacity, fs.num_intersects = st.list_cap, st.list_cap
+        st.partials = None
+        _lib.check(lib.ts_shard_rank_fwd_b(ctypes.byref(fs), ctypes.byref(R), s), "ts_shard_rank_fwd_b")
+    _frame._pairs_per_tile[dev.index] = total / max(1, st.s_cam.tile_rows * st.s_cam.tile_bounds_x)
+    b = _LazyBinning()
+    b.cam, b.n, b.num_tiles, b.num_intersects = st.s_cam, st.m, st.num_tiles, total
+    b._ws, b._offs, b._bucket, b._cap = st.stripe_ws, st.s_offs, st.bucket, st.list_cap
+    _frame.last_binning[dev.index] = b
+    _frame._mark("rank fwd: exit")
+    return out_img, mat, total
+
+
+def _fast_backward(lib, s, dev, st: "_RankState", exchange: Exchange, v_img: Tensor, sh_degree: int, opacity_shape,
+                   rest_shape):
+    _frame._mark("rank bwd: enter")
+    f32 = dict(dtype=torch.float32, device=dev)
+    fo, fs, R, n, ch = st.fo, st.fs, st.R, st.n, st.ch
+    segs = _frame.backward_segments(fs.cam, st.segs, st.total, dev.index)
+    bwd_split = st.split and segs <= 1
+    rows_n = st.list_cap * (4 if bwd_split else 1)
+    if st.partials is None or st.partials.shape[0] < rows_n:
+        st.partials = torch.empty((rows_n, _lib.PARTIAL_ROW_FLOATS), **f32)
+    row_flags, fs.flag_gen = _frame.row_flags_for(dev, rows_n)
+    fs.v_out_img, fs.partials, fs.row_flags = v_img.data_ptr(), st.partials.data_ptr(), row_flags.data_ptr()
+    fs.num_intersects = st.total
+    _frame._mark("rank bwd: rows / flags ready")
+    _lib.check(lib.ts_shard_rank_bwd_a(ctypes.byref(fs), ctypes.byref(R), s), "ts_shard_rank_bwd_a")
+    fs.num_intersects = st.list_cap
+    _frame._mark("rank bwd: bwd_a issued")
+    exchange.rows(st.grad_rows, st.recv_caps, st.send_caps, backward=True, out=st.back)
+    _frame._mark("rank bwd: rows exchanged")
+    nn = max(n, 1)
+    k_op = 1
+    for d in opacity_shape[1:]:
+        k_op *= int(d)
+    k_rest = 1
+    for d in rest_shape[1:]:
+        k_rest *= int(d)
+    # ONE allocation for the seven gradient tensors handed out and the three intermediates
+    widths = (2, k_op, 3, 3, 4, 3, k_rest, 7)
+    flat = torch.empty((nn * sum(widths),), **f32)
+    parts = flat.split([nn * k for k in widths])
+    v_xy, v_opac = parts[0][:2 * n].view(n, 2), parts[1][:k_op * n].view((n,) + tuple(opacity_shape[1:]))
+    v_means, v_scales, v_quats, v_dc = (parts[2][:3 * n].view(n, 3), parts[3][:3 * n].view(n, 3), parts[4][:4 * n].view(n, 4),
+                                        parts[5][:3 * n].view(n, 3))
+    v_rest = parts[6][:k_rest * n].view((n,) + tuple(rest_shape[1:]))
+    p_tmp = parts[7].data_ptr()
+    fo.v_xy, fo.v_opacity = v_xy.data_ptr(), v_opac.data_ptr()
+    fo.v_conic, fo.v_colors, fo.v_depth = p_tmp, p_tmp + 12 * nn, p_tmp + 24 * nn
+    fo.v_means, fo.v_scales, fo.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
+    fo.v_colors_dc, fo.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
+    fo.sh_degree = int(sh_degree)
+    _frame._mark("rank bwd: gradients allocated")
+    _lib.check(lib.ts_shard_rank_bwd_b(ctypes.byref(fo), ctypes.byref(R), s), "ts_shard_rank_bwd_b")
+    _frame._mark("rank bwd: bwd_b issued")
+    return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest), v_xy
+
+
 class _ShardedFrame(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin,
-                background, fx, fy, sh_degree, with_depth, layout, exchange):
+                background, fx, fy, sh_degree, with_depth, layout, exchange, expect_backward=True):
         dev = _need_hip(means, scales, quats, opacities, colors_dc, colors_rest, view34, projview, origin, background)
         inputs = tuple(_f32c(t) for t in (means, scales, quats, opacities, colors_dc, colors_rest, view34,
                                           projview, origin))
@@ -693,6 +972,43 @@ class _ShardedFrame(torch.autograd.Function):
             raise ValueError("the model shard does not hold the rows this rank owns")
         ch = 4 if with_depth else 3
         lib = _lib.load()
+        # (which path a frame takes must be the same on every rank - the two paths make different collectives -, so it
+        # depends only on what all ranks share: switches, the call pattern, the gathered count matrix)
+        st = None
+        if RANK_EXECUTOR and exchange.can_gather and _comm.gather_usable and not kernel_timer.enabled \
+                and not _frame.CAPACITY_ALLOC and not PADDED_EXCHANGE:
+            cur = torch.cuda.current_stream(dev)
+            st = _rank_state(lib, dev, layout, means.shape[0], colors_rest.shape[1] + 1, ch, fx, fy, cur.cuda_stream)
+            if st.busy:
+                st = None                                    # (a frame still waits for its backward pass: stage functions)
+        if st is not None and st.caps is not None:
+            with torch.cuda.device(dev):
+                if st.mode != _frame._list_mode(dev.index, st.tiles16):
+                    st.size(lib, st.caps, st.list_cap)       # the lists changed shape: this rank's own affair
+                out, mat, total = _fast_forward(lib, cur, dev, st, exchange, inputs, background, int(sh_degree))
+                rank_executor_frames[0] += 1
+                if out is None:
+                    st.renew(lib, mat, total)
+            if out is not None:
+                if not expect_backward:                      # no backward pass will come for this frame (no_grad)
+                    st.renew(lib, mat, total)
+                    ctx.state = None
+                    ctx.mark_non_differentiable(st.xys, st.radii)
+                    return out, st.xys, st.radii
+                st.busy = True
+                ctx.state, ctx.layout, ctx.exchange = st, layout, exchange
+                ctx.inputs = inputs
+                ctx.caps_next = (mat, total)
+                ctx.opacity_shape, ctx.rest_shape, ctx.sh_degree = opacities.shape, colors_rest.shape, int(sh_degree)
+                xys, radii = st.xys, st.radii
+                ctx.xys_out = xys
+                ctx.mark_non_differentiable(xys, radii)
+                ctx.set_materialize_grads(False)
+                ctx.out_shape = tuple(out.shape)
+                return out, xys, radii
+            rank_executor_frames[1] += 1
+        ctx.state = None
+        rank_executor_frames[2] += 1
         with torch.cuda.device(dev):
             s = _stream(dev)
             O, send = _owner_stage(lib, s, dev, layout, exchange, *inputs, fx, fy, int(sh_degree), ch, keep=True)
@@ -713,6 +1029,12 @@ class _ShardedFrame(torch.autograd.Function):
                                            keep=True, padded=False)
                     records = exchange.rows(send, O.send_counts, O.recv_counts)
                     S, out = _stripe_stage(lib, s, dev, layout, records, background, fx, fy, ch, keep=True)
+        if st is not None and st.caps is None:
+            # the first frame of a layout ran with exact sizes: its counts give the executor's first capacities.  The
+            # count matrix has to be the same on every rank: one all_gather of the counts, outside the frame's path
+            with torch.cuda.device(dev):
+                mat = exchange.gather(O.counts).cpu().numpy().astype(np.int64)
+                st.size(lib, _capacity(mat), int(S.total * _frame.CAPACITY_GROWTH) + 4096)
         O.inputs = inputs
         ctx.owner, ctx.stripe, ctx.layout, ctx.exchange = O, S, layout, exchange
         ctx.opacity_shape, ctx.rest_shape, ctx.sh_degree = opacities.shape, colors_rest.shape, int(sh_degree)
@@ -725,9 +1047,26 @@ class _ShardedFrame(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_img, _v_xys, _v_radii):
+        lib = _lib.load()
+        st = ctx.state
+        if st is not None:                                  # the rank executor's frame
+            dev = st.dev
+            try:
+                with torch.cuda.device(dev):
+                    if v_img is None:
+                        v_img = torch.zeros(ctx.out_shape, dtype=torch.float32, device=dev)
+                    grads, v_xy = _fast_backward(lib, _stream(dev), dev, st, ctx.exchange, _f32c(v_img), ctx.sh_degree,
+                                                 ctx.opacity_shape, ctx.rest_shape)
+                    st.renew(lib, *ctx.caps_next)
+                    _frame._mark("rank bwd: capacities renewed")
+            finally:
+                st.busy = False
+            xo = ctx.xys_out
+            v_xy = v_xy.clone()                             # (the gradients share one allocation; xys.grad outlives them)
+            xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
+            return grads + (None,) * 11
         O, S, layout, exchange = ctx.owner, ctx.stripe, ctx.layout, ctx.exchange
         dev = O.xys.device
-        lib = _lib.load()
         with torch.cuda.device(dev):
             s = _stream(dev)
             if v_img is None:
@@ -738,7 +1077,7 @@ class _ShardedFrame(torch.autograd.Function):
                                           ctx.rest_shape)
         xo = ctx.xys_out                       # what extras['xys'].grad holds in the reference, for the OWNED rows
         xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
-        return grads + (None,) * 10
+        return grads + (None,) * 11
 
 
 def render_sharded(model_shard, camera, device, layout: ShardLayout, exchange: Exchange, with_depth: bool = False):
@@ -750,7 +1089,8 @@ def render_sharded(model_shard, camera, device, layout: ShardLayout, exchange: E
     out, xys, _ = _ShardedFrame.apply(model_shard.means, model_shard.scales, model_shard.quats,
                                       model_shard.opacities, model_shard.colors_dc, model_shard.colors_rest,
                                       view[:3, :], projview, origin, model_shard.background, camera.f_x, camera.f_y,
-                                      model_shard.active_sh_degree, with_depth, layout, exchange)
+                                      model_shard.active_sh_degree, with_depth, layout, exchange,
+                                      torch.is_grad_enabled() and any(p.requires_grad for p in model_shard.parameters()))
     y0 = 16 * layout.tile_rows[0]
     return out, (y0, y0 + out.shape[0]), xys
 

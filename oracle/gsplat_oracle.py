@@ -565,3 +565,85 @@ def rasterize_pixel_loop(xys, depths, radii, conics, num_tiles_hit, colors, opac
             fT[i, j] = T
             fI[i, j] = cur
     return out, 1.0 - fT, fT, fI
+
+
+def rasterize_backward_pixel_loop(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                                  background, v_out_img, v_out_alpha=None, alpha_max_bwd=ALPHA_MAX, clamp_gates_grad=True):
+    """Scalar, per-pixel restatement of the BACKWARD compositing loop as SURVEY.md App. A.5 records gsplat 0.1.x's
+    rasterize_backward (tiny cases only; float64 arithmetic on the given inputs): every pixel replays its list from
+    the last Gaussian the forward pass composited back to the first,
+
+        alpha = min(alpha_max_bwd, opacity * vis);  skipped if sigma < 0 or alpha < 1/255
+        ra = 1 / (1 - alpha);  T *= ra;  fac = alpha * T
+        v_alpha = (c T - buffer ra) . v_out + T_final ra (v_out_alpha - bg . v_out);   buffer += c fac
+        v_sigma = -opacity vis v_alpha     [0 where the forward clamp is active, with ``clamp_gates_grad``]
+
+    App. C's open choice: the defaults (alpha_max_bwd = ALPHA_MAX = 0.999, clamp_gates_grad) are what autograd derives
+    from ``rasterize_gaussians`` (checked in tests/test_oracle_kat.py); (0.99, False) is upstream's own backward pass as
+    the survey records it - the setting the HIP kernels take with -DTS_BWD_CLAMP_UPSTREAM=1
+    (tests/test_gpu_variants.py).  v_conic holds the true partials (xx, xy, yy) as everywhere in this oracle.
+    -> (v_xy [N,2], v_conic [N,3], v_colors [N,C], v_opacity [N]) float64."""
+    H, W = int(img_height), int(img_width)
+    C = colors.shape[1]
+    n = xys.shape[0]
+    tbx, tby = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+    _, _, gids, tile_bins = bin_and_sort(xys, depths, radii, num_tiles_hit, (tbx, tby, 1))
+    _, _, fT, fI = rasterize_pixel_loop(xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, background)
+    if opacity.dim() == 2:
+        opacity = opacity[:, 0]
+    X, CN, COL, OP = xys.double().tolist(), conics.double().tolist(), colors.double().tolist(), opacity.double().tolist()
+    BG = [float(b) for b in background]
+    VO = v_out_img.double().tolist()
+    VA = None if v_out_alpha is None else v_out_alpha.double().tolist()
+    v_xy = [[0.0, 0.0] for _ in range(n)]
+    v_conic = [[0.0, 0.0, 0.0] for _ in range(n)]
+    v_col = [[0.0] * C for _ in range(n)]
+    v_op = [0.0] * n
+    G, TB, FT, FI = gids.tolist(), tile_bins.tolist(), fT.double().tolist(), fI.tolist()
+    for i in range(H):
+        for j in range(W):
+            t = (i // BLOCK) * tbx + (j // BLOCK)
+            s, e = TB[t]
+            if e <= s:
+                continue
+            px, py = j + PIXEL_CENTER_OFFSET, i + PIXEL_CENTER_OFFSET
+            T_final = FT[i][j]
+            T = T_final
+            vo = VO[i][j]
+            va = 0.0 if VA is None else VA[i][j]
+            tail = va - sum(BG[c] * vo[c] for c in range(C))
+            buf = [0.0] * C
+            for idx in range(min(FI[i][j], e - 1), s - 1, -1):
+                g = G[idx]
+                dx, dy = X[g][0] - px, X[g][1] - py
+                cxx, cxy, cyy = CN[g]
+                sigma = 0.5 * (cxx * dx * dx + cyy * dy * dy) + cxy * dx * dy
+                vis = math.exp(-sigma)
+                raw = OP[g] * vis
+                alpha = min(alpha_max_bwd, raw)
+                if sigma < 0 or alpha < ALPHA_MIN:
+                    continue
+                ra = 1.0 / (1.0 - alpha)
+                T *= ra
+                fac = alpha * T
+                v_alpha = T_final * ra * tail
+                for c in range(C):
+                    v_col[g][c] += fac * vo[c]
+                    v_alpha += (COL[g][c] * T - buf[c] * ra) * vo[c]
+                    buf[c] += COL[g][c] * fac
+                v_sigma = -raw * v_alpha
+                if clamp_gates_grad and raw > ALPHA_MAX:
+                    v_sigma = 0.0
+                    v_alpha_op = 0.0
+                else:
+                    v_alpha_op = v_alpha
+                v_conic[g][0] += 0.5 * v_sigma * dx * dx
+                v_conic[g][1] += v_sigma * dx * dy
+                v_conic[g][2] += 0.5 * v_sigma * dy * dy
+                v_xy[g][0] += v_sigma * (cxx * dx + cxy * dy)
+                v_xy[g][1] += v_sigma * (cxy * dx + cyy * dy)
+                v_op[g] += vis * v_alpha_op
+    f64 = torch.float64
+    return (torch.tensor(v_xy, dtype=f64).reshape(n, 2), torch.tensor(v_conic, dtype=f64).reshape(n, 3),
+            torch.tensor(v_col, dtype=f64).reshape(n, C), torch.tensor(v_op, dtype=f64))
+

@@ -83,6 +83,31 @@ def test_row_flag_generations_wrap_and_match_zeroed_flags(monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_row_flags_are_kept_through_alternating_pass_sizes(monkeypatch):
+    """frame.row_flags_for: a stream that alternates large and small backward passes keeps ONE flag array -
+    it is given back only after FLAGS_SHRINK_AFTER consecutive small passes - and the table of arrays is bounded."""
+    monkeypatch.setattr(frame, "FLAGS_SHRINK_AFTER", 5)
+    key = (DEV.index, torch.cuda.current_stream(DEV).cuda_stream)
+    frame._row_flags.pop(key, None)
+    big, small = 40_000_000, 1000
+    a, g1 = frame.row_flags_for(DEV, big)
+    for k in range(6):                                    # large / small alternately: the same array, generations count up
+        t, g = frame.row_flags_for(DEV, small if k % 2 == 0 else big)
+        assert t.data_ptr() == a.data_ptr() and g == g1 + 1 + k
+    for k in range(4):                                    # four small passes in a row: still kept
+        assert frame.row_flags_for(DEV, small)[0].data_ptr() == a.data_ptr()
+    t, g = frame.row_flags_for(DEV, small)                # the fifth: given back, a small fresh array, generation 1
+    assert t.numel() < big // 8 and g == 1 and int(t.max()) == 0
+    for k in range(40):                                   # (device, stream) keys of streams that are gone do not pile up:
+        frame._row_flags[(DEV.index, -1000 - k)] = [t, 1, 0]
+    before = len(frame._row_flags)
+    with torch.cuda.stream(torch.cuda.Stream(DEV)):       # a stream the table has not seen: one entry in, one out
+        frame.row_flags_for(DEV, small)
+    assert len(frame._row_flags) == before >= 32
+    for k_ in [k_ for k_ in frame._row_flags if k_[1] <= -1000]:
+        del frame._row_flags[k_]
+
+
 @pytest.mark.parametrize("n,sh,w,h,mult,wide", [(300000, 1, 1920, 1080, 1.0, 0), (270000, 0, 1000, 523, 3.0, 0),
                                                 (400000, 0, 1283, 717, 2.0, 2), (262144, 2, 640, 360, 6.0, 0)])
 def test_two_hop_scatter_fills_the_buckets_of_the_direct_scatter(n, sh, w, h, mult, wide, monkeypatch):

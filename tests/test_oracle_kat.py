@@ -313,3 +313,42 @@ def test_fuzz_cases_are_deterministic_and_buildable():
             assert torch.equal(p, q)
         assert torch.equal(c1.view_matrix, c2.view_matrix)
         assert m1.means.shape[0] == a["n"]
+
+
+def test_explicit_backward_loop_equals_autograd_of_the_forward():
+    """oracle.rasterize_backward_pixel_loop (the backward compositing loop written out per pixel) with
+    its defaults - alpha clamp 0.999, no gradient through a clamped alpha - is what autograd derives from
+    rasterize_gaussians, to float64 rounding, on a scene where a sixth of the opacities sit above the clamp; with
+    upstream's own constants (0.99, no gating: App. C's other setting, tests/test_gpu_variants.py) it is measurably
+    different - the switch is not vacuous."""
+    import math
+    n, W, H = 60, 40, 32
+    g = torch.Generator().manual_seed(3)
+    xys = torch.stack([torch.rand(n, generator=g) * W, torch.rand(n, generator=g) * H], 1).double()
+    depths = (1 + torch.rand(n, generator=g)).double()
+    radii = torch.full((n,), 12, dtype=torch.int32)
+    a, c = 0.02 + 0.1 * torch.rand(n, generator=g), 0.02 + 0.1 * torch.rand(n, generator=g)
+    b = (torch.rand(n, generator=g) - 0.5) * 0.04
+    conics = torch.stack([a, b, c], 1).double()
+    colors = torch.rand(n, 3, generator=g).double()
+    opacity = torch.cat([0.3 + 0.6 * torch.rand(n - 10, generator=g), 0.995 + 0.005 * torch.rand(10, generator=g)]).double()
+    tbx, tby = (W + 15) // 16, (H + 15) // 16
+
+    def nth_of(x, y, r):
+        tcx, tcy, tr = x / 16, y / 16, r / 16
+        minx, maxx = int(min(max(math.trunc(tcx - tr), 0), tbx)), int(min(max(math.trunc(tcx + tr + 1), 0), tbx))
+        miny, maxy = int(min(max(math.trunc(tcy - tr), 0), tby)), int(min(max(math.trunc(tcy + tr + 1), 0), tby))
+        return (maxx - minx) * (maxy - miny)
+    nth = torch.tensor([nth_of(float(xys[i, 0]), float(xys[i, 1]), 12.0) for i in range(n)], dtype=torch.int32)
+    bg = torch.tensor([0.2, 0.4, 0.1]).double()
+    leaf = [t.clone().requires_grad_(True) for t in (xys, conics, colors, opacity)]
+    img, alpha = O.rasterize_gaussians(leaf[0], depths, radii, leaf[1], nth, leaf[2], leaf[3], H, W, bg)
+    w, wa = torch.rand(H, W, 3, generator=g).double(), torch.rand(H, W, generator=g).double()
+    ((img * w).sum() + (alpha * wa).sum()).backward()
+    got = O.rasterize_backward_pixel_loop(xys, depths, radii, conics, nth, colors, opacity, H, W, bg, w, wa)
+    for t, ref in zip(got, leaf):
+        assert (t - ref.grad).abs().max() <= 1e-11 * max(1.0, float(ref.grad.abs().max()))
+    up = O.rasterize_backward_pixel_loop(xys, depths, radii, conics, nth, colors, opacity, H, W, bg, w, wa,
+                                         alpha_max_bwd=0.99, clamp_gates_grad=False)
+    assert (up[0] - got[0]).abs().max() > 1e-3 and (up[3] - got[3]).abs().max() > 1e-2
+

@@ -53,6 +53,32 @@ def _flags_match(obj: Path, cmd) -> bool:
     return sp.exists() and sp.read_text() == " ".join(cmd[1:])
 
 
+def build_variant(out_dir, flags, jobs: int = 8) -> Path:
+    """A second build of the library with extra -D flags into ``out_dir`` (objects and .so; the in-tree build is not
+    touched), sources compiled in parallel -> path of the .so.  Load it in a process of its own with TS_LIB_PATH=<path>
+    TS_ALLOW_VARIANT_LIB=1 (tests/test_gpu_variants.py: the other settings of SURVEY App. C's switches)."""
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    flags = list(flags)
+
+    def one(item):
+        src, extra = item
+        o = out_dir / (Path(src).stem + ".o")
+        subprocess.run([hipcc, *COMMON, *extra, *flags, "-c", str(CSRC / src), "-o", str(o)], check=True)
+        return str(o)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    rocm = Path(hipcc).resolve().parent.parent
+    have_roctx = any((r / "include" / "rocprofiler-sdk-roctx" / "roctx.h").exists() for r in (rocm, Path("/opt/rocm")))
+    lib = out_dir / "libtinysplat_hip.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs,
+                    *(["-lrocprofiler-sdk-roctx"] if have_roctx else []), "-o", str(lib)], check=True)
+    _stamp_path(lib).write_text(" ".join([*COMMON, *flags]))
+    return lib
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     # developer knob for ablation runs (tools/time_raster.py): extra -D flags, implies a rebuild

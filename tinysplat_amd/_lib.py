@@ -10,7 +10,10 @@ import os
 from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
+# TS_LIB_PATH: another build of the library (tests/test_gpu_variants.py loads builds with the other settings of the
+# compile-time switches in a process of their own); a variant build needs TS_ALLOW_VARIANT_LIB=1 as usual
+LIB_PATH = Path(os.environ["TS_LIB_PATH"]) if os.environ.get("TS_LIB_PATH") else \
+    Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
 ABI_VERSION = 6
 HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot

@@ -191,7 +191,7 @@ struct TightTest {
         cull_all = false; geometric = false;
         gx = gy = hA = B = tau4A = D4 = inv2A = dymax = dxext = dy_left = 0.0f;
         if (!tight) return;
-        gx = q0.x; gy = q0.y;
+        gx = q0.x - ts::kPixOff; gy = q0.y - ts::kPixOff;      // (row_range works on pixel INDICES: sample = index + off)
         hA = 0.5f * ts::kLog2e * q0.w; B = ts::kLog2e * q1.x;
         const float hC = 0.5f * ts::kLog2e * q1.y;
         const float op = q0.z;

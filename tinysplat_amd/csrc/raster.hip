@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             float a = araw;
             mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx[k]);
             if (GENERAL) {
-                a = fminf(ts::kAlphaMax, araw);
+                a = fminf(ts::kAlphaMaxBwd, araw);
                 validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
             }
             if (validm == 0ull) continue;                              // wave-uniform
@@ -1093,7 +1093,8 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             T[k] = Tk;
             // d alpha / d sigma = -alpha, or 0 where the 0.999 clamp is active
             float v_sig = -am * v_a;
-            if (GENERAL) v_sig = TS_LANE(TS_BALLOT(araw > ts::kAlphaMax)) ? 0.0f : v_sig;
+            if (GENERAL && ts::kClampGatesGrad) v_sig = TS_LANE(TS_BALLOT(araw > ts::kAlphaMax)) ? 0.0f : v_sig;
+            if (GENERAL && !ts::kClampGatesGrad) v_sig = -(TS_LANE(validm) ? araw : 0.0f) * v_a;   // -opacity vis v_alpha
             const float vdx = v_sig * dx, vdy = v_sig * dy;
             acc[0] += v_sig; acc[1] += vdx; acc[2] += vdy;
             acc[3] = __builtin_fmaf(vdx, dx, acc[3]);

@@ -20,10 +20,25 @@
 namespace ts {
 
 constexpr float kBlur = 0.3f;          // low-pass added to the cov2d diagonal
-constexpr float kAlphaMax = 0.999f;    // forward (and, by choice, backward) alpha clamp
+// SURVEY App. C's two open choices are compile-time switches, so that vectors from a pinned gsplat are a one-line
+// flip; the other setting of each is built and checked against the oracle with the same constants once per test
+// session (tests/test_gpu_variants.py):
+//   TS_PIX_OFF (0 | 0.5f)          pixel (j, i) sampled at (j + off, i + off); 0.1.3-era: 0
+//   TS_BWD_CLAMP_UPSTREAM (0 | 1)  0: the backward pass differentiates the forward pass (alpha clamped at 0.999, no
+//                                  gradient through a clamped alpha); 1: upstream's rasterize_backward as SURVEY App. C
+//                                  records it - alpha re-clamped at 0.99, v_sigma = -opacity * vis * v_alpha unconditionally
+#ifndef TS_PIX_OFF
+#define TS_PIX_OFF 0.0f
+#endif
+#ifndef TS_BWD_CLAMP_UPSTREAM
+#define TS_BWD_CLAMP_UPSTREAM 0
+#endif
+constexpr float kAlphaMax = 0.999f;    // forward (and, by default, backward) alpha clamp
+constexpr float kAlphaMaxBwd = TS_BWD_CLAMP_UPSTREAM ? 0.99f : kAlphaMax;
+constexpr bool kClampGatesGrad = !TS_BWD_CLAMP_UPSTREAM;
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTEps = 1e-4f;         // transmittance early-out
-constexpr float kPixOff = 0.0f;        // pixel (j,i) sampled at (j+off, i+off); 0.1.3-era = 0
+constexpr float kPixOff = TS_PIX_OFF;
 constexpr int kTile = 16;
 
 struct Cam {                 // device-side camera block (matrices by value)

@@ -77,9 +77,14 @@ HYBRID_SEGS = max(1, min(8, int(os.environ.get("TS_HYBRID_SEGS", "8"))))
 HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
 
 
-def _list_segments(tiles16: int, mode: int, split: bool):
-    """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch"""
+def _list_segments(tiles16: int, mode: int, split: bool, prev_pairs: Optional[float] = None):
+    """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch.
+    ``prev_pairs``: bounding-box pairs per tile of the previous frame on the device, if known - a launch of short lists
+    (the backward pass would fall back to split blocks / whole tiles anyway, ``backward_segments``) does not keep the
+    boundary records at all (up to 36 planes written for nothing); a wrong guess only costs speed."""
     if mode != 0 or tiles16 <= 0:
+        return 1, 0
+    if prev_pairs is not None and prev_pairs < 0.5 * LIST_SEGMENTS_FROM:
         return 1, 0
     if not split:
         return (HYBRID_SEGS, HYBRID_WHOLE16) if (HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM) else (1, 0)
@@ -156,20 +161,33 @@ _row_flags_lock = threading.Lock()
 FLAG_GENERATIONS = os.environ.get("TS_FLAG_GENERATIONS", "1") != "0"
 
 
+FLAGS_SHRINK_AFTER = 256      # consecutive passes that needed < 1/8 of the array before it is given back
+
+
 def row_flags_for(dev: torch.device, rows: int):
     """-> (uint8 tensor of >= rows bytes, generation).  generation 0: a fresh array the kernels zero themselves.
 
     One array per (device, STREAM): two backward passes on different streams of a device (or from two host threads,
     each on its own stream) never share a generation counter or race on the wrap-around zeroing; passes on ONE
-    stream are ordered by the stream.  An array much larger than a frame needs (a big frame followed by small
-    ones) is released instead of being kept for ever."""
+    stream are ordered by the stream.  An array much larger than the passes need is given back only after
+    FLAGS_SHRINK_AFTER consecutive small passes - a workload that alternates large and small passes on one stream (a
+    full frame, then a rank's stripes; multi-resolution training) keeps one array instead of allocating and zeroing
+    megabytes at every switch - and the table holds at most 32 (device, stream) entries."""
     if not FLAG_GENERATIONS:
         return torch.empty((rows,), dtype=torch.uint8, device=dev), 0
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     with _row_flags_lock:
         slot = _row_flags.get(key)
-        if slot is None or slot[0].numel() < rows or slot[0].numel() > 8 * max(rows, 1 << 20):
-            slot = _row_flags[key] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0]
+        if slot is not None and slot[0].numel() > 8 * max(rows, 1 << 20):
+            slot[2] += 1
+            if slot[2] >= FLAGS_SHRINK_AFTER:
+                slot = None
+        elif slot is not None:
+            slot[2] = 0
+        if slot is None or slot[0].numel() < rows:
+            if key not in _row_flags and len(_row_flags) >= 32:          # streams that are gone
+                _row_flags.pop(next(iter(_row_flags)))
+            slot = _row_flags[key] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0, 0]
         slot[1] += 1
         if slot[1] > 255:
             slot[0].zero_()
@@ -278,7 +296,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
-    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
+    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split, prev_i) if keep else (1, 0)
     cam.hints = (cam.hints & ~0xFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
     F.segs = segs
     _mark("fwd:inputs checked")

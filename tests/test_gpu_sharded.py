@@ -268,7 +268,7 @@ def _launch(world, out_dir, n, sh, w, h, mult, depth, timeout=900, backend="gloo
            str(mult), str(int(depth))]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", TS_TEST_BACKEND=backend)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "Error" in l or "assert" in l or "File \"/" in l)[-6000:]
     return [torch.load(Path(out_dir) / f"rank{k}.pt") for k in range(world)]
 
 

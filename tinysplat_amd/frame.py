@@ -77,14 +77,9 @@ HYBRID_SEGS = max(1, min(8, int(os.environ.get("TS_HYBRID_SEGS", "8"))))
 HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
 
 
-def _list_segments(tiles16: int, mode: int, split: bool, prev_pairs: Optional[float] = None):
-    """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch.
-    ``prev_pairs``: bounding-box pairs per tile of the previous frame on the device, if known - a launch of short lists
-    (the backward pass would fall back to split blocks / whole tiles anyway, ``backward_segments``) does not keep the
-    boundary records at all (up to 36 planes written for nothing); a wrong guess only costs speed."""
+def _list_segments(tiles16: int, mode: int, split: bool):
+    """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch"""
     if mode != 0 or tiles16 <= 0:
-        return 1, 0
-    if prev_pairs is not None and prev_pairs < 0.5 * LIST_SEGMENTS_FROM:
         return 1, 0
     if not split:
         return (HYBRID_SEGS, HYBRID_WHOLE16) if (HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM) else (1, 0)
@@ -96,14 +91,22 @@ def _list_segments(tiles16: int, mode: int, split: bool, prev_pairs: Optional[fl
 last_segments = {}      # device index -> list segments of the most recent backward pass (1 = none; tests, tools)
 
 
-def backward_segments(cam, segs: int, total: int, dev_index: int = 0) -> int:
-    """the backward pass's choice (see above): ``segs``, or 1 with the field of ``cam`` cleared -> split blocks"""
+def segments_for_count(cam, segs: int, total: int) -> int:
+    """The frame's own choice between list segments and the uncut replay, from ITS pair count (the same frame always
+    takes the same path): ``segs``, or 1 with the field of ``cam`` cleared.  Called by the FORWARD pass as soon as the
+    count is known - a launch of short lists then keeps no boundary records at all (up to 36 planes written
+    for nothing) - and again by the backward pass (where the forward pass was enqueued before the count was known)."""
     if segs > 1 and total >= LIST_SEGMENTS_FROM * cam.tile_rows * cam.tile_bounds_x:
-        last_segments[dev_index] = segs
         return segs
     cam.hints &= ~0xFF00
-    last_segments[dev_index] = 1
     return 1
+
+
+def backward_segments(cam, segs: int, total: int, dev_index: int = 0) -> int:
+    """the backward pass's choice (see above): ``segs``, or 1 with the field of ``cam`` cleared -> split blocks"""
+    segs = segments_for_count(cam, segs, total)
+    last_segments[dev_index] = segs
+    return segs
 
 # WIDE LISTS: the frame path bins, scatters and sorts on 32x16 tiles - two horizontally adjacent 16x16 tiles
 # as one list (ts_camera.wide_tiles; 0.73x the list entries on the random scenes, longer lists for the sort
@@ -296,7 +299,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
-    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split, prev_i) if keep else (1, 0)
+    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
     cam.hints = (cam.hints & ~0xFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
     F.segs = segs
     _mark("fwd:inputs checked")
@@ -446,6 +449,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
             cap = lists(total)
             _mark("fwd:lists allocated")
             fr.capacity, fr.num_intersects = -1, total
+            F.segs = segments_for_count(fr.cam, F.segs, total)      # short lists: no boundary records are kept
             if redo:
                 prepare()
             composite()

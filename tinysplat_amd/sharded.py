@@ -510,8 +510,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     cam.wide_tiles = 1 if S.mode else 0
     S.cam = cam
     S.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
-    S.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split,
-                                        _frame._pairs_per_tile.get(dev.index)) if keep else (1, 0)
+    S.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split) if keep else (1, 0)
     cam.hints = (cam.hints & ~0xFF00) | (((S.segs << 8) | (w16 << 12)) if S.segs > 1 else 0)
     fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch))
     num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
@@ -612,6 +611,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
         redo = cap is not None
         cap = lists(total)
         fr.capacity, fr.num_intersects = -1, total
+        S.segs = _frame.segments_for_count(fr.cam, S.segs, total)      # short lists: no boundary records are kept
         if redo:
             stage_import()
         composite()

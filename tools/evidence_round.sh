@@ -19,6 +19,13 @@ for a in "--config 2" "--config 5 --steps 20 --warmup 5" "--config 5 --steps 20 
          "--config 5 --steps 20 --warmup 5 --emulate-ranks 8 --emulate-rank 4" "--config 5 --steps 20 --warmup 5 --emulate-ranks 8 --emulate-rank 4 --shard-mode replicated"; do
   timeout 300 python bench.py $a --no-cpu-baseline --no-pmc 2>/dev/null | tee "$OUT/bench_$(echo $a | tr -d ' -').json" | python tools/print_bench.py | head -1 | cut -c1-230
 done
+echo "== hybrid compositing launches: settings around the default (tools/hybrid_sweep.py)"
+timeout 300 python tools/hybrid_sweep.py --settings "1:0 8:13 8:12 8:14 4:13 1:0" 2>&1 | grep "^S=" | tee $OUT/${TAG}_hybrid_sweep.txt
+echo "== one emulated rank step for EVERY rank of 8 (tools/rank_table.py), config 3 and config 5"
+timeout 600 python tools/rank_table.py --config 3 --modes equal 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config3.txt | tail -1
+timeout 900 python tools/rank_table.py --config 5 --modes equal --steps 20 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config5.txt | tail -1
+timeout 600 python tools/rank_table.py --config 3 --modes equal --shard-mode replicated 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config3_replicated.txt | tail -1
+echo "== host side of the emulated rank step"; timeout 300 python tools/host_profile_rank.py 200 2>&1 | grep -v amdgpu | head -19 | tee $OUT/${TAG}_rank_host_marks.txt | head -3
 echo "== bench --gpus 2 (both ranks on this GPU, gloo: functional)"; timeout 300 python bench.py --gpus 2 --single-device --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | cut -c1-300
 echo "== marker + kernel trace of three frames (roctx ranges of the executor calls)"
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/mk && timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d /tmp/mk -o mk -- python $OLDPWD/bench.py --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-bandwidth --no-rgbd-figure > /dev/null 2>&1; \

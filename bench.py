@@ -452,6 +452,12 @@ def main():
     ap.add_argument("--gather-calibration", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-rgbd-figure", action="store_true",
                     help="do not time the RGB + depth frame (the reference's full adapter call) beside the RGB headline")
+    ap.add_argument("--upstream", default="grad", choices=("grad", "loss"),
+                    help="how the backward pass of a step is started.  'grad' (default): D2's loss L = (rgb * w_rgb).sum() "
+                         "(+ (depth * w_d).sum()) enters as its analytic upstream gradient, v_out = w, handed to "
+                         "torch.autograd.backward - the timed step is the render path's forward + backward and nothing "
+                         "else.  'loss': the loss is evaluated by torch kernels inside the step (rocBLAS dot, fill, mul: "
+                         "~33 us per frame on config 3 that belong to no row of SURVEY 8(a)) - rounds 1-4 timed this")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="leave the process's CPU affinity alone (default: the cores of the GPU's NUMA node)")
     args = ap.parse_args()
@@ -505,6 +511,19 @@ def main():
     model.requires_grad_(True)
     w_rgb, w_d = loss_weights(w, h)
     w_rgb, w_d = w_rgb.to(dev), w_d.to(dev)
+    w_rgbd = torch.cat([w_rgb, w_d.unsqueeze(-1)], dim=-1).contiguous()       # v_out of a 4-channel stripe image
+
+    def backprop(outs, y0=0, y1=None):
+        """Backward pass of D2's loss for the outputs `outs` = [(tensor, weights)]: L = sum((t * w).sum())."""
+        if args.upstream == "grad":      # dL/dt = w: the analytic upstream gradient, no loss kernels in the step
+            torch.autograd.backward([t_ for t_, _ in outs], [w_[y0:y1] for _, w_ in outs])
+            return
+        loss = None
+        for t_, w_ in outs:
+            l_ = torch.dot(t_.reshape(-1), w_[y0:y1].reshape(-1))
+            loss = l_ if loss is None else loss + l_
+        loss.backward()
+
     adapter = GaussianRasterizer(model, None, device=dev)
     sharded = world > 1 or args.emulate_ranks > 1 or args.force_dist
     # ---- which multi-GPU design runs is decided BEFORE the first frame (VERDICT r3 / ADVICE r3): every rank makes
@@ -584,11 +603,7 @@ def main():
             p_.grad = None
         if gshard is not None and step_mode[0] == "gaussians":
             out, (y0, y1), _ = render_sharded(gshard[0], cam, dev, gshard[1], gshard[2], with_depth=args.depth)
-            if out.shape[2] == 3:
-                loss = torch.dot(out.reshape(-1), w_rgb[y0:y1].reshape(-1))
-            else:
-                loss = (out[:, :, :3] * w_rgb[y0:y1]).sum() + (out[:, :, 3] * w_d[y0:y1]).sum()
-            loss.backward()
+            backprop([(out, w_rgb if out.shape[2] == 3 else w_rgbd)], y0, y1)
             return
         if args.forward_only:
             with torch.no_grad():
@@ -596,8 +611,8 @@ def main():
             return
         if not sharded and args.depth:           # the adapter call itself (rasterize.py:26-62)
             rgb, extras = adapter(cam, (w, h), sh)
-            # D2's loss on both outputs, (rgb * w).sum() + (depth * w_d).sum(), each as one pass over a contiguous image
-            loss = torch.dot(rgb.reshape(-1), w_rgb.reshape(-1)) + torch.dot(extras["depth"].reshape(-1), w_d.reshape(-1))
+            # D2's loss on both outputs, (rgb * w).sum() + (depth * w_d).sum()
+            backprop([(rgb, w_rgb), (extras["depth"], w_d)])
         else:
             if args.emulate_ranks > 1 and world == 1:
                 r_, ws_ = args.emulate_rank, args.emulate_ranks
@@ -605,15 +620,13 @@ def main():
                 r_, ws_ = rank, world
             out, (y0, y1), _ = render_stripe(model, cam, (w, h), dev, r_, ws_, with_depth=args.depth,
                                              collective=(world > 1 or args.force_dist))
-            # D2's loss (rgb * w).sum(); a full-range slice of a 3-channel frame would only add a zero-fill and
-            # a copy of the whole image to the backward pass
-            if out.shape[2] == 3:        # (rgb * w).sum() as one pass over the image (and one in backward)
-                loss = torch.dot(out.reshape(-1), w_rgb[y0:y1].reshape(-1))
-            else:
-                loss = (out[:, :, :3] * w_rgb[y0:y1]).sum()
-            if args.depth:
-                loss = loss + (out[:, :, 3] * w_d[y0:y1]).sum()
-        loss.backward()
+            # D2's loss (rgb * w).sum() (+ (depth * w_d).sum() on the fourth channel)
+            if out.shape[2] == 3:
+                backprop([(out, w_rgb)], y0, y1)
+            elif args.depth:
+                backprop([(out, w_rgbd)], y0, y1)
+            else:                        # a 4-channel stripe whose depth takes no part in the loss
+                (out[:, :, :3] * w_rgb[y0:y1]).sum().backward()
 
     def barrier():
         if world > 1 or args.force_dist:
@@ -704,8 +717,7 @@ def main():
             for p_ in model.parameters():
                 p_.grad = None
             rgb, extras = adapter(cam, (w, h), sh)
-            (torch.dot(rgb.reshape(-1), w_rgb.reshape(-1))
-             + torch.dot(extras["depth"].reshape(-1), w_d.reshape(-1))).backward()
+            backprop([(rgb, w_rgb), (extras["depth"], w_d)])
         for _ in range(3):
             step_rgbd()
         torch.cuda.synchronize()
@@ -929,6 +941,9 @@ def main():
                                        + (" (ALL RANKS ON ONE GPU: functional test, not a measurement)"
                                           if args.single_device else "")) if world > 1 else "single GPU",
                        "scale_mult": args.scale_mult,
+                       "upstream": ("v_out = w handed to autograd.backward (the analytic dL/d image of D2's "
+                                    "L = (rgb * w).sum()): no loss kernels inside the step" if args.upstream == "grad"
+                                    else "D2's loss evaluated by torch kernels inside the step (rounds 1-4)"),
                        "host_cpus": (f"cores of the GPU's NUMA node ({host_cpus})" if host_cpus else "not pinned"),
                        "tile_lists": {0: "16x16 (gsplat's)", 1: "32x16 lists, 32x16 waves",
                                       2: "32x16 lists (pairs of 16x16 tiles), one wave per 16x16 tile"}.get(

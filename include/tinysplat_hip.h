@@ -76,12 +76,18 @@ typedef struct ts_camera {
      * tiles than the GPU has SIMDs: instead of TS_RASTER_SPLIT_BLOCKS in the backward pass); 1..15 = a HYBRID
      * launch for full frames: the tiles are handed out in eight bands (one per XCD) and the first W16/16 of every
      * band stay whole, only the tiles dispatched last are cut, so that their small work items fill the wave slots
-     * the whole tiles leave behind at the end of the launch (ts_cut_tiles tells which). */
+     * the whole tiles leave behind at the end of the launch (ts_cut_tiles tells which).
+     * bits 16..19: C16 (TS_CAM_COOP_TILES(C16), 0..15; a pure performance hint of ts_raster_fwd*, one wave per 16x16
+     * tile on 16x16 lists) - COOPERATIVE TILES: the first C16/16 of every band, which the forward launch hands out
+     * last, are composited by a workgroup of four waves each (shared staging and sort, one 8x8 block per wave), so
+     * that the forward launch's tail is filled with items a quarter as long.  Never a cut tile (C16 is capped by
+     * W16; with S > 1 and W16 = 0 it is ignored).  Image, final_Ts, final_index: bit for bit the same. */
     int32_t hints;
 } ts_camera;
 #define TS_HINT_BALANCED_WALK 1
 #define TS_CAM_LIST_SEGMENTS(s) (((s) & 15) << 8)
 #define TS_CAM_WHOLE_TILES(w16) (((w16) & 15) << 12)
+#define TS_CAM_COOP_TILES(c16) (((c16) & 15) << 16)
 /* floats final_Ts must hold: the rows*W transmittances, then (S > 1, 16x16 lists) one checkpoint block of
  * S records of (1+channels) 256 floats per cut tile, from a 64-float aligned offset; < 0: bad argument */
 int64_t ts_final_floats(const ts_camera* cam_host, int32_t channels);

@@ -736,6 +736,76 @@ def test_hybrid_launch_cuts_only_the_last_tiles(depth, monkeypatch):
     assert int((lens[_cut_tile_mask(425, 11)] >= 65).sum()) > 100
 
 
+@pytest.mark.parametrize("n,w,h,mult,depth", [(30000, 400, 272, 2.0, False),       # lists of <= 128 entries: one wave sorts
+                                              (260000, 641, 367, 2.0, True),       # shared sort (1 / 2 / 4 keys per lane)
+                                              (60000, 200, 90, 6.0, False)])       # 78 tiles: bands of 12, most of them empty
+def test_cooperative_tiles_change_no_bit(n, w, h, mult, depth, monkeypatch):
+    """COOPERATIVE TILES (csrc/raster.hip; forced here on small frames): the tiles the forward launch hands out last are
+    composited by four waves each - shared staging and sort, one 8x8 block per wave.  Image, depth, sorted lists and
+    every gradient are bit for bit those of the launch without them, whatever the share, with and without the hybrid
+    backward launch, training forward and no_grad forward alike."""
+    from tinysplat_amd import frame
+    from tinysplat_amd.frame import render_frame
+    model, cam = scene_args(n, 1, w, h, seed=47, scale_mult=mult)
+    g = torch.Generator().manual_seed(48)
+    wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    monkeypatch.setattr(frame, "SPLIT_BLOCKS_BELOW", 0)
+    monkeypatch.setattr(frame, "HYBRID_FROM", 1)
+    monkeypatch.setattr(frame, "WIDE_TILES", 0)           # (long lists would switch the frame to wide lists: no hint there)
+    view = cam.view_matrix.to(DEV)
+    projview = (cam.proj_matrix @ cam.view_matrix).to(DEV).contiguous()
+
+    def run(c16, segs, grad=True):
+        monkeypatch.setattr(frame, "HYBRID_COOP16", c16)
+        monkeypatch.setattr(frame, "HYBRID_SEGS", segs)
+        md = model.to(DEV).requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            out, xys, _ = render_frame(md, view[:3, :].contiguous(), projview, view[:3, 3].contiguous(), cam.f_x,
+                                       cam.f_y, w, h, with_depth=depth)
+        if not grad:
+            return [out]
+        out.backward(torch.cat([wr, wd.unsqueeze(-1)], dim=-1) if depth else wr)
+        b = frame.last_binning[0]
+        assert (b.cam.hints >> 16) & 15 == c16
+        return ([out.detach(), b.gaussian_ids_sorted[:int(b.tile_bins[:, 1].max())].clone(), xys.grad]
+                + [p.grad for p in md.parameters()])
+    lens = None
+    for segs in (1, 8):
+        base = run(0, segs)
+        if lens is None:
+            tb = frame.last_binning[0].tile_bins
+            lens = (tb[:, 1] - tb[:, 0]).cpu()
+        for c16 in (1, 5, 15):
+            got = run(c16, segs)
+            for k, (a, b) in enumerate(zip(base, got)):
+                assert torch.equal(a, b), (segs, c16, k)
+    view_base = run(0, 8, grad=False)[0]
+    assert torch.equal(view_base, base[0])
+    assert torch.equal(run(15, 8, grad=False)[0], view_base)
+    if n == 260000:
+        assert int((lens > 128).sum()) > 100 and int((lens > 256).sum()) > 20 and int((lens > 512).sum()) > 0, lens.max()
+
+
+def test_cooperative_tiles_in_the_drop_in_op(monkeypatch):
+    """The drop-in op (lists sorted by ts_sort_tiles, ts_raster_fwd) on a frame of more than COOP_FROM tiles: same
+    image, alpha and gradients with and without the hint."""
+    n, w, h = 150000, 1296, 976                       # 81 x 61 = 4 941 tiles
+    model, cam = scene_args(n, 0, w, h, seed=49, scale_mult=2.0)
+    res = []
+    for c16 in (0, 4, 15):
+        monkeypatch.setattr(ops, "COOP16", c16)
+        ops.clear_binning_cache()
+        md = model.to(DEV).requires_grad_(True)
+        xys, depths, radii, conics, nth, _ = ops.project_gaussians(*project_args(md, cam, (w, h), DEV))
+        col = torch.clamp(ops.spherical_harmonics(*sh_args(md, cam, DEV)) + 0.5, min=0)
+        img, alpha = ops.rasterize_gaussians(*raster_args(md, xys, depths, radii, conics, nth, col, (w, h)))
+        (img.sum() + 0.5 * alpha.sum()).backward()
+        res.append([img.detach(), alpha.detach()] + [p.grad for p in md.parameters()])
+    for got in res[1:]:
+        for a, b in zip(res[0], got):
+            assert torch.equal(a, b)
+
+
 def test_tight_binning_stress_anisotropic_faint_and_opaque(monkeypatch):
     """Needle-like and huge Gaussians, opacities from just above 1/255 to > 0.999, centres on and off
     the image: the tight lists must still give bitwise the bounding-box result."""

@@ -202,6 +202,10 @@ using ts::kLog2_255;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
 
+// workgroup barrier that orders LDS traffic only: global loads (a prefetch) and stores of the wave stay in flight,
+// where __syncthreads() waits for all of them
+#define TS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 __device__ __forceinline__ int wave_max_int(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
@@ -562,6 +566,320 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
     }
 }
 
+// COOPERATIVE TILES (bits 16..19 of ts_camera.hints = C16; forward launch, one wave per 16x16 tile on 16x16 lists).
+// The forward launch is two rounds of ~130-us waves as well, and its items cannot be list segments (the transmittance is
+// a chain) - but a tile's list can be STAGED by four waves and its four 8x8 blocks composited by four waves: the tiles
+// that are dispatched LAST (the first C16/16 of every band; whole tiles are handed out from the band's end) become
+// workgroups of their own.  Per round of 256 list entries every wave gathers and culls 64 of them against the four
+// blocks' rectangles (stage_splat, as a whole-tile wave does per chunk) and compacts its survivors into the shared
+// record array; after a barrier wave w walks the staged entries whose mask names block w - found with ONE vector read
+// of the mask words and a ballot per source wave, then a scalar loop over the set bits - and runs the same per-pixel
+// body on one pixel per lane.  The tile's sort is shared too: four runs sorted in registers, merged by ranking every
+// key in the three other runs (binary searches in LDS; keys are unique).  Against a whole-tile wave the walk and the
+// sort are divided by four instead of replicated (which is what made TS_RASTER_SPLIT_BLOCKS cost 2.4x per tile), the
+// record of an entry is read once per BLOCK it touches instead of once (LDS bandwidth: the reason why this is not
+// the mapping of every tile), the rectangles of the unfinished pixels follow per 256 instead of per 64 entries.
+// Every pixel sees the same entries in the same order through the same arithmetic: image, final_Ts and final_index
+// are bitwise those of the whole-tile waves.
+#define TS_CAM_COOP16(cam) (((cam).hints >> 16) & 15)
+#ifndef TS_COOP
+#define TS_COOP (TS_RASTER_WAVES == 4)
+#endif
+#ifndef TS_COOP_AHEAD
+#define TS_COOP_AHEAD 4
+#endif
+constexpr int kCoopAhead = TS_COOP_AHEAD;
+struct FwdPlan {
+    int per_xcd;          // tile groups (of kWaves tiles) per band
+    int coop;             // of which composited cooperatively: groups 0 .. coop-1 of every band, one workgroup per TILE
+    bool descending;      // whole groups are handed out from the band's end (the cut tiles of a hybrid launch first)
+    __host__ __device__ int grid() const { return 8 * (per_xcd + (kWaves - 1) * coop); }
+};
+// segs: the launch keeps boundary state (the SEGS instantiations with S > 1)
+__host__ __device__ __forceinline__ FwdPlan fwd_plan(int num_tiles, int hints, bool segs, bool coop_ok) {
+    FwdPlan p;
+    const int groups = (num_tiles + kWaves - 1) / kWaves;
+    p.per_xcd = (groups + 7) >> 3;
+    const int w16 = (hints >> 12) & 15, c16 = (hints >> 16) & 15;
+    p.coop = (TS_COOP && coop_ok) ? (p.per_xcd * c16) / 16 : 0;
+    if (segs) {
+        const CutTiles m = cut_tiles(num_tiles, hints);       // (band = kWaves * per_xcd tiles for kWaves == 4)
+        p.coop = w16 > 0 ? min(p.coop, m.whole / kWaves) : 0;   // a cut tile keeps its boundary state: whole-tile wave
+    }
+    p.descending = (segs && TS_FWD_CUT_FIRST && w16 > 0) || p.coop > 0;
+    return p;
+}
+
+// the per-pixel body of fwd_chunk on ONE pixel per lane (same operations in the same order: identical bits)
+template <int CH, bool GENERAL>
+__device__ __forceinline__ void fwd_body1(const float4 r0, const float4 r1, const float4 r2, float fpx, float fpy,
+                                          float& T, int& fidx, float (&acc)[CH]) {
+#pragma clang fp contract(off)
+    const int idx = __float_as_int(r2.z);
+    const float neg_lo = -r1.y;
+    float col[CH];
+    col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
+    if (CH == 4) col[CH - 1] = r2.y;
+    const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx, r0.y - fpy);
+    float a = __builtin_amdgcn_exp2f(-sgl);
+    float ae = a >= ts::kAlphaMin ? a : 0.0f;
+    if (GENERAL) {
+        ae = fminf(ts::kAlphaMax, ae);
+        ae = sgl >= neg_lo ? ae : 0.0f;
+    }
+    const float nT = __builtin_fmaf(-ae, T, T);
+    const float Tn = nT <= ts::kTEps ? -__builtin_fabsf(T) : nT;
+    const float vis = __builtin_fabsf(T) - __builtin_fabsf(Tn);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = __builtin_fmaf(col[c], vis, acc[c]);
+    fidx = vis > 0.0f ? idx : fidx;
+    T = Tn;
+}
+
+// one sorted run of a cooperative tile's list: n_run <= 64 E keys of g[] sorted in registers, position lane * E + e
+template <int E>
+__device__ __forceinline__ void coop_sort_run(const int* __restrict__ g, const float* __restrict__ depths, int n_run,
+                                              int lane, unsigned long long (&k)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        k[e] = i < n_run ? make_key(depths, g[i]) : ~0ull;
+    }
+    // (key i starts at network position (i % 64) * E + i / 64: with E > 1 the whole network must run, whatever n_run -
+    // a run can be shorter than 32 E + 1 keys, which sort_tile_wave's choice of E rules out)
+    bitonic_regs<E, 64>(k, lane, E == 1 ? min(pow2_at_least(max(n_run, 1)), 64) : 64 * E, nullptr);
+}
+// ... and its merge with the three other runs: rank of a key = its position in its own run + the keys below it in the
+// others.  keys: [4][256] in LDS, run v holds nv(v) keys (the rest is padding that is never ranked).
+template <int E>
+__device__ __forceinline__ void coop_sort_tile(const int* __restrict__ g, const float* __restrict__ depths,
+                                               int* __restrict__ out, int* ids_l, int n, int wave, int lane,
+                                               unsigned long long* keys) {
+    const int q = (n + 3) >> 2;                              // run length (the last runs may be shorter or empty)
+    const int n_own = max(0, min(q, n - wave * q));
+    unsigned long long k[E];
+    coop_sort_run<E>(g + wave * q, depths, n_own, lane, k);
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[wave * 256 + lane * E + e] = k[e];
+    TS_LDS_BARRIER();
+    // branch-free lower bounds with power-of-two steps, the 3 E searches of a lane in lockstep: every step has all its
+    // LDS reads in flight together (one after the other they were ~50 dependent round trips per lane)
+    int lo[E][3], len[3];
+#pragma unroll
+    for (int dv = 0; dv < 3; ++dv) len[dv] = max(0, min(q, n - ((wave + dv + 1) & 3) * q));
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int dv = 0; dv < 3; ++dv) lo[e][dv] = 0;
+#pragma unroll
+    for (int step = 64 * E; step >= 1; step >>= 1) {             // runs hold at most 64 E keys (a key may lie above all of them)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+#pragma unroll
+            for (int dv = 0; dv < 3; ++dv) {
+                const unsigned long long* run = keys + ((wave + dv + 1) & 3) * 256;
+                const int p = lo[e][dv] + step;
+                // (p - 1 <= 64 E - 1 lies inside the run's 256 slots; beyond its length the slot holds padding or
+                // stale keys, which the length test rules out)
+                if (p <= len[dv] && run[p - 1] < k[e]) lo[e][dv] = p;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int p = lane * E + e;
+        if (p < n_own) {
+            const int rank = p + lo[e][0] + lo[e][1] + lo[e][2];
+            out[rank] = (int)(unsigned int)k[e];            // for the backward pass
+            ids_l[rank] = (int)(unsigned int)k[e];          // for this workgroup's own walk
+        }
+    }
+}
+
+// One 16x16 tile composited by the four waves of a workgroup (see COOPERATIVE TILES).  rec: 256 x 3 float4 staged
+// records (the whole-tile waves' lds_all), also the key array of the shared sort; rect_sh[4]: rectangle of the
+// unfinished pixels of block k; cnt_sh[4]: entries wave s staged in this round; alive_sh[4]: block k has unfinished pixels.
+template <int CH, bool SORT>
+__device__ __forceinline__ void coop_fwd_tile(
+    const ts_camera& cam, int tile, const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
+    const int* __restrict__ bucket_ids, const float* __restrict__ depths, int* ids_rw,
+    const float4* __restrict__ splats, const float* __restrict__ background, float* __restrict__ out_img,
+    float* __restrict__ out_depth, float* __restrict__ final_Ts, int* __restrict__ final_index, int clamp_rgb,
+    unsigned char* __restrict__ clamp_mask, float4* rec, float4* rect_sh, int* cnt_sh, int* alive_sh, int clock_unit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tbx = cam.tile_bounds_x;
+    const int tx = tile % tbx, ty = tile / tbx + cam.tile_row0;
+    const int px = tx * 16 + 8 * (wave & 1) + (lane & 7), py = ty * 16 + 8 * (wave >> 1) + (lane >> 3);
+    const float fpx = (float)px + ts::kPixOff, fpy = (float)py + ts::kPixOff;
+    const float BX0 = (float)(tx * 16 + 8 * (wave & 1)) + ts::kPixOff, BY0 = (float)(ty * 16 + 8 * (wave >> 1)) + ts::kPixOff;
+    const int W = cam.img_width, H = cam.img_height;
+    const bool inside = px < W && py < H;
+    float T = inside ? 1.0f : -1.0f, acc[CH];
+    int fidx = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
+    const int2 range = reinterpret_cast<const int2*>(tile_bins)[tile];
+    const int n = range.y - range.x;
+    TS_WAVE_CLOCK(0, clock_unit + wave, n);          // (timeline builds: the cooperative waves follow the tiles' rows)
+    (void)clock_unit;
+
+    // rectangle of this wave's unfinished pixels -> LDS (read by the four staging waves after the next barrier)
+    auto publish = [&]() {
+        const unsigned long long m = __ballot(T > 0.0f);
+        int xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+        const bool any = mask_rect(m, xmin, xmax, ymin, ymax);
+        if (lane == 0) {
+            alive_sh[wave] = any ? 1 : 0;
+            if (any) rect_sh[wave] = make_float4(BX0 + (float)xmin, BX0 + (float)xmax, BY0 + (float)ymin, BY0 + (float)ymax);
+        }
+    };
+    publish();
+
+    int idr[4] = {0, 0, 0, 0};               // shared sort: this lane's ids of rounds 0 .. 3
+    bool from_lds = false;
+    TS_SEG_T0(tseg_s);
+    if (SORT && n > 0 && n <= kWaveSortMax) {
+        const int* g = bucket_ids + range.x;
+        int* out = ids_rw + range.x;
+        if (n <= 128) {                       // short list: one wave's network, the others wait
+            if (wave == 0) {
+                if (n <= 64) sort_tile_wave<1>(g, depths, out, n, lane);
+                else sort_tile_wave<2>(g, depths, out, n, lane);
+            }
+        } else {
+            unsigned long long* keys = reinterpret_cast<unsigned long long*>(rec);
+            int* ids_l = reinterpret_cast<int*>(rec) + 2048;          // 8 KiB of keys, then 4 KiB of sorted ids
+            if (n <= 256) coop_sort_tile<1>(g, depths, out, ids_l, n, wave, lane, keys);
+            else if (n <= 512) coop_sort_tile<2>(g, depths, out, ids_l, n, wave, lane, keys);
+            else coop_sort_tile<4>(g, depths, out, ids_l, n, wave, lane, keys);
+        }
+        if (n <= 128) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the list is read back by other waves
+            __syncthreads();
+        } else {
+            // the shared sort left the sorted ids in LDS as well (behind the keys): every lane takes the ids of its
+            // entries of all (<= 4) rounds from there - no wait for the global stores, no round trip through memory
+            TS_LDS_BARRIER();
+            const int* ids_l = reinterpret_cast<const int*>(rec) + 2048;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 256 * r + 64 * wave + lane;
+                if (i < n) idr[r] = ids_l[i];
+            }
+            from_lds = true;
+        }
+    }
+    TS_SEG_ADD(ts_wave_clock_.seg, 3, tseg_s);
+    const int* ids = SORT ? ids_rw : ids_sorted;
+
+    // software pipeline over rounds of 256 entries: this wave stages entries base + 64 wave + lane
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    int id_next = 0;
+    {
+        const int i0 = range.x + 64 * wave + lane;
+        if (i0 < range.y) {
+            const int g = from_lds ? idr[0] : ids[i0];
+            n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+        }
+        if (i0 + 256 < range.y) id_next = from_lds ? idr[1] : ids[i0 + 256];
+    }
+    int round = 0;
+    for (int base = range.x; base < range.y; base += 256) {
+        TS_SEG_T0(tseg_w0);
+        TS_LDS_BARRIER();                     // rectangles / alive flags of the last round are in LDS, rec[] is free
+        TS_SEG_ADD(ts_wave_clock_.seg, 1, tseg_w0);
+        TS_SEG_T0(tseg_p);
+        const int live = (alive_sh[0] ? 1 : 0) | (alive_sh[1] ? 2 : 0) | (alive_sh[2] ? 4 : 0) | (alive_sh[3] ? 8 : 0);
+        if (live == 0) break;                 // (the same value in all four waves)
+        const int i = base + 64 * wave + lane;
+        const bool have = i < range.y;
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        if (i + 256 < range.y) {
+            const int g = id_next;
+            n0 = splats[3 * (size_t)g]; n1 = splats[3 * (size_t)g + 1]; n2 = splats[3 * (size_t)g + 2];
+        }
+        if (i + 512 < range.y) id_next = from_lds ? (round == 0 ? idr[2] : idr[3]) : ids[i + 512];
+        ++round;
+        Staged s = stage_splat<4>(have, q0, q1, rect_sh, live);
+        const bool keep = (s.mask & 15) != 0;
+        const unsigned long long kmask = __ballot(keep);
+        if (keep) {
+            const int pos = 64 * wave + __popcll(kmask & ((1ull << lane) - 1ull));
+            rec[3 * pos] = make_float4(s.gx, s.gy, s.hA, s.B);
+            rec[3 * pos + 1] = make_float4(s.hC, s.lo, q1.z, q1.w);
+            rec[3 * pos + 2] = make_float4(q2.x, q2.y, __int_as_float(i), __int_as_float(s.mask));
+        }
+        if (lane == 0) cnt_sh[wave] = __popcll(kmask);
+        TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
+        TS_SEG_T0(tseg_w1);
+        TS_LDS_BARRIER();
+        TS_SEG_ADD(ts_wave_clock_.seg, 1, tseg_w1);
+        TS_SEG_T0(tseg_b);
+        // block `wave`: the staged entries of the four source waves in list order
+#pragma unroll 1
+        for (int src = 0; src < 4; ++src) {
+            const int c = cnt_sh[src];
+            const float4* rs = rec + 3 * 64 * src;
+            const int m = lane < c ? __float_as_int(rs[3 * lane + 2].w) : 0;
+            unsigned long long bits = __ballot(((m >> wave) & 1) != 0);
+            if (bits == 0ull) continue;
+            const bool general = __ballot(((m >> wave) & 1) != 0 && (m & 16) != 0) != 0ull;
+            // one loop per variant (the choice is made once per source chunk, as a whole-tile wave makes it per chunk)
+            auto run = [&](auto gen_tag) {
+                constexpr bool G = decltype(gen_tag)::value;
+                // the records of up to kCoopAhead entries are requested together: one LDS round trip per group, not
+                // one per body (a wave has ONE pixel per lane here: nothing else of its own to overlap the wait with)
+                while (bits != 0ull) {
+                    float4 r0[kCoopAhead], r1[kCoopAhead], r2[kCoopAhead];
+                    int got = 0;
+#pragma unroll
+                    for (int u = 0; u < kCoopAhead; ++u) {
+                        if (bits != 0ull) {
+                            const int j = __builtin_ctzll(bits);
+                            bits &= bits - 1ull;
+                            r0[u] = rs[3 * j]; r1[u] = rs[3 * j + 1]; r2[u] = rs[3 * j + 2];
+                            got = u + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kCoopAhead; ++u)
+                        if (u < got) fwd_body1<CH, G>(r0[u], r1[u], r2[u], fpx, fpy, T, fidx, acc);
+                }
+            };
+            if (general) run(std::true_type{});
+            else run(std::false_type{});
+        }
+        publish();
+        TS_SEG_ADD(ts_wave_clock_.seg, 2, tseg_b);
+    }
+
+    if (!inside) return;
+    float bg[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) bg[c] = background[c];
+    const size_t pix = (size_t)(py - cam.tile_row0 * 16) * W + px;
+    const float Tf = __builtin_fabsf(T);
+    if (final_Ts) {
+        final_Ts[pix] = Tf;
+        final_index[pix] = fidx;
+    }
+    const bool planes = CH == 4 && out_depth != nullptr;
+    float* o = out_img + pix * (planes ? 3 : CH);
+    int pass = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float val = acc[c] + Tf * bg[c];
+        if (clamp_rgb && c < 3) {
+            pass |= (val <= 1.0f) ? (1 << c) : 0;
+            val = fminf(val, 1.0f);
+        }
+        if (c == 3 && planes) out_depth[pix] = val;
+        else o[c] = val;
+    }
+    if (clamp_mask) clamp_mask[pix] = (unsigned char)pass;
+}
+
 // Pixel layout of a wave: lane l -> (lx, ly) = (l & 7, l >> 3) inside an 8x8 block; the lane owns
 // that position in each of the four blocks k of the 16x16 tile.
 // SPLIT: four waves per tile, each owning ONE 8x8 block (the other three count as outside the image).
@@ -592,11 +910,28 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int units = SPLIT ? NB * num_tiles : num_tiles;
     int unit = xcd_tile_group((units + kWaves - 1) / kWaves) * kWaves + wave;
-    if (SEGS && !SPLIT && TS_FWD_CUT_FIRST && TS_CAM_WHOLE16(cam) > 0) {
+    constexpr bool kCoop = TS_COOP && !SPLIT && NBX == 2 && !WL;
+    if constexpr (!SPLIT && NBX == 2 && !WL) {
         // hybrid launch: the cut tiles of a band - the ones that also keep their boundary state, the longest items of
-        // this launch - are handed out FIRST here (the backward launch hands them out last, as small items)
-        const int per_xcd = ((units + kWaves - 1) / kWaves + 7) >> 3;
-        unit = ((int)(blockIdx.x & 7) * per_xcd + (per_xcd - 1 - (int)(blockIdx.x >> 3))) * kWaves + wave;
+        // this launch - are handed out FIRST here (the backward launch hands them out last, as small items); the
+        // tiles handed out last are composited by a workgroup each (COOPERATIVE TILES)
+        const FwdPlan pl = fwd_plan(num_tiles, cam.hints, SEGS && final_Ts != nullptr && TS_CAM_SEGS(cam) > 1, kCoop);
+        const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+        if (slot < pl.per_xcd - pl.coop) {
+            if (pl.descending) unit = (xcd * pl.per_xcd + (pl.per_xcd - 1 - slot)) * kWaves + wave;
+        } else if constexpr (kCoop) {
+            const int t = slot - (pl.per_xcd - pl.coop);                 // 0 .. kWaves * coop - 1
+            const int ctile = xcd * pl.per_xcd * kWaves + (kWaves * pl.coop - 1 - t);
+            if (ctile >= num_tiles) return;
+            __shared__ int coop_cnt[4], coop_alive[4];
+            coop_fwd_tile<CH, SORT>(cam, ctile, tile_bins, ids_sorted, bucket_ids, depths, ids_rw, splats, background,
+                                    out_img, out_depth, final_Ts, final_index, clamp_rgb, clamp_mask, &lds_all[0][0],
+                                    &rect_all[0][0], coop_cnt, coop_alive,
+                                    num_tiles + kWaves * (xcd * kWaves * pl.coop + t));
+            return;
+        } else {
+            return;
+        }
     }
     if (unit >= units) return;
     const int tile = SPLIT ? unit / NB : unit;
@@ -1543,12 +1878,13 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
     const bool wide = cam->wide_tiles != 0 && !narrow;
     const int units = split ? (wide ? 8 : 4) * nt : nt;
-    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
+    int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
     // list segments (ts_camera.hints bits 8..11): a launch on 16x16 lists also keeps the boundary state of the cut tiles
     const bool segs = !wide && !narrow && final_Ts && TS_CAM_SEGS(*cam) > 1;
+    if (!split && !wide && !narrow) grid = fwd_plan(nt, cam->hints, segs, true).grid();      // COOPERATIVE TILES
 #define TS_LAUNCH_FWD(C, S, X, L, G)                                                               \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L, false, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, gaussian_ids_sorted, (const int*)nullptr, (const float*)nullptr,   \
@@ -1582,11 +1918,12 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
         return TS_E_BADARG;
     const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
     const int units = split ? 4 * nt : nt;
-    const int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
+    int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
     const bool segs = final_Ts && TS_CAM_SEGS(*cam) > 1;                // list segments: see ts_raster_fwd_planes
+    if (!split) grid = fwd_plan(nt, cam->hints, segs, true).grid();     // COOPERATIVE TILES
 #define TS_LAUNCH_FWD_SORT(C, S, G)                                                                            \
     hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
                        tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background, \

@@ -75,6 +75,11 @@ LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
 HYBRID_FROM = int(os.environ.get("TS_HYBRID_FROM", "4096"))
 HYBRID_SEGS = max(1, min(8, int(os.environ.get("TS_HYBRID_SEGS", "8"))))
 HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
+# COOPERATIVE TILES (bits 16..19 of ts_camera.hints, csrc/raster.hip: COOPERATIVE TILES): the FORWARD launch of such a
+# frame hands the first HYBRID_COOP16 / 16 of every band - the tiles it dispatches last - to a workgroup of four waves
+# each (shared staging and sort, one 8x8 block per wave) instead of one wave, so that the launch's own tail is filled
+# with items a quarter as long.  Same image, final_Ts and final_index, bit for bit.  0 switches it off.
+HYBRID_COOP16 = max(0, min(15, int(os.environ.get("TS_HYBRID_COOP16", "3"))))
 
 
 def _list_segments(tiles16: int, mode: int, split: bool):
@@ -301,6 +306,8 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     m = max(n, 1)
     segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
     cam.hints = (cam.hints & ~0xFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
+    if mode == 0 and not F.split and cam.tile_rows * cam.tile_bounds_x >= HYBRID_FROM:
+        cam.hints |= HYBRID_COOP16 << 16
     F.segs = segs
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()

@@ -13,6 +13,7 @@ missing libtinysplat_hip.so raises at the first call.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -20,6 +21,12 @@ from torch import Tensor
 
 from . import _lib
 from ._lib import TsCamera
+
+# COOPERATIVE TILES (csrc/raster.hip; ts_camera.hints bits 16..19): a forward compositing launch of at least COOP_FROM
+# 16x16 tiles hands the COOP16 / 16 of every band that it dispatches last to workgroups of four waves.  Results do
+# not depend on it (frame.py holds the frame path's copy of the two knobs).
+COOP_FROM = int(os.environ.get("TS_HYBRID_FROM", "4096"))
+COOP16 = max(0, min(15, int(os.environ.get("TS_HYBRID_COOP16", "3"))))
 
 BLOCK = 16            # rasterize.py:19-20
 CLIP_THRESH = 0.01    # gsplat's default near-plane threshold for project_gaussians
@@ -383,6 +390,8 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Ten
     radii_c, nth_c = _i32c(radii), _i32c(num_tiles_hit)
     tb = _tile_bounds(img_height, img_width)
     cam = _camera(0.0, 0.0, 0.0, 0.0, img_height, img_width, tb, tile_rows=tile_rows)
+    if cam.tile_rows * cam.tile_bounds_x >= COOP_FROM:      # COOPERATIVE TILES of the forward launch (a pure hint)
+        cam.hints |= COOP16 << 16
     key = (dev.index, int(img_height), int(img_width), cam.tile_row0, cam.tile_rows)
     if use_cache:
         hit = _bin_cache.get(dev.index)

@@ -38,11 +38,12 @@ tiles = int(frame.last_binning[0].num_tiles)
 saved = {}
 for which, name in ((0, "raster_fwd"), (1, "raster_bwd")):
     ROW = 12
-    rows_ = tiles if which == 0 else 1 << 17           # backward: a hybrid launch has more work items than tiles
+    rows_ = 1 << 17           # a hybrid launch has more work items than tiles (backward: list segments; forward: cooperative waves)
     buf = (ctypes.c_ulonglong * (ROW * rows_))()
     rc = lib.ts_debug_timeline(buf, which, rows_)
     assert rc == 0, rc
     a = np.frombuffer(buf, dtype=np.uint64).reshape(rows_, ROW)
+    is_coop = (np.arange(rows_) >= tiles)[a[:, 1] > 0] if which == 0 else None
     a = a[a[:, 1] > 0]
     seg = a[:, 4:8].astype(np.float64)
     tot = a[:, 8].astype(np.float64)
@@ -94,6 +95,14 @@ for which, name in ((0, "raster_fwd"), (1, "raster_bwd")):
     # duration of a wave against the number of waves started at the same time on its SIMD (first round only)
     first = t0 < 0.05 * span
     print(f"   first-round waves: {first.sum()}, mean duration {dur[first].mean():.1f} us; later waves: mean {dur[~first].mean():.1f} us")
+    if which == 0 and is_coop is not None and is_coop.any():
+        dc, dw = dur[is_coop], dur[~is_coop]
+        print(f"   whole-tile waves: {len(dw)}, mean {dw.mean():.1f} us, sum {dw.sum() / 1e3:.1f} ms | cooperative waves: {len(dc)} "
+              f"({len(dc) // 4} tiles), mean {dc.mean():.1f} us p95 {np.percentile(dc, 95):.1f}, sum {dc.sum() / 1e3:.1f} ms; "
+              f"first cooperative wave starts at {t0[is_coop].min():.1f} us, last whole-tile wave ends at {t1[~is_coop].max():.1f} us")
+        sc, tc = seg[is_coop], tot[is_coop]
+        print("   cooperative waves, share of their cycles: staging %.1f %%, barrier waits %.1f %%, bodies + record reads %.1f %%, "
+              "shared sort %.1f %%, rest %.1f %%" % tuple(list(sc.sum(axis=0) / tc.sum() * 100) + [100 - sc.sum() / tc.sum() * 100]))
     waves_per_simd = np.bincount(np.unique(slot, return_inverse=True)[1])
     print(f"   waves per SIMD: min {waves_per_simd.min()} mean {waves_per_simd.mean():.2f} max {waves_per_simd.max()}")
     busy_end = np.zeros(nsimd)

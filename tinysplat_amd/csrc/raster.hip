@@ -61,6 +61,9 @@ namespace {
 #ifndef TS_BWD_MIN_WAVES
 #define TS_BWD_MIN_WAVES 1
 #endif
+#ifndef TS_BWD_MIN_WAVES_16
+#define TS_BWD_MIN_WAVES_16 5          // the 16x16 backward kernels at five waves per SIMD (96 VGPRs: 5 - 11 dwords spilled at
+#endif                                 // chunk level with TS_LDS_DMA; they took 107 / 115).  Round 5: raster_bwd 465 -> 450 us
 
 #ifndef TS_ABLATE
 #define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0)
@@ -154,7 +157,7 @@ struct WaveClock {
 // (global_load_lds_dwordx4: 16 bytes per lane to base + lane * 16) instead of through twelve VGPRs that stay live
 // across the whole chunk - the registers that kept raster_bwd at four and raster_fwd at five waves per SIMD.
 #ifndef TS_LDS_DMA
-#define TS_LDS_DMA 0
+#define TS_LDS_DMA 1                   // (round 4: no gain on its own; round 5: what lets raster_bwd fit five waves per SIMD)
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -1469,7 +1472,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
 #endif
 constexpr int kBwdWaves = TS_BWD_WAVES;
 template <int CH, bool SPLIT, int NBX, bool WL>
-__global__ __launch_bounds__(64 * kBwdWaves, TS_BWD_MIN_WAVES) void raster_bwd_kernel(
+__global__ __launch_bounds__(64 * kBwdWaves, NBX == 2 ? TS_BWD_MIN_WAVES_16 : TS_BWD_MIN_WAVES) void raster_bwd_kernel(
     const ts_camera cam, const int num_tiles, const long long num_isects,
     const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
     const float4* __restrict__ splats, const float* __restrict__ background,

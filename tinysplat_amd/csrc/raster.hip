@@ -592,10 +592,20 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 #define TS_COOP_AHEAD 4
 #endif
 constexpr int kCoopAhead = TS_COOP_AHEAD;
+// TS_SEGS_COOP=1 (measured, not the default): in a launch that keeps boundary state (hybrid launch, S > 1) the CUT tiles
+// are the cooperative ones - a cooperative wave has one pixel per lane, so the per-segment colour sums are three
+// registers there, where they are twelve (spilled at the five-wave budget) in the whole-tile waves of such a launch;
+// C16 is ignored then.  The whole-tile waves lose their spills (96 VGPRs + 92 bytes -> 94), but the boundary records
+// and the three extra FMAs per body then sit in the items that END the launch instead of the ones that start it:
+// raster_fwd 290 -> 300 us on config 3.
+#ifndef TS_SEGS_COOP
+#define TS_SEGS_COOP 0
+#endif
+constexpr bool kSegsCoop = TS_SEGS_COOP && TS_COOP;
 struct FwdPlan {
     int per_xcd;          // tile groups (of kWaves tiles) per band
-    int coop;             // of which composited cooperatively: groups 0 .. coop-1 of every band, one workgroup per TILE
-    bool descending;      // whole groups are handed out from the band's end (the cut tiles of a hybrid launch first)
+    int coop, coop_lo;    // groups coop_lo .. coop_lo + coop - 1 of every band: one workgroup per TILE, handed out last
+    bool descending;      // groups (and cooperative tiles) are handed out from the band's end: the cut tiles first
     __host__ __device__ int grid() const { return 8 * (per_xcd + (kWaves - 1) * coop); }
 };
 // segs: the launch keeps boundary state (the SEGS instantiations with S > 1)
@@ -604,19 +614,24 @@ __host__ __device__ __forceinline__ FwdPlan fwd_plan(int num_tiles, int hints, b
     const int groups = (num_tiles + kWaves - 1) / kWaves;
     p.per_xcd = (groups + 7) >> 3;
     const int w16 = (hints >> 12) & 15, c16 = (hints >> 16) & 15;
-    p.coop = (TS_COOP && coop_ok) ? (p.per_xcd * c16) / 16 : 0;
-    if (segs) {
-        const CutTiles m = cut_tiles(num_tiles, hints);       // (band = kWaves * per_xcd tiles for kWaves == 4)
-        p.coop = w16 > 0 ? min(p.coop, m.whole / kWaves) : 0;   // a cut tile keeps its boundary state: whole-tile wave
+    const CutTiles m = cut_tiles(num_tiles, hints);           // (band = kWaves * per_xcd tiles for kWaves == 4)
+    if (segs && kSegsCoop && coop_ok) {
+        p.coop = (m.band - m.whole) / kWaves;                 // W16 = 0: every tile is cut
+        p.coop_lo = m.whole / kWaves;
+        p.descending = false;
+        return p;
     }
+    p.coop = (TS_COOP && coop_ok) ? (p.per_xcd * c16) / 16 : 0;
+    if (segs) p.coop = w16 > 0 ? min(p.coop, m.whole / kWaves) : 0;     // a cut tile keeps its boundary state: whole-tile wave
+    p.coop_lo = 0;
     p.descending = (segs && TS_FWD_CUT_FIRST && w16 > 0) || p.coop > 0;
     return p;
 }
 
 // the per-pixel body of fwd_chunk on ONE pixel per lane (same operations in the same order: identical bits)
-template <int CH, bool GENERAL>
+template <int CH, bool GENERAL, bool LOC>
 __device__ __forceinline__ void fwd_body1(const float4 r0, const float4 r1, const float4 r2, float fpx, float fpy,
-                                          float& T, int& fidx, float (&acc)[CH]) {
+                                          float& T, int& fidx, float (&acc)[CH], float (&loc)[CH]) {
 #pragma clang fp contract(off)
     const int idx = __float_as_int(r2.z);
     const float neg_lo = -r1.y;
@@ -635,6 +650,10 @@ __device__ __forceinline__ void fwd_body1(const float4 r0, const float4 r1, cons
     const float vis = __builtin_fabsf(T) - __builtin_fabsf(Tn);
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = __builtin_fmaf(col[c], vis, acc[c]);
+    if (LOC) {          // the same contribution summed per list segment (LIST SEGMENTS)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) loc[c] = __builtin_fmaf(col[c], vis, loc[c]);
+    }
     fidx = vis > 0.0f ? idx : fidx;
     T = Tn;
 }
@@ -702,9 +721,9 @@ __device__ __forceinline__ void coop_sort_tile(const int* __restrict__ g, const 
 // One 16x16 tile composited by the four waves of a workgroup (see COOPERATIVE TILES).  rec: 256 x 3 float4 staged
 // records (the whole-tile waves' lds_all), also the key array of the shared sort; rect_sh[4]: rectangle of the
 // unfinished pixels of block k; cnt_sh[4]: entries wave s staged in this round; alive_sh[4]: block k has unfinished pixels.
-template <int CH, bool SORT>
+template <int CH, bool SORT, bool SEGS>
 __device__ __forceinline__ void coop_fwd_tile(
-    const ts_camera& cam, int tile, const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
+    const ts_camera& cam, int tile, int num_tiles, const int* __restrict__ tile_bins, const int* __restrict__ ids_sorted,
     const int* __restrict__ bucket_ids, const float* __restrict__ depths, int* ids_rw,
     const float4* __restrict__ splats, const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ out_depth, float* __restrict__ final_Ts, int* __restrict__ final_index, int clamp_rgb,
@@ -725,6 +744,24 @@ __device__ __forceinline__ void coop_fwd_tile(
     const int n = range.y - range.x;
     TS_WAVE_CLOCK(0, clock_unit + wave, n);          // (timeline builds: the cooperative waves follow the tiles' rows)
     (void)clock_unit;
+
+    // list segments: a cut tile's boundary records (CHECKPOINTS), block `wave` of every record by this wave
+    const int S_seg = max(1, min(TS_CAM_SEGS(cam), kSegMax));
+    int ck_block = -1;
+    if (SEGS && final_Ts != nullptr && S_seg > 1 && n >= kSegMinList) ck_block = cut_tiles(num_tiles, cam.hints).block_of(tile);
+    const bool seg_on = SEGS && ck_block >= 0;
+    float* ckp = nullptr;
+    if (seg_on) ckp = final_Ts + ckpt_offset(seg_plane_stride(cam)) + ckpt_record<CH>(ck_block, S_seg, 1);
+    int next_ck = seg_on ? range.x + seg_bound(n, S_seg, 1) : 0x7fffffff;       // list index of the next boundary
+    int ck = 1;                                                                 // its number (1 .. S-1)
+    float loc[CH];                              // colour the entries of the CURRENT segment contributed to this pixel
+#pragma unroll
+    for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
+    auto store_ck = [&](int number) {
+        ckpt_store<CH>(ckp + (number - 1) * ((1 + CH) * 256), wave, lane, __builtin_fabsf(T), loc);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) loc[c] = 0.0f;
+    };
 
     // rectangle of this wave's unfinished pixels -> LDS (read by the four staging waves after the next barrier)
     auto publish = [&]() {
@@ -822,6 +859,11 @@ __device__ __forceinline__ void coop_fwd_tile(
         // block `wave`: the staged entries of the four source waves in list order
 #pragma unroll 1
         for (int src = 0; src < 4; ++src) {
+            if (SEGS && base + 64 * src == next_ck) {     // a segment boundary (never the list's first entry)
+                store_ck(ck);
+                ++ck;
+                next_ck = ck < S_seg ? range.x + seg_bound(n, S_seg, ck) : 0x7fffffff;
+            }
             const int c = cnt_sh[src];
             const float4* rs = rec + 3 * 64 * src;
             const int m = lane < c ? __float_as_int(rs[3 * lane + 2].w) : 0;
@@ -829,8 +871,8 @@ __device__ __forceinline__ void coop_fwd_tile(
             if (bits == 0ull) continue;
             const bool general = __ballot(((m >> wave) & 1) != 0 && (m & 16) != 0) != 0ull;
             // one loop per variant (the choice is made once per source chunk, as a whole-tile wave makes it per chunk)
-            auto run = [&](auto gen_tag) {
-                constexpr bool G = decltype(gen_tag)::value;
+            auto run = [&](auto gen_tag, auto loc_tag) {
+                constexpr bool G = decltype(gen_tag)::value, L = decltype(loc_tag)::value;
                 // the records of up to kCoopAhead entries are requested together: one LDS round trip per group, not
                 // one per body (a wave has ONE pixel per lane here: nothing else of its own to overlap the wait with)
                 while (bits != 0ull) {
@@ -847,16 +889,28 @@ __device__ __forceinline__ void coop_fwd_tile(
                     }
 #pragma unroll
                     for (int u = 0; u < kCoopAhead; ++u)
-                        if (u < got) fwd_body1<CH, G>(r0[u], r1[u], r2[u], fpx, fpy, T, fidx, acc);
+                        if (u < got) fwd_body1<CH, G, L>(r0[u], r1[u], r2[u], fpx, fpy, T, fidx, acc, loc);
                 }
             };
-            if (general) run(std::true_type{});
-            else run(std::false_type{});
+            if (SEGS && seg_on) {
+                if (general) run(std::true_type{}, std::true_type{});
+                else run(std::false_type{}, std::true_type{});
+            } else {
+                if (general) run(std::true_type{}, std::false_type{});
+                else run(std::false_type{}, std::false_type{});
+            }
         }
         publish();
         TS_SEG_ADD(ts_wave_clock_.seg, 2, tseg_b);
     }
 
+    if (SEGS && seg_on) {
+        // the pass ended in segment ck - 1: its colour goes into record ck; the records behind hold no colour (see the
+        // whole-tile waves of the split launches)
+        store_ck(ck);
+#pragma unroll 1
+        for (int r = ck + 1; r <= S_seg; ++r) store_ck(r);
+    }
     if (!inside) return;
     float bg[CH];
 #pragma unroll
@@ -917,20 +971,21 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
     if constexpr (!SPLIT && NBX == 2 && !WL) {
         // hybrid launch: the cut tiles of a band - the ones that also keep their boundary state, the longest items of
         // this launch - are handed out FIRST here (the backward launch hands them out last, as small items); the
-        // tiles handed out last are composited by a workgroup each (COOPERATIVE TILES)
+        // tiles handed out last - C16 / 16 of a band from its start - are composited by a workgroup each (COOPERATIVE
+        // TILES; TS_SEGS_COOP=1: the cut tiles themselves)
         const FwdPlan pl = fwd_plan(num_tiles, cam.hints, SEGS && final_Ts != nullptr && TS_CAM_SEGS(cam) > 1, kCoop);
         const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
         if (slot < pl.per_xcd - pl.coop) {
             if (pl.descending) unit = (xcd * pl.per_xcd + (pl.per_xcd - 1 - slot)) * kWaves + wave;
         } else if constexpr (kCoop) {
             const int t = slot - (pl.per_xcd - pl.coop);                 // 0 .. kWaves * coop - 1
-            const int ctile = xcd * pl.per_xcd * kWaves + (kWaves * pl.coop - 1 - t);
+            const int ctile = (xcd * pl.per_xcd + pl.coop_lo) * kWaves + (pl.descending ? kWaves * pl.coop - 1 - t : t);
             if (ctile >= num_tiles) return;
             __shared__ int coop_cnt[4], coop_alive[4];
-            coop_fwd_tile<CH, SORT>(cam, ctile, tile_bins, ids_sorted, bucket_ids, depths, ids_rw, splats, background,
-                                    out_img, out_depth, final_Ts, final_index, clamp_rgb, clamp_mask, &lds_all[0][0],
-                                    &rect_all[0][0], coop_cnt, coop_alive,
-                                    num_tiles + kWaves * (xcd * kWaves * pl.coop + t));
+            coop_fwd_tile<CH, SORT, SEGS>(cam, ctile, num_tiles, tile_bins, ids_sorted, bucket_ids, depths, ids_rw, splats,
+                                          background, out_img, out_depth, final_Ts, final_index, clamp_rgb, clamp_mask,
+                                          &lds_all[0][0], &rect_all[0][0], coop_cnt, coop_alive,
+                                          num_tiles + kWaves * (xcd * kWaves * pl.coop + t));
             return;
         } else {
             return;
@@ -1016,7 +1071,8 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
     // list segments: this pass leaves the per-pixel state at the segment boundaries for the backward pass - in a SPLIT
     // launch for every tile (each of the four waves keeps the pixels of its block), with one wave per tile for the CUT
     // tiles of a hybrid launch (or, W16 = 0, for all of them)
-    constexpr bool kSegsF = SEGS && NBX == 2 && !WL;
+    // (one wave per tile, TS_SEGS_COOP: the cut tiles are cooperative workgroups - no whole-tile wave keeps boundary state)
+    constexpr bool kSegsF = SEGS && NBX == 2 && !WL && (SPLIT || !kSegsCoop);
     const int S_seg = max(1, min(TS_CAM_SEGS(cam), kSegMax));
     int ck_block = -1;                                               // the tile's checkpoint block, -1 = none
     if (kSegsF && final_Ts != nullptr && S_seg > 1 && range.y - range.x >= kSegMinList)

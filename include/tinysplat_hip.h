@@ -81,10 +81,16 @@ typedef struct ts_camera {
      * tile on 16x16 lists) - COOPERATIVE TILES: the first C16/16 of every band, which the forward launch hands out
      * last, are composited by a workgroup of four waves each (shared staging and sort, one 8x8 block per wave), so
      * that the forward launch's tail is filled with items a quarter as long.  Never a cut tile (C16 is capped by
-     * W16; with S > 1 and W16 = 0 it is ignored).  Image, final_Ts, final_index: bit for bit the same. */
+     * W16; with S > 1 and W16 = 0 it is ignored).  Image, final_Ts, final_index: bit for bit the same.
+     * TS_HINT_COOP_SPLIT (bit 20; a pure performance hint of ts_raster_fwd*): a launch that asks for
+     * TS_RASTER_SPLIT_BLOCKS on 16x16 lists composites every tile as a cooperative workgroup instead - four waves per
+     * tile as the split mapping has, but each list is staged and sorted ONCE by the four of them instead of walked by
+     * each.  With S > 1 the boundary records are the ones the split launch would leave (W16 = 0: every tile; W16 > 0:
+     * the cut tiles are the cooperative ones and the others one wave each).  Same bits in every output. */
     int32_t hints;
 } ts_camera;
 #define TS_HINT_BALANCED_WALK 1
+#define TS_HINT_COOP_SPLIT (1 << 20)
 #define TS_CAM_LIST_SEGMENTS(s) (((s) & 15) << 8)
 #define TS_CAM_WHOLE_TILES(w16) (((w16) & 15) << 12)
 #define TS_CAM_COOP_TILES(c16) (((c16) & 15) << 16)

@@ -786,6 +786,39 @@ def test_cooperative_tiles_change_no_bit(n, w, h, mult, depth, monkeypatch):
         assert int((lens > 128).sum()) > 100 and int((lens > 256).sum()) > 20 and int((lens > 512).sum()) > 0, lens.max()
 
 
+@pytest.mark.parametrize("n,w,h,mult,sh,segs", [(120000, 400, 272, 2.0, 1, "auto"),   # long lists: list segments in backward
+                                                (120000, 400, 272, 2.0, 1, 1),        # ... split blocks in backward
+                                                (3000, 256, 256, 1.0, 0, "auto"),     # lists of one chunk: stays split
+                                                (50000, 1920, 128, 2.0, 2, "auto")])  # a stripe-shaped launch (120 x 8 tiles)
+def test_cooperative_tiles_replace_the_split_forward_pass(n, w, h, mult, sh, segs, monkeypatch):
+    """TS_HINT_COOP_SPLIT (small launches): the forward pass composites every tile with four waves that SHARE the staging
+    and the sort instead of four waves that each walk the whole list.  Image, depth, sorted lists, the boundary records
+    the backward pass's list segments start from - so every gradient - are bit for bit the split forward pass's."""
+    from tinysplat_amd import frame
+    model, cam = scene_args(n, sh, w, h, seed=51, scale_mult=mult)
+    g = torch.Generator().manual_seed(52)
+    wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
+    monkeypatch.setattr(frame, "LIST_SEGMENTS", segs)
+    monkeypatch.setattr(frame, "WIDE_TILES", 0)
+    res = []
+    for coop in (False, True):
+        monkeypatch.setattr(frame, "COOP_SPLIT", coop)
+        md = model.to(DEV).requires_grad_(True)
+        r = GaussianRasterizer(md, None, device=torch.device(DEV))
+        rgb, ex = r(cam, (w, h), sh)
+        ((rgb * wr).sum() + (ex["depth"] * wd).sum()).backward()
+        b = frame.last_binning[0]
+        assert bool(b.cam.hints & (1 << 20)) == coop
+        with torch.no_grad():
+            rgb_v, ex_v = r(cam, (w, h), sh)
+        assert torch.equal(rgb_v, rgb.detach()) and torch.equal(ex_v["depth"], ex["depth"].detach())
+        res.append([rgb.detach(), ex["depth"].detach(), b.gaussian_ids_sorted[:int(b.tile_bins[:, 1].max())].clone(),
+                    ex["xys"].grad] + [p.grad for p in md.parameters()] + [frame.last_segments[0]])
+    assert res[0][-1] == res[1][-1]
+    for k, (a, b) in enumerate(zip(res[0][:-1], res[1][:-1])):
+        assert torch.equal(a, b), k
+
+
 def test_cooperative_tiles_in_the_drop_in_op(monkeypatch):
     """The drop-in op (lists sorted by ts_sort_tiles, ts_raster_fwd) on a frame of more than COOP_FROM tiles: same
     image, alpha and gradients with and without the hint."""

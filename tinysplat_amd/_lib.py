@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ["TS_LIB_PATH"]) if os.environ.get("TS_LIB_PATH") else
     Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
 ABI_VERSION = 6
 HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
+HINT_COOP_SPLIT = 1 << 20        # ts_camera.hints: TS_HINT_COOP_SPLIT
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
 
 

@@ -176,6 +176,9 @@ __device__ __forceinline__ void dma_record(const float4* __restrict__ splats, in
 #ifndef TS_SELECT_SGPR
 #define TS_SELECT_SGPR 1
 #endif
+#ifndef TS_BWD_EXEC_MASK
+#define TS_BWD_EXEC_MASK 0
+#endif
 
 #ifndef TS_NT_ROWS
 #define TS_NT_ROWS 0                    // gradient rows written (raster_bwd) / read (reduce_partials) non-temporally
@@ -602,6 +605,9 @@ constexpr int kCoopAhead = TS_COOP_AHEAD;
 #define TS_SEGS_COOP 0
 #endif
 constexpr bool kSegsCoop = TS_SEGS_COOP && TS_COOP;
+// internal (set by ts_raster_fwd* in the camera copy it hands to the kernel, never by callers): the launch asked for
+// TS_RASTER_SPLIT_BLOCKS under TS_HINT_COOP_SPLIT - every tile (S > 1: every cut tile) is a cooperative workgroup
+constexpr int kHintCoopAll = 1 << 21;
 struct FwdPlan {
     int per_xcd;          // tile groups (of kWaves tiles) per band
     int coop, coop_lo;    // groups coop_lo .. coop_lo + coop - 1 of every band: one workgroup per TILE, handed out last
@@ -615,7 +621,13 @@ __host__ __device__ __forceinline__ FwdPlan fwd_plan(int num_tiles, int hints, b
     p.per_xcd = (groups + 7) >> 3;
     const int w16 = (hints >> 12) & 15, c16 = (hints >> 16) & 15;
     const CutTiles m = cut_tiles(num_tiles, hints);           // (band = kWaves * per_xcd tiles for kWaves == 4)
-    if (segs && kSegsCoop && coop_ok) {
+    if (TS_COOP && coop_ok && (hints & kHintCoopAll) && !segs) {      // a small launch, no boundary state: every tile
+        p.coop = p.per_xcd;
+        p.coop_lo = 0;
+        p.descending = false;
+        return p;
+    }
+    if (segs && coop_ok && (kSegsCoop || (TS_COOP && (hints & kHintCoopAll)))) {
         p.coop = (m.band - m.whole) / kWaves;                 // W16 = 0: every tile is cut
         p.coop_lo = m.whole / kWaves;
         p.descending = false;
@@ -1471,8 +1483,13 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             // the select takes its mask from an ordinary SGPR pair: the VOP2 form on a vcc that the SCALAR unit
             // wrote (the s_and of the two ballots) costs a wave 19 cycles instead of 5 (tools/micro/lat_bench.hip)
             float am;
-            if (TS_SELECT_SGPR) asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(am) : "v"(a), "s"(validm));
+            if (TS_BWD_EXEC_MASK) am = a;
+            else if (TS_SELECT_SGPR) asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(am) : "v"(a), "s"(validm));
             else am = TS_LANE(validm) ? a : 0.0f;
+#if TS_BWD_EXEC_MASK
+            // experiment: the rest of the body under EXEC = valid lanes (an invalid lane adds +-0 everywhere: same bits)
+            if (TS_LANE(validm)) {
+#endif
             const float ra = __builtin_amdgcn_rcpf(1.0f - am);
             const float Tk = T[k] * ra;                 // transmittance in front of the Gaussian
             const float fac = am * Tk;
@@ -1494,6 +1511,9 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             acc[3] = __builtin_fmaf(vdx, dx, acc[3]);
             acc[4] = __builtin_fmaf(vdx, dy, acc[4]);
             acc[5] = __builtin_fmaf(vdy, dy, acc[5]);
+#if TS_BWD_EXEC_MASK
+            }
+#endif
         }
         // `any` is wave-uniform.  It is passed through an empty asm so that the compiler cannot prove
         // "block 3 ran => a flush follows": with that knowledge it specialises the last block body
@@ -1934,8 +1954,14 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     const int nt = narrow ? cam->tile_rows * cam->tile_bounds_x : ts_num_tiles(cam);
     if (nt <= 0) return 0;
     if (!tile_bins || !background || !out_img || (!final_Ts != !final_index)) return TS_E_BADARG;
-    const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
     const bool wide = cam->wide_tiles != 0 && !narrow;
+    ts_camera kcam = *cam;
+    kcam.hints &= ~kHintCoopAll;
+    if (split && TS_COOP && !wide && !narrow && (cam->hints & TS_HINT_COOP_SPLIT)) {
+        split = false;                          // four waves per tile with SHARED staging instead (COOPERATIVE TILES)
+        kcam.hints |= kHintCoopAll;
+    }
     const int units = split ? (wide ? 8 : 4) * nt : nt;
     int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
@@ -1943,9 +1969,9 @@ int ts_raster_fwd_planes(int32_t channels, int32_t flags, const ts_camera* cam, 
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
     // list segments (ts_camera.hints bits 8..11): a launch on 16x16 lists also keeps the boundary state of the cut tiles
     const bool segs = !wide && !narrow && final_Ts && TS_CAM_SEGS(*cam) > 1;
-    if (!split && !wide && !narrow) grid = fwd_plan(nt, cam->hints, segs, true).grid();      // COOPERATIVE TILES
+    if (!split && !wide && !narrow) grid = fwd_plan(nt, kcam.hints, segs, true).grid();      // COOPERATIVE TILES
 #define TS_LAUNCH_FWD(C, S, X, L, G)                                                               \
-    hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L, false, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, X, L, false, G>), dim3(grid), dim3(kThreads), 0, s, kcam, nt, \
                        tile_bins, gaussian_ids_sorted, (const int*)nullptr, (const float*)nullptr,   \
                        (int*)nullptr, sp, background, out_img, out_depth, final_Ts,                  \
                        final_index, clamp, clamp ? clamp_mask : nullptr)
@@ -1975,16 +2001,22 @@ int ts_raster_fwd_sort(int32_t channels, int32_t flags, const ts_camera* cam, co
     if (!tile_bins || !background || !out_img || (!final_Ts != !final_index) || !bucket_ids || !depths ||
         !gaussian_ids_sorted)
         return TS_E_BADARG;
-    const bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    bool split = (flags & TS_RASTER_SPLIT_BLOCKS) != 0;
+    ts_camera kcam = *cam;
+    kcam.hints &= ~kHintCoopAll;
+    if (split && TS_COOP && (cam->hints & TS_HINT_COOP_SPLIT)) {          // see ts_raster_fwd_planes
+        split = false;
+        kcam.hints |= kHintCoopAll;
+    }
     const int units = split ? 4 * nt : nt;
     int grid = 8 * (((units + kWaves - 1) / kWaves + 7) / 8);      // see xcd_tile_group
     hipStream_t s = (hipStream_t)stream;
     const float4* sp = reinterpret_cast<const float4*>(splats);
     const int clamp = (flags & TS_RASTER_CLAMP_RGB) ? 1 : 0;
     const bool segs = final_Ts && TS_CAM_SEGS(*cam) > 1;                // list segments: see ts_raster_fwd_planes
-    if (!split) grid = fwd_plan(nt, cam->hints, segs, true).grid();     // COOPERATIVE TILES
+    if (!split) grid = fwd_plan(nt, kcam.hints, segs, true).grid();     // COOPERATIVE TILES
 #define TS_LAUNCH_FWD_SORT(C, S, G)                                                                            \
-    hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true, G>), dim3(grid), dim3(kThreads), 0, s, *cam, nt, \
+    hipLaunchKernelGGL((raster_fwd_kernel<C, S, 2, false, true, G>), dim3(grid), dim3(kThreads), 0, s, kcam, nt, \
                        tile_bins, (const int*)nullptr, bucket_ids, depths, gaussian_ids_sorted, sp, background, \
                        out_img, out_depth, final_Ts, final_index, clamp, clamp ? clamp_mask : nullptr)
     if (channels == 3) {

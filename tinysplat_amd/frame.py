@@ -80,6 +80,21 @@ HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
 # each (shared staging and sort, one 8x8 block per wave) instead of one wave, so that the launch's own tail is filled
 # with items a quarter as long.  Same image, final_Ts and final_index, bit for bit.  0 switches it off.
 HYBRID_COOP16 = max(0, min(15, int(os.environ.get("TS_HYBRID_COOP16", "3"))))
+# ... and a SMALL launch (<= SPLIT_BLOCKS_BELOW tiles), whose forward pass used four waves per tile that each walked the
+# whole list (TS_RASTER_SPLIT_BLOCKS), composites every tile that way: TS_HINT_COOP_SPLIT, same four waves per tile,
+# each list staged and sorted once.  The backward pass (list segments or split blocks) is unchanged, and so is every
+# output bit.  TS_COOP_SPLIT=0 switches it off.
+COOP_SPLIT = os.environ.get("TS_COOP_SPLIT", "1") != "0"
+
+
+def set_launch_hints(cam, segs: int, w16: int, mode: int, split: bool) -> None:
+    """The compositing launches' fields of ``cam.hints``: list segments / whole-tile share (bits 8..15), cooperative
+    tiles of the forward launch (bits 16..20)."""
+    cam.hints = (cam.hints & ~0x1FFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
+    if mode == 0 and not split and cam.tile_rows * cam.tile_bounds_x >= HYBRID_FROM:
+        cam.hints |= HYBRID_COOP16 << 16
+    if mode == 0 and split and COOP_SPLIT:
+        cam.hints |= _lib.HINT_COOP_SPLIT
 
 
 def _list_segments(tiles16: int, mode: int, split: bool):
@@ -305,9 +320,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     rows = _stripe_rows(cam)
     m = max(n, 1)
     segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
-    cam.hints = (cam.hints & ~0xFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
-    if mode == 0 and not F.split and cam.tile_rows * cam.tile_bounds_x >= HYBRID_FROM:
-        cam.hints |= HYBRID_COOP16 << 16
+    set_launch_hints(cam, segs, w16, mode, F.split)
     F.segs = segs
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()

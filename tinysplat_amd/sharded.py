@@ -511,7 +511,7 @@ def _stripe_stage(lib, s, dev, layout: ShardLayout, records: Tensor, background:
     S.cam = cam
     S.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
     S.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, S.mode, S.split) if keep else (1, 0)
-    cam.hints = (cam.hints & ~0xFF00) | (((S.segs << 8) | (w16 << 12)) if S.segs > 1 else 0)
+    _frame.set_launch_hints(cam, S.segs, w16, S.mode, S.split)
     fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch))
     num_tiles = int(lib.ts_num_tiles(ctypes.byref(cam)))
     S.num_tiles = num_tiles
@@ -766,7 +766,7 @@ class _RankState:
         cam.wide_tiles = 1 if self.mode else 0
         self.split = 0 < cam.tile_rows * cam.tile_bounds_x <= _frame.SPLIT_BLOCKS_BELOW
         self.segs, w16 = _frame._list_segments(cam.tile_rows * cam.tile_bounds_x, self.mode, self.split)
-        cam.hints = (cam.hints & ~0xFF00) | (((self.segs << 8) | (w16 << 12)) if self.segs > 1 else 0)
+        _frame.set_launch_hints(cam, self.segs, w16, self.mode, self.split)
         self.hints0 = cam.hints
         self.s_cam = cam
         self.fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch))

@@ -177,7 +177,10 @@ __device__ __forceinline__ void dma_record(const float4* __restrict__ splats, in
 #define TS_SELECT_SGPR 1
 #endif
 #ifndef TS_BWD_EXEC_MASK
-#define TS_BWD_EXEC_MASK 0
+#define TS_BWD_EXEC_MASK 0             // measured (round 5): the body's second half under EXEC = valid lanes: 450 -> 459 us
+#endif
+#ifndef TS_BWD_EARLY_RECORD
+#define TS_BWD_EARLY_RECORD 0          // measured (round 5): next record requested in front of the row flush: 451 -> 458 - 465 us
 #endif
 
 #ifndef TS_NT_ROWS
@@ -1433,13 +1436,24 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
     // in one and not in the other, and a gradient would depend on which chunk an entry lands in).
 #pragma clang fp contract(off)
     TS_WORK(0, cnt);
+    // staged record: three float4 for three channels (the block mask rides in the unused fourth colour word),
+    // four for RGB + depth.  TS_BWD_EARLY_RECORD (an experiment, off): the NEXT entry's record requested in front of the
+    // row flush of this one - its registers are dead by then, and the flush (no LDS access in it) would cover the round
+    // trip that the wave waits out at the top of every iteration (7.6 % of a backward wave's cycles); slower (above)
+    constexpr int RS = CH == 3 ? 3 : 4;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float bm_f = 0.0f;
+    if (TS_BWD_EARLY_RECORD && cnt > 0 && TS_ABLATE != 3) {
+        r0 = lds[0]; r1 = lds[1]; r2 = lds[2];
+        bm_f = CH == 3 ? r2.y : lds[3].x;
+    }
     for (int j = 0; j < (TS_ABLATE == 3 ? 0 : cnt); ++j) {
         TS_SEG_T0(tseg_a);
-        // staged record: three float4 for three channels (the block mask rides in the unused fourth colour word),
-        // four for RGB + depth
-        constexpr int RS = CH == 3 ? 3 : 4;
-        const float4 r0 = lds[RS * j], r1 = lds[RS * j + 1], r2 = lds[RS * j + 2];
-        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(CH == 3 ? r2.y : lds[RS * j + 3].x));
+        if (!TS_BWD_EARLY_RECORD) {
+            r0 = lds[RS * j]; r1 = lds[RS * j + 1]; r2 = lds[RS * j + 2];
+            bm_f = CH == 3 ? r2.y : lds[RS * j + 3].x;
+        }
+        const int bm = __builtin_amdgcn_readfirstlane(__float_as_int(bm_f));
         const int idx = __float_as_int(r2.z);
         const float neg_lo = -r1.y;
         float col[CH];
@@ -1522,11 +1536,15 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         asm volatile("" : "+s"(any));
         TS_SEG_ADD(ts_seg_, 2, tseg_b);
         TS_SEG_T0(tseg_c);
+        const int row_slot = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
+        if (TS_BWD_EARLY_RECORD && j + 1 < cnt) {
+            r0 = lds[RS * (j + 1)]; r1 = lds[RS * (j + 1) + 1]; r2 = lds[RS * (j + 1) + 2];
+            bm_f = CH == 3 ? r2.y : lds[RS * (j + 1) + 3].x;
+        }
         if (any) {
             TS_STAT(5, 1);
             TS_WORK(2, 1);
-            flush_row<CH>(acc, __builtin_amdgcn_readfirstlane(__float_as_int(r2.w)), num_isects,
-                          partials, row_flags, lane);
+            flush_row<CH>(acc, row_slot, num_isects, partials, row_flags, lane);
             // zero the accumulators two at a time (v_mov_b64 on a register pair)
 #pragma unroll
             for (int c = 0; c + 1 < 6 + CH; c += 2) {

@@ -21,6 +21,14 @@ for a in "--config 2" "--config 5 --steps 20 --warmup 5" "--config 5 --steps 20 
 done
 echo "== hybrid compositing launches: settings around the default (tools/hybrid_sweep.py)"
 timeout 300 python tools/hybrid_sweep.py --settings "1:0 8:13 8:12 8:14 4:13 1:0" 2>&1 | grep "^S=" | tee $OUT/${TAG}_hybrid_sweep.txt
+echo "== cooperative tiles of the forward launch: shares around the default (tools/coop_sweep.py), small launches (tools/coop_split_check.py)"
+timeout 300 python tools/coop_sweep.py --settings "0 2 3 4 6 0" 2>&1 | grep "^C16" | tee $OUT/${TAG}_coop_sweep.txt
+( timeout 300 python tools/coop_split_check.py 2>&1 | grep "^coop_split"; timeout 300 python tools/coop_split_check.py --depth 2>&1 | grep "^coop_split"; \
+  timeout 300 python tools/coop_split_check.py --n 200000 --width 512 --height 512 --ranks 1 --rank 0 2>&1 | grep "^coop_split" ) | tee $OUT/${TAG}_coop_split.txt
+if [ -f build/tl/libtinysplat_hip.so ]; then
+  echo "== per-wave timeline of both compositing launches (-DTS_TIMELINE=1 build under build/tl)"
+  TS_LIB_PATH=build/tl/libtinysplat_hip.so TS_ALLOW_VARIANT_LIB=1 timeout 300 python tools/raster_timeline.py 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_wave_timeline.txt | grep "resident waves per SIMD on average"
+fi
 echo "== one emulated rank step for EVERY rank of 8 (tools/rank_table.py), config 3 and config 5"
 timeout 600 python tools/rank_table.py --config 3 --modes equal 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config3.txt | tail -1
 timeout 900 python tools/rank_table.py --config 5 --modes equal --steps 20 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config5.txt | tail -1

@@ -57,10 +57,13 @@ def test_binding_covers_the_header_and_version_matches():
     assert lib.ts_final_floats(ctypes.byref(cam), 3) == px + 8 * 384 * 4 * 4 * 256
     cam.wide_tiles = 1
     assert lib.ts_final_floats(ctypes.byref(cam), 3) == px
-    assert all(frame._list_segments(t, 0, True) == (max(2, min(8, 8192 // t)), 0) for t in (1, 200, 1020, 1536, 5000)) \
-        or frame.LIST_SEGMENTS != "auto"
+    assert all(frame._list_segments(t, 0, True) == (max(2, min(8, frame.SEGMENT_ITEMS // t)), 0)
+               for t in (1, 200, 1020, 1536, 2400, 5000)) or frame.LIST_SEGMENTS != "auto"
     assert frame._list_segments(1020, 2, True) == (1, 0) and frame._list_segments(1020, 0, False) == (1, 0)
     assert frame._list_segments(8160, 0, False) == ((frame.HYBRID_SEGS, frame.HYBRID_WHOLE16) if frame.HYBRID_SEGS > 1 else (1, 0))
+    # between a rank's stripe and a full frame most tiles are cut; below HYBRID_MID_FROM a launch that is not split stays whole
+    assert frame._list_segments(4080, 0, False) == ((frame.HYBRID_SEGS, frame.HYBRID_MID_WHOLE16) if frame.HYBRID_SEGS > 1 else (1, 0))
+    assert frame._list_segments(frame.HYBRID_MID_FROM - 1, 0, False) == (1, 0)
     assert lib.ts_bin_ws_ints(1_000_000, 8160) >= 8160 * 2
     assert ctypes.sizeof(_lib.TsCamera) == 56        # incl. wide_tiles + hints (ABI 3; the second word was `reserved` until round 4)
     assert ctypes.sizeof(_lib.TsStripes) == 4 * (_lib.MAX_RANKS + 2)

@@ -41,15 +41,15 @@ TIGHT_BINNING = os.environ.get("TS_TIGHT_BINNING", "1") != "0"
 # Launches with at most this many tiles (a stripe of a multi-GPU frame, a small image) composite with
 # four waves per tile, one per 8x8 block (TS_RASTER_SPLIT_BLOCKS): an MI355X has 1024 SIMDs, and with
 # one wave per tile such launches cannot hide any latency.  0 disables.
-SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
+SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "2400"))
 
 # LIST SEGMENTS in the backward pass of such a launch (bits 8..11 of ts_camera.hints, csrc/raster.hip: LIST SEGMENTS;
 # TS_LIST_SEGMENTS = auto (default) | 1 (off: split backward) | 2..8): the split forward pass also leaves, per pixel,
 # the transmittance in front of and the colour behind up to S - 1 boundaries of every list of two chunks or more, and
 # the backward pass replays the segments as independent work items of one wave over the whole tile - instead of four
 # waves per tile that each walk and stage the WHOLE list for a quarter of the pixels and write a gradient row of
-# their own.  "auto": as many segments (2 .. 8) as bring the launch to ~8 192 work items (two rounds of raster_bwd's
-# wave slots).  A list of one chunk (<= 64 entries) cannot be cut, and a launch of such lists is better off split:
+# their own.  "auto": as many segments (2 .. 8) as bring the launch to ~16 384 work items (three rounds of raster_bwd's
+# 5 120 wave slots; 8 192 while the kernel ran four waves per SIMD).  A list of one chunk (<= 64 entries) cannot be cut, and a launch of such lists is better off split:
 # the BACKWARD pass decides - segments when the frame averages >= LIST_SEGMENTS_FROM bounding-box pairs per tile (the
 # frame's own pair count, known by then - the same frame always takes the same path; ~0.65 of them are listed),
 # split blocks otherwise.  Measured on MI355X, raster_fwd + raster_bwd + reduce_partials, split -> 8 segments
@@ -65,6 +65,7 @@ SPLIT_BLOCKS_BELOW = int(os.environ.get("TS_SPLIT_BLOCKS_BELOW", "1536"))
 _ls = os.environ.get("TS_LIST_SEGMENTS", "auto")
 LIST_SEGMENTS = _ls if _ls == "auto" else max(1, min(8, int(_ls)))
 LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
+SEGMENT_ITEMS = int(os.environ.get("TS_SEGMENT_ITEMS", "16384"))      # "auto": work items a small launch is cut into
 
 
 # HYBRID LAUNCHES (bits 12..15 of ts_camera.hints, csrc/raster.hip: HYBRID LAUNCH): a full frame - at least HYBRID_FROM
@@ -75,6 +76,12 @@ LIST_SEGMENTS_FROM = int(os.environ.get("TS_LIST_SEGMENTS_FROM", "192"))
 HYBRID_FROM = int(os.environ.get("TS_HYBRID_FROM", "4096"))
 HYBRID_SEGS = max(1, min(8, int(os.environ.get("TS_HYBRID_SEGS", "8"))))
 HYBRID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_WHOLE16", "13"))))
+# ... and a launch between the two regimes (HYBRID_MID_FROM <= tiles < HYBRID_FROM: one rank of 2 or 3 on a 1080p frame) has
+# fewer tiles than the GPU has wave slots, so a whole tile's wave IS the critical path: most tiles are cut there
+# (tools/midrange_policy.sh: 4 080 tiles 0.79 -> 0.72 ms per step, 2 760 tiles 0.655 -> 0.61)
+HYBRID_MID_FROM = int(os.environ.get("TS_HYBRID_MID_FROM", "1537"))
+HYBRID_MID_WHOLE16 = max(1, min(15, int(os.environ.get("TS_HYBRID_MID_WHOLE16", "6"))))
+HYBRID_MID_COOP16 = max(0, min(15, int(os.environ.get("TS_HYBRID_MID_COOP16", "6"))))
 # COOPERATIVE TILES (bits 16..19 of ts_camera.hints, csrc/raster.hip: COOPERATIVE TILES): the FORWARD launch of such a
 # frame hands the first HYBRID_COOP16 / 16 of every band - the tiles it dispatches last - to a workgroup of four waves
 # each (shared staging and sort, one 8x8 block per wave) instead of one wave, so that the launch's own tail is filled
@@ -91,8 +98,11 @@ def set_launch_hints(cam, segs: int, w16: int, mode: int, split: bool) -> None:
     """The compositing launches' fields of ``cam.hints``: list segments / whole-tile share (bits 8..15), cooperative
     tiles of the forward launch (bits 16..20)."""
     cam.hints = (cam.hints & ~0x1FFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
-    if mode == 0 and not split and cam.tile_rows * cam.tile_bounds_x >= HYBRID_FROM:
+    tiles16 = cam.tile_rows * cam.tile_bounds_x
+    if mode == 0 and not split and tiles16 >= HYBRID_FROM:
         cam.hints |= HYBRID_COOP16 << 16
+    elif mode == 0 and not split and tiles16 >= HYBRID_MID_FROM:
+        cam.hints |= HYBRID_MID_COOP16 << 16
     if mode == 0 and split and COOP_SPLIT:
         cam.hints |= _lib.HINT_COOP_SPLIT
 
@@ -102,10 +112,14 @@ def _list_segments(tiles16: int, mode: int, split: bool):
     if mode != 0 or tiles16 <= 0:
         return 1, 0
     if not split:
-        return (HYBRID_SEGS, HYBRID_WHOLE16) if (HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM) else (1, 0)
+        if HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM:
+            return HYBRID_SEGS, HYBRID_WHOLE16
+        if HYBRID_SEGS > 1 and tiles16 >= HYBRID_MID_FROM:
+            return HYBRID_SEGS, HYBRID_MID_WHOLE16
+        return 1, 0
     if LIST_SEGMENTS != "auto":
         return int(LIST_SEGMENTS), 0
-    return max(2, min(8, 8192 // tiles16)), 0
+    return max(2, min(8, SEGMENT_ITEMS // tiles16)), 0
 
 
 last_segments = {}      # device index -> list segments of the most recent backward pass (1 = none; tests, tools)

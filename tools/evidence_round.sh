@@ -29,6 +29,8 @@ if [ -f build/tl/libtinysplat_hip.so ]; then
   echo "== per-wave timeline of both compositing launches (-DTS_TIMELINE=1 build under build/tl)"
   TS_LIB_PATH=build/tl/libtinysplat_hip.so TS_ALLOW_VARIANT_LIB=1 timeout 300 python tools/raster_timeline.py 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_wave_timeline.txt | grep "resident waves per SIMD on average"
 fi
+echo "== launch policies between a rank's stripe and a full frame (tools/midrange_policy.sh)"
+timeout 900 bash tools/midrange_policy.sh 2>&1 | grep "^G=" | tee $OUT/${TAG}_midrange_policy.txt | head -3
 echo "== one emulated rank step for EVERY rank of 8 (tools/rank_table.py), config 3 and config 5"
 timeout 600 python tools/rank_table.py --config 3 --modes equal 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config3.txt | tail -1
 timeout 900 python tools/rank_table.py --config 5 --modes equal --steps 20 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_rank_table_config5.txt | tail -1

@@ -1309,8 +1309,10 @@ __device__ __forceinline__ float wave_sum10(const float v[10], int lane) {
 #define TS_DPP_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
 #define TS_DPP_HM_HI "row_half_mirror row_mask:0xf bank_mask:0xa"
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-template <bool HAVE9>
-__device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane) {
+// `zero` (TS_FLUSH_ZERO_EARLY): called right behind the asm block, which is the last reader of the caller's accumulators -
+// the caller's zeroing moves then stand where the permlane / DPP hazards below would otherwise need s_nops
+template <bool HAVE9, class Zero>
+__device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane, Zero zero) {
     float c0, c1, c2, t1, t3;
     if (HAVE9) {
         asm("s_nop 1\n\t"
@@ -1353,6 +1355,7 @@ __device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane) 
             : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(t1), "=&v"(t3)
             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
     }
+    zero();
     // lane bit 4: odd / even rows exchanged in one issue (v_permlane16_swap), c0 stays in the even rows
     const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0), __float_as_uint(c1), false, false);
     const float d = __uint_as_float(r.x) + __uint_as_float(r.y);
@@ -1378,8 +1381,11 @@ __device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane) 
 // Wave-reduces the 6+CH per-lane sums of one (tile, Gaussian) and writes its row of `partials`
 // (lanes 48..57 each store one float of the 40/48-byte row, lane 58 sets the flag; TS_FLUSH_ASM: the first lane
 // of ten quads stores, lane 1 sets the flag).
+#ifndef TS_FLUSH_ZERO_EARLY
+#define TS_FLUSH_ZERO_EARLY 1
+#endif
 template <int CH>
-__device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, long long num_isects,
+__device__ __forceinline__ void flush_row(float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
                                           unsigned char* __restrict__ row_flags, int lane) {
     // num_isects carries the row-flag value in its top byte (see ts_raster_bwd: TS_RASTER_FLAG_GEN)
@@ -1391,7 +1397,19 @@ __device__ __forceinline__ void flush_row(const float (&v)[6 + CH], int slot_i, 
         float v10[10];
 #pragma unroll
         for (int c = 0; c < 10; ++c) v10[c] = c < 6 + CH ? v[c] : 0.0f;
-        r = TS_FLUSH_ASM ? wave_sum10_masked<(CH == 4)>(v10, lane) : wave_sum10<(CH == 4)>(v10, lane);
+        auto zero = [&]() {
+            if (!TS_FLUSH_ZERO_EARLY) return;
+            // zero the accumulators two at a time (v_mov_b64 on a register pair)
+#pragma unroll
+            for (int c = 0; c + 1 < 6 + CH; c += 2) {
+                f2 z = (f2)(0.0f);
+                asm volatile("" : "+v"(z));
+                v[c] = z.x; v[c + 1] = z.y;
+            }
+            if ((6 + CH) & 1) v[5 + CH] = 0.0f;
+        };
+        if (TS_FLUSH_ASM) r = wave_sum10_masked<(CH == 4)>(v10, lane, zero);
+        else { r = wave_sum10<(CH == 4)>(v10, lane); zero(); }
     }
     const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
     (void)num_isects;
@@ -1546,14 +1564,16 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             TS_STAT(5, 1);
             TS_WORK(2, 1);
             flush_row<CH>(acc, row_slot, num_isects, partials, row_flags, lane);
-            // zero the accumulators two at a time (v_mov_b64 on a register pair)
+            if (!TS_FLUSH_ZERO_EARLY || TS_ABLATE == 4) {
+                // zero the accumulators two at a time (v_mov_b64 on a register pair)
 #pragma unroll
-            for (int c = 0; c + 1 < 6 + CH; c += 2) {
-                f2 z = (f2)(0.0f);
-                asm volatile("" : "+v"(z));
-                acc[c] = z.x; acc[c + 1] = z.y;
+                for (int c = 0; c + 1 < 6 + CH; c += 2) {
+                    f2 z = (f2)(0.0f);
+                    asm volatile("" : "+v"(z));
+                    acc[c] = z.x; acc[c + 1] = z.y;
+                }
+                if ((6 + CH) & 1) acc[5 + CH] = 0.0f;
             }
-            if ((6 + CH) & 1) acc[5 + CH] = 0.0f;
         }
         TS_SEG_ADD(ts_seg_, 3, tseg_c);
     }

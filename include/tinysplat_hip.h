@@ -454,6 +454,18 @@ int ts_shard_owner_fwd(const ts_frame* fo, const ts_stripes* stripes_host, int32
                        void* stream);
 int ts_shard_owner_fwd_padded(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* group_base_host,
                               int32_t* route_ws, int32_t* counts, void* stream);   /* see ts_route_count_padded */
+/* The owner stage's forward pass in ONE launch + the route scan (round 5; what ts_shard_owner_fwd* issue when the rank
+ * owns at most TS_SMALL_N_FUSED Gaussians - environment, default 262144, 0 = never -: a rank of 8 on a 1 M scene is
+ * bound by launch floors there): projection (project_flags as ts_project_fwd), colour stage on the split coefficient
+ * tensors, packed records (cum_tiles_hit := num_tiles_hit, as the owner stage packs them) and the destination counts
+ * of ts_route_count_padded - the same bits in every array the three launches write. */
+int ts_shard_owner_fwd_fused(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                             const float* scales, const float* quats, const float* view34, const float* projview,
+                             const ts_camera* cam_host, int32_t project_flags, const float* origin,
+                             const float* colors_dc, const float* colors_rest, const float* opacity, int32_t channels,
+                             int32_t raster_flags, float* xys, float* depths, int32_t* radii, float* conics,
+                             int32_t* num_tiles_hit, uint8_t* clamp_mask, float* splats, const ts_stripes* stripes_host,
+                             const int32_t* group_base_host, int32_t* route_ws, int32_t* counts, void* stream);
 int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream);
 int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream);
 int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* route_ws,

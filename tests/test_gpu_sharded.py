@@ -103,6 +103,61 @@ def _check_simulated(n, sh, w, h, mult, depth, world, stripes=None, rel=1e-5):
     return recv_counts
 
 
+@pytest.mark.parametrize("n,sh,depth", [(70000, 3, False), (9001, 1, True), (300, 0, False)])
+def test_fused_owner_forward_writes_the_bits_of_its_three_launches(n, sh, depth):
+    """csrc/shard.hip FUSED OWNER FORWARD (what a rank's owner stage issues for a small shard): projection, colour stage,
+    packed records and destination counts in one launch - every array holds the bits the three launches leave."""
+    import ctypes
+    from tinysplat_amd import _lib
+    from tinysplat_amd.ops import _camera, _stream, _tile_bounds
+    w, h, world = 640, 368, 4
+    model, cam = make_scene(n, sh, w, h, seed=61, scale_mult=3.0)
+    md = model.to(DEV)
+    lay = ShardLayout(n, world, 1, (w, h))
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    s = _stream(dev)
+    nb = md.colors_rest.shape[1] + 1
+    ch = 4 if depth else 3
+    view = cam.view_matrix.to(DEV)
+    view34 = view[:3, :].contiguous()
+    projview = (cam.proj_matrix @ cam.view_matrix).to(DEV).contiguous()
+    origin = view[:3, 3].contiguous()
+    c = _camera(cam.f_x, cam.f_y, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0)
+    n_route = int(lib.ts_route_ws_ints(n, world))
+    gb = (ctypes.c_int32 * (world + 1))(*[0, n, 2 * n, 3 * n, 4 * n])
+
+    def buffers():
+        f32, i32 = dict(dtype=torch.float32, device=DEV), dict(dtype=torch.int32, device=DEV)
+        return dict(xys=torch.zeros(n, 2, **f32), depths=torch.zeros(n, **f32), radii=torch.zeros(n, **i32),
+                    conics=torch.zeros(n, 3, **f32), nth=torch.zeros(n, **i32), splats=torch.zeros(n, 12, **f32),
+                    mask=torch.zeros(n, dtype=torch.uint8, device=DEV), ws=torch.zeros(n_route, **i32),
+                    counts=torch.zeros(world, **i32))
+    a, b = buffers(), buffers()
+    P = lambda t: t.data_ptr()
+    means, scales, quats, opac = md.means.contiguous(), md.scales.contiguous(), md.quats.contiguous(), md.opacities.contiguous()
+    dc, rest = md.colors_dc.contiguous(), md.colors_rest.contiguous()
+    assert lib.ts_project_fwd(n, P(means), P(scales), P(quats), P(view34), P(projview), c, 3, P(a["xys"]), P(a["depths"]),
+                              P(a["radii"]), P(a["conics"]), P(a["nth"]), None, s) == 0
+    assert lib.ts_colors_pack_fwd(n, sh, nb, P(means), P(origin), P(dc), P(rest) if nb > 1 else None, P(a["mask"]), None, ch,
+                                  1, P(a["xys"]), P(a["radii"]), P(a["conics"]), P(opac), P(a["nth"]), c,
+                                  P(a["depths"]) if depth else None, P(a["splats"]), s) == 0
+    assert lib.ts_route_count_padded(n, P(a["xys"]), P(a["radii"]), c, lay.c_stripes, gb, P(a["ws"]), P(a["counts"]), s) == 0
+    assert lib.ts_shard_owner_fwd_fused(n, sh, nb, P(means), P(scales), P(quats), P(view34), P(projview), c, 3, P(origin),
+                                        P(dc), P(rest) if nb > 1 else None, P(opac), ch, 1, P(b["xys"]), P(b["depths"]),
+                                        P(b["radii"]), P(b["conics"]), P(b["nth"]), P(b["mask"]), P(b["splats"]),
+                                        lay.c_stripes, gb, P(b["ws"]), P(b["counts"]), s) == 0
+    torch.cuda.synchronize()
+    vis = a["radii"] > 0
+    assert int(vis.sum()) > n // 3
+    for k in ("xys", "depths", "radii", "conics", "nth", "ws", "counts"):
+        assert torch.equal(a[k], b[k]), k
+    # (the records carry integers in float words: compare the bits)
+    assert torch.equal(a["splats"][vis].view(torch.int32), b["splats"][vis].view(torch.int32))
+    assert torch.equal(a["mask"][vis], b["mask"][vis])
+    assert int(b["counts"].sum()) >= int(vis.sum())
+
+
 @pytest.mark.parametrize("world,depth,n,sh,w,h,mult,stripes", [
     (1, False, 20000, 3, 400, 300, 3.0, None),
     (2, False, 40000, 3, 640, 360, 2.0, None),

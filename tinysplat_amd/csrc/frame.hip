@@ -11,6 +11,8 @@
 // stores it into the caller's mapped pinned word (ts_frame_fwd_project), where the caller polls it between
 // _prepare and _composite.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 // roctx is optional: a ROCm install without rocprofiler-sdk still builds and loads the library (ranges become no-ops)
 #if !defined(TS_NO_ROCTX) && __has_include(<rocprofiler-sdk-roctx/roctx.h>)
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -68,6 +70,14 @@ inline bool segmented(const ts_frame* f) {
 }
 inline int bwd_split(const ts_frame* f) {
     return ((f->flags & TS_FRAME_SPLIT) && !segmented(f)) ? TS_RASTER_SPLIT_BLOCKS : 0;
+}
+// Gaussians up to which a rank's owner stage runs its small-N fusions (TS_SMALL_N_FUSED, read once; 0 = never)
+inline int small_n_fused() {
+    static const int v = [] {
+        const char* e = getenv("TS_SMALL_N_FUSED");
+        return e ? atoi(e) : 262144;
+    }();
+    return v;
 }
 inline int raster_flags(const ts_frame* f) {
     return TS_RASTER_CLAMP_RGB | ((f->flags & TS_FRAME_SPLIT) ? TS_RASTER_SPLIT_BLOCKS : 0) |
@@ -188,6 +198,13 @@ int ts_shard_owner_fwd_padded(const ts_frame* fo, const ts_stripes* stripes, con
                               int32_t* route_ws, int32_t* counts, void* stream) {
     TsRange range_("ts_shard_owner_fwd");
     if (bad(fo) || !stripes) return TS_E_BADARG;
+    if (fo->n > 0 && fo->n <= small_n_fused())          // a small shard: one launch instead of three (shard.hip)
+        return ts_shard_owner_fwd_fused(fo->n, fo->sh_degree, fo->num_bases, fo->means, fo->scales, fo->quats, fo->view34,
+                                        fo->projview, &fo->cam, 3, fo->origin, fo->colors_dc,
+                                        fo->num_bases > 1 ? fo->colors_rest : nullptr, fo->opacities, fo->channels,
+                                        TS_RASTER_LOGIT_OPACITY, fo->xys, fo->depths, fo->radii, fo->conics,
+                                        fo->num_tiles_hit, fo->sh_mask, fo->splats, stripes, group_base, route_ws, counts,
+                                        stream);
     TS_TRY(ts_project_fwd(fo->n, fo->means, fo->scales, fo->quats, fo->view34, fo->projview, &fo->cam, 3, fo->xys,
                           fo->depths, fo->radii, fo->conics, fo->num_tiles_hit, nullptr, stream));
     // colour stage + packed records of the owned Gaussians; the slot fields are rewritten by the importing rank,

@@ -33,6 +33,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
+#include "project_inputs.h"
 
 // destination ranks [d0, d1] of a Gaussian (d0 > d1: none)
 struct DestRange { int d0, d1; };
@@ -81,6 +82,92 @@ __global__ __launch_bounds__(kThreads) void route_count_kernel(int n, const floa
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) s += cnt[w][threadIdx.x];
         block_counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// FUSED OWNER FORWARD (small N: a rank of 8 owns ~125 k Gaussians and its stage is bound by launch floors, not by
+// bytes): projection (project.hip: project_fwd_kernel), colour stage + packed record (sh_colors_fwd_sparse_kernel +
+// pack_one, from registers) and the per-block destination counts (route_count_kernel) of one owned Gaussian per lane,
+// in ONE launch.  The same device functions in the same order: every array the three launches wrote holds the same
+// bits (the clamp mask of a culled Gaussian, which nothing reads, is 0 here).
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void owner_fwd_kernel(
+    int n, int num_bases, const float* __restrict__ means3d, const float* __restrict__ scales,
+    const float* __restrict__ quats, const float* __restrict__ viewmat, const float* __restrict__ projmat,
+    const ts_camera cam, const int pflags, const float* __restrict__ origin, const float* __restrict__ dc,
+    const float* __restrict__ rest, const float* __restrict__ opacity, const int channels, const int rflags,
+    float* __restrict__ xys, float* __restrict__ depths, int* __restrict__ radii, float* __restrict__ conics,
+    int* __restrict__ num_tiles_hit, unsigned char* __restrict__ mask, float4* __restrict__ splats,
+    const ts_stripes st, int* __restrict__ block_counts) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    __shared__ int cnt[kWaves][TS_MAX_RANKS];
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    DestRange r{1, 0};
+    if (i < n) {
+        const ts::Cam C = load_cam(viewmat, projmat, cam);
+        const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
+        float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        prep_inputs(pflags, sc, q, nullptr);
+        ts::ProjOut o;
+        ts::project_one(C, m, sc, q, o);
+        reinterpret_cast<float2*>(xys)[i] = make_float2(o.x, o.y);
+        depths[i] = o.depth;
+        radii[i] = o.radius;
+        conics[3 * i] = o.conic[0]; conics[3 * i + 1] = o.conic[1]; conics[3 * i + 2] = o.conic[2];
+        num_tiles_hit[i] = o.tiles;
+        if (o.radius > 0) {
+            // colour stage: the association order of sh_colors_fwd_kernel / _sparse_kernel (identical bits)
+            float Y[KA];
+            ts::sh_basis(DEG, m[0] - origin[0], m[1] - origin[1], m[2] - origin[2], Y);
+            float c0 = Y[0] * dc[3 * i], c1 = Y[0] * dc[3 * i + 1], c2 = Y[0] * dc[3 * i + 2];
+            const float* row = rest + (size_t)i * 3 * (num_bases - 1);
+#pragma unroll
+            for (int k = 1; k < KA; ++k) {
+                c0 = c0 + Y[k] * row[3 * (k - 1)];
+                c1 = c1 + Y[k] * row[3 * (k - 1) + 1];
+                c2 = c2 + Y[k] * row[3 * (k - 1) + 2];
+            }
+            c0 = c0 + 0.5f; c1 = c1 + 0.5f; c2 = c2 + 0.5f;
+            if (mask) mask[i] = (unsigned char)((c0 >= 0.0f ? 1 : 0) | (c1 >= 0.0f ? 2 : 0) | (c2 >= 0.0f ? 4 : 0));
+            c0 = fmaxf(c0, 0.0f); c1 = fmaxf(c1, 0.0f); c2 = fmaxf(c2, 0.0f);
+            // packed record (pack.h: pack_one, full-frame camera) from the registers
+            const ts::TileBox b = ts::tile_bbox(o.x, o.y, (float)o.radius, cam.tile_bounds_x, cam.tile_bounds_y,
+                                                cam.tile_row0, cam.tile_rows);
+            const int w = b.maxx - b.minx, h = b.maxy - b.miny;
+            const int cntb = h > 0 ? w * h : 0;
+            if (cntb > 0) {
+                const int slot_base = (o.tiles - cntb) - b.miny * w - b.minx;      // (cum_tiles_hit := num_tiles_hit here)
+                float op = opacity[i];
+                if (rflags & TS_RASTER_LOGIT_OPACITY) op = 1.0f / (1.0f + expf(-op));
+                splats[3 * (size_t)i] = make_float4(o.x, o.y, op, o.conic[0]);
+                splats[3 * (size_t)i + 1] = make_float4(o.conic[1], o.conic[2], c0, c1);
+                splats[3 * (size_t)i + 2] = make_float4(c2, channels == 4 ? o.depth : 0.0f, __int_as_float(slot_base),
+                                                        __int_as_float(w | (b.minx << 16)));
+            }
+            // destinations: dest_range on the registers
+            const ts::TileBox fb = ts::tile_bbox(o.x, o.y, (float)o.radius, cam.tile_bounds_x, cam.tile_bounds_y, 0,
+                                                 cam.tile_bounds_y);
+            if (fb.maxx > fb.minx && fb.maxy > fb.miny) {
+                const int lo = max(fb.miny, st.row[0]), hi = min(fb.maxy, st.row[st.num]);
+                if (hi > lo) { r.d0 = stripe_of_row(st, lo); r.d1 = stripe_of_row(st, hi - 1); }
+            }
+        } else if (mask) {
+            mask[i] = 0;
+        }
+    }
+    for (int d = 0; d < st.num; ++d) {
+        const unsigned long long mm = __ballot(r.d0 <= d && d <= r.d1);
+        if (lane == 0) cnt[wave][d] = __popcll(mm);
+    }
+    __syncthreads();
+    if (threadIdx.x < st.num) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) sum += cnt[w][threadIdx.x];
+        block_counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
     }
 }
 
@@ -365,6 +452,48 @@ int ts_import_pack(int32_t m, const float* records, const int32_t* cum_tiles_hit
     hipLaunchKernelGGL(import_pack_kernel, dim3((m + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        (hipStream_t)stream, m, reinterpret_cast<const float4*>(records), cum_tiles_hit, *cam,
                        reinterpret_cast<float4*>(splats));
+    return launch_status();
+}
+
+int ts_shard_owner_fwd_fused(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                             const float* scales, const float* quats, const float* viewmat, const float* projmat,
+                             const ts_camera* cam, int32_t project_flags, const float* origin, const float* colors_dc,
+                             const float* colors_rest, const float* opacity, int32_t channels, int32_t raster_flags,
+                             float* xys, float* depths, int32_t* radii, float* conics, int32_t* num_tiles_hit,
+                             uint8_t* clamp_mask, float* splats, const ts_stripes* stripes, const int32_t* group_base,
+                             int32_t* route_ws, int32_t* counts, void* stream) {
+    if (n < 0 || !cam || bad_stripes(stripes, cam) || !route_ws || !counts || (channels != 3 && channels != 4) ||
+        degrees_to_use < 0 || degrees_to_use > 4 || num_bases < (degrees_to_use + 1) * (degrees_to_use + 1))
+        return TS_E_BADARG;
+    if (n > 0 && (!means3d || !scales || !quats || !viewmat || !projmat || !origin || !colors_dc || !opacity || !xys ||
+                  !depths || !radii || !conics || !num_tiles_hit || !splats || (num_bases > 1 && !colors_rest)))
+        return TS_E_BADARG;
+    GroupBase gb;
+    gb.padded = group_base != nullptr;
+    for (int d = 0; d <= TS_MAX_RANKS; ++d) gb.base[d] = 0;
+    if (group_base) {
+        for (int d = 0; d <= stripes->num; ++d) {
+            if (group_base[d] < 0 || (d > 0 && group_base[d] < group_base[d - 1])) return TS_E_BADARG;
+            gb.base[d] = group_base[d];
+        }
+    }
+    const int blocks = route_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_OWNER_FWD(D)                                                                                            \
+    hipLaunchKernelGGL(owner_fwd_kernel<D>, dim3(blocks), dim3(kThreads), 0, s, n, num_bases, means3d, scales, quats, \
+                       viewmat, projmat, *cam, (int)project_flags, origin, colors_dc, colors_rest, opacity,        \
+                       (int)channels, (int)raster_flags, xys, depths, radii, conics, num_tiles_hit, clamp_mask,    \
+                       reinterpret_cast<float4*>(splats), *stripes, route_ws)
+    switch (degrees_to_use) {
+        case 0: TS_OWNER_FWD(0); break;
+        case 1: TS_OWNER_FWD(1); break;
+        case 2: TS_OWNER_FWD(2); break;
+        case 3: TS_OWNER_FWD(3); break;
+        default: TS_OWNER_FWD(4); break;
+    }
+#undef TS_OWNER_FWD
+    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, blocks, (int)stripes->num, route_ws,
+                       route_ws + (size_t)blocks * stripes->num, counts, gb);
     return launch_status();
 }
 

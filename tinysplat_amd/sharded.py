@@ -53,6 +53,9 @@ from .synthetic import SplatModel
 RECORD_FLOATS = 16       # TS_EXPORT_RECORD_FLOATS
 ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS
 
+# Gaussians up to which a rank's owner stage runs as its small-N fusion (csrc/shard.hip: FUSED OWNER FORWARD; the
+# library reads the same variable: 0 = never)
+SMALL_N_FUSED = int(os.environ.get("TS_SMALL_N_FUSED", "262144"))
 # PADDED EXCHANGE (an option: TS_PADDED_EXCHANGE=1 switches it on): how many records a rank sends to every other rank
 # is known only after its owner stage has run, and sizing the all_to_all from it costs a host read in the middle of
 # the frame - where the GPU is what bounds a rank's step, it idles while the host waits for the counts, allocates and
@@ -458,7 +461,12 @@ def _owner_stage(lib, s, dev, layout: ShardLayout, exchange: Exchange, means, sc
         for c in O.caps[me].tolist():
             base.append(base[-1] + c)
         gb = (ctypes.c_int32 * (world + 1))(*base)
-    if kernel_timer.enabled:
+    if kernel_timer.enabled and 0 < n <= SMALL_N_FUSED:      # (what ts_shard_owner_fwd_padded issues for a small shard)
+        _call("ts_owner_fwd_fused", lib.ts_shard_owner_fwd_fused, n, int(sh_degree), nb, fr.means, fr.scales, fr.quats,
+              fr.view34, fr.projview, O.cam, 3, fr.origin, fr.colors_dc, fr.colors_rest if nb > 1 else None, fr.opacities,
+              ch, 1, fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, fr.sh_mask, fr.splats, layout.c_stripes,
+              gb, O.p_route_ws, counts.data_ptr(), s)
+    elif kernel_timer.enabled:
         _call("ts_project_fwd", lib.ts_project_fwd, n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview, O.cam, 3,
               fr.xys, fr.depths, fr.radii, fr.conics, fr.num_tiles_hit, None, s)
         # colour stage + packed records of the owned Gaussians (slot fields are rewritten by the importing rank)

@@ -466,6 +466,16 @@ int ts_shard_owner_fwd_fused(int32_t n, int32_t degrees_to_use, int32_t num_base
                              int32_t raster_flags, float* xys, float* depths, int32_t* radii, float* conics,
                              int32_t* num_tiles_hit, uint8_t* clamp_mask, float* splats, const ts_stripes* stripes_host,
                              const int32_t* group_base_host, int32_t* route_ws, int32_t* counts, void* stream);
+/* ... and its backward pass in one launch (what ts_shard_owner_bwd issues for such a shard): ts_route_accumulate,
+ * ts_sh_colors_bwd (no mask: it was applied to the sums) and ts_project_bwd (flags 3) in the lane that owns the Gaussian;
+ * the same bits in v_xy / v_conic / v_colors / v_depth / v_opacity and the six parameter gradients. */
+int ts_shard_owner_bwd_fused(int32_t n, int32_t channels, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                             const float* scales, const float* quats, const float* view34, const float* projview,
+                             const float* origin, const float* xys, const int32_t* radii, const float* splats,
+                             const uint8_t* color_mask, const ts_camera* cam_host, const ts_stripes* stripes_host,
+                             const int32_t* route_ws, const float* grad_rows, float* v_xy, float* v_conic,
+                             float* v_colors, float* v_depth, float* v_opacity, float* v_colors_dc, float* v_colors_rest,
+                             float* v_means3d, float* v_scales, float* v_quats, void* stream);
 int ts_shard_stripe_fwd_import(const ts_frame* fs, const float* records, void* stream);
 int ts_shard_stripe_bwd(const ts_frame* fs, float* grad_rows, void* stream);
 int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes_host, const int32_t* route_ws,

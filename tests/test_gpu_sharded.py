@@ -156,6 +156,36 @@ def test_fused_owner_forward_writes_the_bits_of_its_three_launches(n, sh, depth)
     assert torch.equal(a["splats"][vis].view(torch.int32), b["splats"][vis].view(torch.int32))
     assert torch.equal(a["mask"][vis], b["mask"][vis])
     assert int(b["counts"].sum()) >= int(vis.sum())
+    # ... and the backward pass: random rows "returned" for every record of the (unpadded-size) groups
+    rows_n = 4 * n
+    g = torch.Generator().manual_seed(62)
+    back = torch.randn(rows_n, 12, generator=g).to(DEV)
+    K = nb - 1
+
+    def grads():
+        f32 = dict(dtype=torch.float32, device=DEV)
+        return dict(v_xy=torch.zeros(n, 2, **f32), v_conic=torch.zeros(n, 3, **f32), v_colors=torch.zeros(n, 3, **f32),
+                    v_depth=torch.zeros(n, **f32), v_opac=torch.zeros(n, **f32), v_dc=torch.zeros(n, 3, **f32),
+                    v_rest=torch.full((n, max(K, 1), 3), 7.0, **f32), v_means=torch.zeros(n, 3, **f32),
+                    v_scales=torch.zeros(n, 3, **f32), v_quats=torch.zeros(n, 4, **f32))
+    ga, gf = grads(), grads()
+    vd = lambda t: P(t["v_depth"]) if depth else None
+    assert lib.ts_route_accumulate(n, ch, P(a["xys"]), P(a["radii"]), P(a["splats"]), P(a["mask"]), c, lay.c_stripes,
+                                   P(a["ws"]), P(back), P(ga["v_xy"]), P(ga["v_conic"]), P(ga["v_colors"]), vd(ga),
+                                   P(ga["v_opac"]), s) == 0
+    assert lib.ts_sh_colors_bwd(n, sh, nb, P(means), P(origin), None, P(ga["v_colors"]), P(ga["v_dc"]),
+                                P(ga["v_rest"]) if K > 0 else None, s) == 0
+    assert lib.ts_project_bwd(n, P(means), P(scales), P(quats), P(view34), P(projview), c, 3, P(a["radii"]), P(ga["v_xy"]),
+                              vd(ga), P(ga["v_conic"]), None, P(ga["v_means"]), P(ga["v_scales"]), P(ga["v_quats"]), s) == 0
+    assert lib.ts_shard_owner_bwd_fused(n, ch, sh, nb, P(means), P(scales), P(quats), P(view34), P(projview), P(origin),
+                                        P(b["xys"]), P(b["radii"]), P(b["splats"]), P(b["mask"]), c, lay.c_stripes,
+                                        P(b["ws"]), P(back), P(gf["v_xy"]), P(gf["v_conic"]), P(gf["v_colors"]), vd(gf),
+                                        P(gf["v_opac"]), P(gf["v_dc"]), P(gf["v_rest"]) if K > 0 else None,
+                                        P(gf["v_means"]), P(gf["v_scales"]), P(gf["v_quats"]), s) == 0
+    torch.cuda.synchronize()
+    for k in ga:
+        assert torch.equal(ga[k], gf[k]), k
+    assert ga["v_means"].abs().max().item() > 0
 
 
 @pytest.mark.parametrize("world,depth,n,sh,w,h,mult,stripes", [

@@ -143,6 +143,8 @@ SIGNATURES = {
     "ts_shard_owner_fwd_padded": (c_int32, [_FRAME, _STRIPES, _P, _P, _P, _P]),
     "ts_shard_owner_fwd_fused": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P,
                                            c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _STRIPES, _P, _P, _P, _P]),
+    "ts_shard_owner_bwd_fused": (c_int32, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                           _CAM, _STRIPES, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ts_shard_stripe_fwd_import": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_stripe_bwd": (c_int32, [_FRAME, _P, _P]),
     "ts_shard_owner_bwd": (c_int32, [_FRAME, _STRIPES, _P, _P, _P]),

@@ -255,6 +255,13 @@ int ts_shard_owner_bwd(const ts_frame* fo, const ts_stripes* stripes, const int3
                        const float* grad_rows, void* stream) {
     TsRange range_("ts_shard_owner_bwd");
     if (bad(fo) || !stripes) return TS_E_BADARG;
+    if (fo->n > 0 && fo->n <= small_n_fused())          // a small shard: one launch instead of three (shard.hip)
+        return ts_shard_owner_bwd_fused(fo->n, fo->channels, fo->sh_degree, fo->num_bases, fo->means, fo->scales, fo->quats,
+                                        fo->view34, fo->projview, fo->origin, fo->xys, fo->radii, fo->splats, fo->sh_mask,
+                                        &fo->cam, stripes, route_ws, grad_rows, fo->v_xy, fo->v_conic, fo->v_colors,
+                                        fo->channels == 4 ? fo->v_depth : nullptr, fo->v_opacity, fo->v_colors_dc,
+                                        fo->num_bases > 1 ? fo->v_colors_rest : nullptr, fo->v_means, fo->v_scales,
+                                        fo->v_quats, stream);
     TS_TRY(ts_route_accumulate(fo->n, fo->channels, fo->xys, fo->radii, fo->splats, fo->sh_mask, &fo->cam, stripes,
                                route_ws, grad_rows, fo->v_xy, fo->v_conic, fo->v_colors,
                                fo->channels == 4 ? fo->v_depth : nullptr, fo->v_opacity, stream));

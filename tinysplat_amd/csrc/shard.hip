@@ -319,6 +319,97 @@ __global__ __launch_bounds__(kThreads) void route_accumulate_kernel(
 }
 
 // record -> the per-Gaussian arrays binning takes, for the importing rank's stripe
+// FUSED OWNER BACKWARD (small N, as owner_fwd_kernel): the rows that came back summed per owned Gaussian
+// (route_accumulate_kernel), the colour stage's backward (project.hip: sh_colors_bwd_kernel without a mask - it was
+// applied to the sums) and the projection's backward (project_bwd_kernel, flags 3) in the lane that owns the Gaussian:
+// the 2-D gradients stay in registers, two launch boundaries less.  Same device functions, same order: same bits.
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void owner_bwd_kernel(
+    int n, int channels, int num_bases, const float* __restrict__ means3d, const float* __restrict__ scales,
+    const float* __restrict__ quats, const float* __restrict__ viewmat, const float* __restrict__ projmat,
+    const float* __restrict__ origin, const float* __restrict__ xys, const int* __restrict__ radii,
+    const float4* __restrict__ splats, const unsigned char* __restrict__ color_mask, const ts_camera cam,
+    const ts_stripes st, const int* __restrict__ block_base, const int* __restrict__ seg,
+    const float4* __restrict__ rows, float* __restrict__ v_xy, float* __restrict__ v_conic,
+    float* __restrict__ v_colors, float* __restrict__ v_depth, float* __restrict__ v_opacity,
+    float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_means3d,
+    float* __restrict__ v_scales, float* __restrict__ v_quats) {
+    constexpr int KA = (DEG + 1) * (DEG + 1);
+    __shared__ int cnt[kWaves][TS_MAX_RANKS];
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const DestRange r = dest_range(i, n, xys, radii, cam, st);
+    for (int d = 0; d < st.num; ++d) {
+        const unsigned long long m = __ballot(r.d0 <= d && d <= r.d1);
+        if (lane == 0) cnt[wave][d] = __popcll(m);
+    }
+    __syncthreads();
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    for (int d = 0; d < st.num; ++d) {
+        const bool mine = r.d0 <= d && d <= r.d1;
+        const unsigned long long m = __ballot(mine);          // whole wave, every iteration (see route_pack_kernel)
+        int pos = seg[d] + block_base[(size_t)d * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) pos += cnt[w][d];
+        if (mine) {
+            const float4 p0 = rows[3 * (size_t)pos], p1 = rows[3 * (size_t)pos + 1], p2 = rows[3 * (size_t)pos + 2];
+            a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+            a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+            a2.x += p2.x; a2.y += p2.y;
+        }
+    }
+    if (i >= n) return;
+    if (r.d0 <= r.d1) {
+        const float op = splats[3 * (size_t)i].z;
+        a2.y *= op * (1.0f - op);                        // through the sigmoid of rasterize.py:86
+        if (color_mask) {
+            const int mk = color_mask[i];
+            if (!(mk & 1)) a1.y = 0.0f;
+            if (!(mk & 2)) a1.z = 0.0f;
+            if (!(mk & 4)) a1.w = 0.0f;
+        }
+    }
+    reinterpret_cast<float2*>(v_xy)[i] = make_float2(a0.x, a0.y);
+    v_conic[3 * i] = a0.z; v_conic[3 * i + 1] = a0.w; v_conic[3 * i + 2] = a1.x;
+    v_colors[3 * i] = a1.y; v_colors[3 * i + 1] = a1.z; v_colors[3 * i + 2] = a1.w;
+    const bool with_depth = channels == 4 && v_depth;
+    if (with_depth) v_depth[i] = a2.x;
+    v_opacity[i] = a2.y;
+    const float m3[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
+    {   // colour stage, backward: v_dc = Y0 v, row k of v_rest = Y_k v (inactive bands: zeros)
+        float Y[KA];
+        ts::sh_basis(DEG, m3[0] - origin[0], m3[1] - origin[1], m3[2] - origin[2], Y);
+        const float v0 = a1.y, v1 = a1.z, v2 = a1.w;
+        v_dc[3 * i] = Y[0] * v0; v_dc[3 * i + 1] = Y[0] * v1; v_dc[3 * i + 2] = Y[0] * v2;
+        const int RS = 3 * (num_bases - 1);
+        float* row = v_rest + (size_t)i * RS;
+#pragma unroll
+        for (int k = 1; k < KA; ++k) {
+            row[3 * (k - 1)] = Y[k] * v0; row[3 * (k - 1) + 1] = Y[k] * v1; row[3 * (k - 1) + 2] = Y[k] * v2;
+        }
+        for (int j = 3 * (KA - 1); j < RS; ++j) row[j] = 0.0f;
+    }
+    ts::ProjGrad g;
+    for (int k = 0; k < 3; ++k) { g.v_mean[k] = 0.0f; g.v_scale[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) g.v_quat[k] = 0.0f;
+    if (radii[i] > 0) {
+        const ts::Cam C = load_cam(viewmat, projmat, cam);
+        float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        float inv_n = 1.0f;
+        prep_inputs(3, sc, q, &inv_n);
+        const float vx[2] = {a0.x, a0.y};
+        const float vc[3] = {a0.z, a0.w, a1.x};
+        ts::project_one_vjp(C, m3, sc, q, vx, with_depth ? a2.x : 0.0f, vc, nullptr, g);
+        g.v_scale[0] *= sc[0]; g.v_scale[1] *= sc[1]; g.v_scale[2] *= sc[2];            // d exp(x) = exp(x) dx
+        const float dotp = q[0] * g.v_quat[0] + q[1] * g.v_quat[1] + q[2] * g.v_quat[2] + q[3] * g.v_quat[3];
+        for (int k = 0; k < 4; ++k) g.v_quat[k] = (g.v_quat[k] - q[k] * dotp) * inv_n;  // q_hat = q / |q|
+    }
+    v_means3d[3 * i] = g.v_mean[0]; v_means3d[3 * i + 1] = g.v_mean[1]; v_means3d[3 * i + 2] = g.v_mean[2];
+    v_scales[3 * i] = g.v_scale[0]; v_scales[3 * i + 1] = g.v_scale[1]; v_scales[3 * i + 2] = g.v_scale[2];
+    reinterpret_cast<float4*>(v_quats)[i] = make_float4(g.v_quat[0], g.v_quat[1], g.v_quat[2], g.v_quat[3]);
+}
+
 __global__ __launch_bounds__(kThreads) void import_records_kernel(int m, const float4* __restrict__ records,
                                                                   const ts_camera cam, float* __restrict__ xys,
                                                                   float* __restrict__ depths,
@@ -494,6 +585,40 @@ int ts_shard_owner_fwd_fused(int32_t n, int32_t degrees_to_use, int32_t num_base
 #undef TS_OWNER_FWD
     hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, blocks, (int)stripes->num, route_ws,
                        route_ws + (size_t)blocks * stripes->num, counts, gb);
+    return launch_status();
+}
+
+int ts_shard_owner_bwd_fused(int32_t n, int32_t channels, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                             const float* scales, const float* quats, const float* viewmat, const float* projmat,
+                             const float* origin, const float* xys, const int32_t* radii, const float* splats,
+                             const uint8_t* color_mask, const ts_camera* cam, const ts_stripes* stripes,
+                             const int32_t* route_ws, const float* grad_rows, float* v_xy, float* v_conic,
+                             float* v_colors, float* v_depth, float* v_opacity, float* v_colors_dc, float* v_colors_rest,
+                             float* v_means3d, float* v_scales, float* v_quats, void* stream) {
+    if (n < 0 || !cam || bad_stripes(stripes, cam) || !route_ws || (channels != 3 && channels != 4) ||
+        degrees_to_use < 0 || degrees_to_use > 4 || num_bases < (degrees_to_use + 1) * (degrees_to_use + 1))
+        return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!means3d || !scales || !quats || !viewmat || !projmat || !origin || !xys || !radii || !splats || !grad_rows ||
+        !v_xy || !v_conic || !v_colors || !v_opacity || !v_colors_dc || (num_bases > 1 && !v_colors_rest) || !v_means3d ||
+        !v_scales || !v_quats)
+        return TS_E_BADARG;
+    const int blocks = route_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+#define TS_OWNER_BWD(D)                                                                                            \
+    hipLaunchKernelGGL(owner_bwd_kernel<D>, dim3(blocks), dim3(kThreads), 0, s, n, (int)channels, (int)num_bases,  \
+                       means3d, scales, quats, viewmat, projmat, origin, xys, radii,                               \
+                       reinterpret_cast<const float4*>(splats), color_mask, *cam, *stripes, route_ws,              \
+                       route_ws + (size_t)blocks * stripes->num, reinterpret_cast<const float4*>(grad_rows), v_xy, \
+                       v_conic, v_colors, v_depth, v_opacity, v_colors_dc, v_colors_rest, v_means3d, v_scales, v_quats)
+    switch (degrees_to_use) {
+        case 0: TS_OWNER_BWD(0); break;
+        case 1: TS_OWNER_BWD(1); break;
+        case 2: TS_OWNER_BWD(2); break;
+        case 3: TS_OWNER_BWD(3); break;
+        default: TS_OWNER_BWD(4); break;
+    }
+#undef TS_OWNER_BWD
     return launch_status();
 }
 

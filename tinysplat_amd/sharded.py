@@ -678,7 +678,12 @@ def _owner_backward(lib, s, dev, layout: ShardLayout, O: _Owner, back: Tensor, s
     fr.v_conic, fr.v_colors, fr.v_depth = tmp.data_ptr(), tmp.data_ptr() + 12 * nn, tmp.data_ptr() + 24 * nn
     fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
     fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
-    if kernel_timer.enabled:
+    if kernel_timer.enabled and 0 < n <= SMALL_N_FUSED:      # (what ts_shard_owner_bwd issues for a small shard)
+        _call("ts_owner_bwd_fused", lib.ts_shard_owner_bwd_fused, n, ch, sh_degree, O.nb, fr.means, fr.scales, fr.quats,
+              fr.view34, fr.projview, fr.origin, fr.xys, fr.radii, fr.splats, fr.sh_mask, O.cam, layout.c_stripes,
+              O.p_route_ws, back.data_ptr(), fr.v_xy, fr.v_conic, fr.v_colors, fr.v_depth if ch == 4 else None,
+              fr.v_opacity, fr.v_colors_dc, fr.v_colors_rest if O.nb > 1 else None, fr.v_means, fr.v_scales, fr.v_quats, s)
+    elif kernel_timer.enabled:
         _call("ts_route_accumulate", lib.ts_route_accumulate, n, ch, fr.xys, fr.radii, fr.splats, fr.sh_mask, O.cam,
               layout.c_stripes, O.p_route_ws, back.data_ptr(), fr.v_xy, fr.v_conic, fr.v_colors,
               fr.v_depth if ch == 4 else None, fr.v_opacity, s)

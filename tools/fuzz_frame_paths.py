@@ -42,6 +42,9 @@ def main(cases=16, seed=0):
         wr, wd = torch.rand(h, w, 3, generator=g).to(DEV), torch.rand(h, w, generator=g).to(DEV)
         msgs = []
         frame.SPLIT_BLOCKS_BELOW, frame.TIGHT_BINNING = 0, True
+        # (bitwise comparisons across list shapes need the uncut backward pass: a hybrid launch - from 1 537 tiles - cuts
+        # lists at boundaries that follow their length, and its gradients equal the uncut pass's to rounding)
+        keep_segs, frame.HYBRID_SEGS = frame.HYBRID_SEGS, 1
         base, md, r = run(model, cam, w, h, sh, wr, wd)
         ops_path, _, _ = run(model, cam, w, h, sh, wr, wd, single_node=False)
         if not all(torch.equal(a, b) for a, b in zip(base, ops_path)):
@@ -60,7 +63,29 @@ def main(cases=16, seed=0):
                 msgs.append(f"split grads differ: max |diff| {(a - b).abs().max().item():.3e} at scale "
                             f"{b.abs().max().item():.3e}, shape {tuple(a.shape)}")
                 break
+        frame.HYBRID_SEGS = keep_segs
+        # cooperative tiles: in place of the split forward pass (every bit of the split frame) ...
+        keep_cs = frame.COOP_SPLIT
+        frame.COOP_SPLIT = not keep_cs
+        other, _, _ = run(model, cam, w, h, sh, wr, wd)
+        frame.COOP_SPLIT = keep_cs
+        if not all(torch.equal(a, b) for a, b in zip(split, other)):
+            msgs.append("cooperative != split forward pass")
         frame.SPLIT_BLOCKS_BELOW = 0
+        # ... and in the tail of a one-wave-per-tile launch, with and without the hybrid backward launch (forced on)
+        keep_h = (frame.HYBRID_FROM, frame.HYBRID_MID_FROM, frame.HYBRID_COOP16, frame.HYBRID_SEGS, frame.WIDE_TILES)
+        frame.HYBRID_FROM, frame.HYBRID_MID_FROM, frame.WIDE_TILES = 1, 1 << 30, 0
+        for segs in (1, 8):
+            frame.HYBRID_SEGS = segs
+            res = []
+            for c16 in (0, rnd.choice([1, 3, 7, 15])):
+                frame.HYBRID_COOP16 = c16
+                res.append(run(model, cam, w, h, sh, wr, wd)[0])
+            if not all(torch.equal(a, b) for a, b in zip(res[0], res[1])):
+                msgs.append(f"cooperative tiles change bits (segments {segs})")
+            if segs == 1 and not all(torch.equal(a, b) for a, b in zip(res[0], base)):
+                msgs.append("forced launch shape without segments != base")
+        frame.HYBRID_FROM, frame.HYBRID_MID_FROM, frame.HYBRID_COOP16, frame.HYBRID_SEGS, frame.WIDE_TILES = keep_h
         tby = (h + 15) // 16
         if tby >= 2:
             parts = []

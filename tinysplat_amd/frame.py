@@ -156,13 +156,15 @@ def backward_segments(cam, segs: int, total: int, dev_index: int = 0) -> int:
 # raster_fwd 0.25 -> 0.39 ms, raster_bwd 0.55 -> 0.71 ms on config 3, because 150-170 VGPRs leave 3 waves per
 # SIMD instead of 4-5.  The drop-in op keeps gsplat's 16x16 lists.
 # TS_WIDE_TILES = 0 | 1 | 2 | auto (default): mode 2 where the lists are long - the previous frame on the
-# device averaged >= WIDE_LISTS_FROM bounding-box pairs per 16x16 tile (config 5: 2 490; config 3: 766, where
-# the two modes are within 1 % of each other and mode 0 keeps the compositing kernels' own time lowest) -
+# device averaged >= WIDE_LISTS_FROM bounding-box pairs per 16x16 tile (config 5: 2 490; config 3: 766).  The
+# threshold was 1 000 until the hybrid backward launch and the cooperative forward tiles (16x16 lists only) existed;
+# with them mode 0 wins up to ~2 200 pairs per tile (tools/list_mode_check.sh: 1 M / 2 M at 1280x720 0.96 -> 0.92,
+# 1.19 -> 1.11 ms; 2.5 M at 1080p 1.61 -> 1.57) and mode 2 beyond (4 M at 1080p 2.07 -> 2.01, config 5 4.64 -> 3.71) -
 # mode 0 otherwise; a first frame goes by its tile count (4K-class frames start wide).  Modes 0 and 2 run the
 # same per-tile arithmetic on the same Gaussians in the same order, so switching never changes a result.
 _wt = os.environ.get("TS_WIDE_TILES", "auto")
 WIDE_TILES = _wt if _wt == "auto" else int(_wt)
-WIDE_LISTS_FROM = int(os.environ.get("TS_WIDE_LISTS_FROM", "1000"))
+WIDE_LISTS_FROM = int(os.environ.get("TS_WIDE_LISTS_FROM", "2300"))
 BALANCED_WALK_FROM = float(os.environ.get("TS_BALANCED_WALK_FROM", "10"))     # bounding-box tiles per Gaussian
 _pairs_per_tile = {}    # device index -> bounding-box pairs per 16x16 tile of the most recent frame
 

@@ -209,10 +209,10 @@ def test_balanced_walk_hint_changes_no_result(n, sh, w, h, mult, monkeypatch):
     listed = int(frame.last_binning[DEV.index].tile_bins[:, 1].max().item())      # tight lists: fewer than I entries
     ids_ref = frame.last_binning[DEV.index].gaussian_ids_sorted[:listed].clone()
     bins_ref = frame.last_binning[DEV.index].tile_bins.clone()
-    assert frame.last_binning[DEV.index].cam.hints == 0
+    assert frame.last_binning[DEV.index].cam.hints & 0xFF == 0          # (bits 8..: the compositing launches' fields)
     monkeypatch.setattr(frame, "BALANCED_WALK_FROM", 0.0)
     got = _run(model, cam, w, h, True, w_rgb, w_d)
-    assert frame.last_binning[DEV.index].cam.hints == 1
+    assert frame.last_binning[DEV.index].cam.hints & 0xFF == 1
     assert torch.equal(frame.last_binning[DEV.index].tile_bins, bins_ref)
     assert torch.equal(frame.last_binning[DEV.index].gaussian_ids_sorted[:listed], ids_ref)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])

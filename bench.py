@@ -708,6 +708,25 @@ def main():
     if args.gather_calibration and rank == 0:
         run_gather_calibration(dev)
 
+    # the same step with D2's loss evaluated by torch kernels inside it, as rounds 1 - 4 timed it (a sub-record, so that
+    # the series stays comparable: `value` is the step with the analytic upstream gradient)
+    with_loss = None
+    if (world == 1 and args.upstream == "grad" and not args.forward_only and not args.train_step
+            and args.emulate_ranks <= 1 and not args.force_dist):
+        args.upstream = "loss"
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k_loss = max(5, min(args.steps, 50))
+        for _ in range(k_loss):
+            step()
+        torch.cuda.synchronize()
+        with_loss = {"ms_per_step": (time.perf_counter() - t1) / k_loss * 1e3, "steps": k_loss,
+                     "note": "--upstream loss: torch's dot / fill / mul kernels of L = (rgb * w).sum() inside the step "
+                             "(what rounds 1 - 4 reported)"}
+        args.upstream = "grad"
+
     # second figure: the reference's whole adapter call renders RGB AND depth (rasterize.py:47-51); the headline
     # workload (D5) is RGB only, so the like-for-like frame is timed beside it
     rgbd = None
@@ -979,6 +998,8 @@ def main():
                 out["multi_gpu"]["replicated_mode"] = second
         if rgbd is not None:
             out["frame_rgbd"] = rgbd
+        if with_loss is not None:
+            out["with_loss_kernels"] = with_loss
         if pmc:
             out["pmc_per_dispatch"] = {e: {k_: round(v, 1) for k_, v in c.items()} for e, c in sorted(pmc.items())}
         if world == 1 and not args.no_cpu_baseline:

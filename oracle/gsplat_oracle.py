@@ -41,6 +41,10 @@ ALPHA_MIN = 1.0 / 255.0     # contribution threshold
 T_EPS = 1e-4                # transmittance early-termination threshold
 F32_SIGMA_ULPS = 2.0         # unit roundoffs (2^-24 of the largest term) one float32 evaluation of sigma may be off by: ~5 roundings, measured 0.1-0.5 (checker margins only)
 PIXEL_CENTER_OFFSET = 0.0   # pixel (j, i) is sampled at (j + off, i + off); 0.1.3-era: 0
+# does the EWA backward see the 1.3 tan(fov) clamp?  False (default): autograd of the forward pass - a
+# clamped coordinate passes no gradient.  True: upstream's project_cov3d_ewa_vjp as App. A.6 recalls it - J is evaluated
+# at the clamped t and v_t goes to the view-space mean as if no clamp had acted (the HIP build: -DTS_FOV_CLAMP_BWD_UNGATED=1)
+FOV_CLAMP_BWD_UNGATED = False
 
 SH_C0 = 0.28209479177387814          # == tinysplat/utils.py:8
 SH_C1 = 0.4886025119029199
@@ -165,6 +169,18 @@ def tile_bbox(xys: Tensor, radii_f: Tensor, tile_bounds):
     return (minx.to(torch.int32), miny.to(torch.int32), maxx.to(torch.int32), maxy.to(torch.int32))
 
 
+class _StraightThrough(torch.autograd.Function):
+    """forward: `value` (bit for bit); backward: the whole gradient goes to `passthrough`, none to `value`"""
+
+    @staticmethod
+    def forward(ctx, passthrough, value):
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
                       viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
                       img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
@@ -207,6 +223,9 @@ def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats:
     limy = 1.3 * ((0.5 * H_t) / fy_t)
     tx = pz_s * torch.minimum(limx, torch.maximum(-limx, px / pz_s))
     ty = pz_s * torch.minimum(limy, torch.maximum(-limy, py / pz_s))
+    if FOV_CLAMP_BWD_UNGATED:          # App. C #4, upstream's reading: same values, v_t lands on the view-space mean
+        tx = _StraightThrough.apply(px, tx)
+        ty = _StraightThrough.apply(py, ty)
     rz = 1.0 / pz_s
     rz2 = rz * rz
     j00 = fx_t * rz

@@ -16,7 +16,7 @@ def scene_args(n, sh_degree, width, height, seed=0, scale_mult=1.0, device="cpu"
     return model, cam
 
 
-def oracle_frame(model, cam, dims, depth=True, raster_dtype=None):
+def oracle_frame(model, cam, dims, depth=True, raster_dtype=None, correct_viewdirs=False):
     """The reference frame recipe (rasterize.py:26-62) executed with the oracle ops on CPU.
     ``raster_dtype=torch.float64``: projection, SH and binning as given (float32, bit-exact radii and
     lists), compositing arithmetic in float64 on those 2-D inputs."""
@@ -24,7 +24,7 @@ def oracle_frame(model, cam, dims, depth=True, raster_dtype=None):
     xys, depths, radii, conics, nth, cov3d = O.project_gaussians(*pa)
     if xys.requires_grad:
         xys.retain_grad()
-    colors = torch.clamp(O.spherical_harmonics(*sh_args(model, cam, "cpu")) + 0.5, min=0.0)
+    colors = torch.clamp(O.spherical_harmonics(*sh_args(model, cam, "cpu", correct_viewdirs)) + 0.5, min=0.0)
     rgb, _, aux = O.rasterize_gaussians(*raster_args(model, xys, depths, radii, conics, nth, colors, dims),
                                         return_aux=True, compute_dtype=raster_dtype)
     rgb = torch.clamp(rgb, max=1.0)

@@ -227,3 +227,23 @@ def test_rescale_of_a_directly_constructed_camera_and_reorder_guard():
     Densifier(model)
     with pytest.raises(RuntimeError, match="held by"):
         model.spatial_sort_()
+
+
+def test_sh_origin_reference_quirk_and_the_corrected_point():
+    """SURVEY App. C #9 (host logic, no GPU): by default the SH view directions start at ``view_matrix[:3, 3]`` (the
+    reference, rasterize.py:77); ``correct_viewdirs`` gives the camera centre - the `position` the reference's
+    ``update_view_matrix`` was called with (scene.py:96-107: inv(view_mat)[:3, 3] == position)."""
+    import numpy as np
+    from tinysplat_amd.rasterizer import sh_args, sh_origin
+    from tinysplat_amd.synthetic import make_scene
+    model, cam = make_scene(50, 1, 64, 48, seed=3)
+    pos, q = np.array([0.4, -1.1, 0.7]), np.array([0.9, 0.1, -0.4, 0.2])
+    cam.update_view_matrix(pos, q / np.linalg.norm(q))
+    vm = cam.view_matrix
+    assert torch.equal(sh_origin(vm), vm[:3, 3])
+    assert torch.allclose(sh_origin(vm, True), torch.as_tensor(pos, dtype=torch.float32), atol=1e-6)
+    assert torch.allclose(sh_origin(vm, True), torch.linalg.inv(vm)[:3, 3], atol=1e-6)
+    d0, d1 = sh_args(model, cam, "cpu")[1], sh_args(model, cam, "cpu", True)[1]
+    want = model.means - torch.as_tensor(pos, dtype=torch.float32)
+    assert torch.allclose(d1, want / want.norm(dim=-1, keepdim=True), atol=1e-5)
+    assert (d0 - d1).abs().max() > 0.1

@@ -236,6 +236,56 @@ def test_rank_executor_with_replayed_records():
         assert float(res[0][2].abs().max()) > 0
 
 
+def test_rank_state_is_reclaimed_when_a_frame_is_dropped_without_backward():
+    """a grad-enabled forward whose backward pass never comes (a preview render, an exception in the loss)
+    must not leave the layout's state busy for good - the next frame runs from the state again -, a frame that starts
+    while an earlier one still waits takes the stage functions, and a second backward pass over a retained graph
+    raises instead of reading buffers that later frames own."""
+    from tinysplat_amd import sharded
+    from tinysplat_amd.sharded import ReplayExchange, render_sharded
+    n, sh, w, h, world, rank = 30000, 1, 480, 272, 2, 0
+    model, cam = make_scene(n, sh, w, h, seed=5, scale_mult=2.0)
+    lay = ShardLayout(n, world, rank, (w, h))
+    parts, counts = [], []
+    for src in range(world):
+        rec, cnt = export_records(shard_model(model, world, src).to(DEV), cam, DEV, lay.for_rank(src), False)
+        off = sum(cnt[:rank])
+        parts.append(rec[off:off + cnt[rank]].clone())
+        counts.append(cnt[rank])
+    ex = ReplayExchange(rank, counts, torch.cat(parts, dim=0))
+    shard = shard_model(model, world, rank).to(DEV).requires_grad_(True)
+    w_rgb, _ = (t.to(DEV) for t in loss_weights(w, h))
+
+    def frame(backward=True, retain=False):
+        for p in shard.parameters():
+            p.grad = None
+        out, (y0, y1), xys = render_sharded(shard, cam, DEV, lay, ex, with_depth=False)
+        loss = (out * w_rgb[y0:y1]).sum()
+        if backward:
+            loss.backward(retain_graph=retain)
+        return loss, [p.grad.clone() for p in shard.parameters()] if backward else None
+
+    _, want = frame()                                   # frame 1: stage functions, sizes the state
+    base = list(sharded.rank_executor_frames)
+    loss, _ = frame(backward=False)                     # from the state; its backward pass never comes
+    del loss                                            # the graph is freed: the state is free again
+    _, got = frame()
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [2, 0, 0]
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    held, _ = frame(backward=False)                     # a frame that keeps waiting ...
+    base = list(sharded.rank_executor_frames)
+    _, got = frame()                                    # ... sends the next one through the stage functions
+    assert [a - b for a, b in zip(sharded.rank_executor_frames, base)] == [0, 0, 1]
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    for p in shard.parameters():
+        p.grad = None
+    held.backward()                                     # and its own backward pass still finds its buffers
+    assert all(torch.equal(a, p.grad) for a, p in zip(want, shard.parameters()))
+    loss, _ = frame(retain=True)
+    with pytest.raises(RuntimeError, match="released by its first backward"):
+        loss.backward()
+
+
 def test_work_balanced_stripes_on_a_skewed_scene():
     """SURVEY 8(e) E2's option: stripes balanced by the previous frame's per-row work.  On a scene with 70 % of its
     Gaussians in the top third of the image, equal rows leave one rank with ~2.5x the mean work; the balanced cut

@@ -1,5 +1,6 @@
-"""SURVEY.md App. C's two open semantic choices are compile-time switches of the HIP library (csrc/splat_math.h:
-TS_PIX_OFF, TS_BWD_CLAMP_UPSTREAM).  The default build takes the survey's reading; here the OTHER setting of each is
+"""SURVEY.md App. C's open semantic choices in the device code are compile-time switches of the HIP library
+(csrc/splat_math.h: TS_PIX_OFF, TS_BWD_CLAMP_UPSTREAM, TS_FOV_CLAMP_BWD_UNGATED; App. C #9, the SH view directions, is a
+run-time flag of the adapter and is tested below without a build).  The default build takes the survey's reading; here the OTHER setting of each is
 built (hipcc, sources in parallel, into a temporary directory) and checked against the oracle with the same constant,
 in a process of its own (TS_LIB_PATH) - so that vectors from a pinned gsplat, should they ever exist, are a one-line
 flip and not a debugging session."""
@@ -14,7 +15,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("mode,flags", [("pixoff", ["-DTS_PIX_OFF=0.5f"]), ("bwdclamp", ["-DTS_BWD_CLAMP_UPSTREAM=1"])])
+@pytest.mark.parametrize("mode,flags", [("pixoff", ["-DTS_PIX_OFF=0.5f"]), ("bwdclamp", ["-DTS_BWD_CLAMP_UPSTREAM=1"]),
+                                        ("fovclamp", ["-DTS_FOV_CLAMP_BWD_UNGATED=1"])])
 def test_other_setting_of_the_app_c_switches(tmp_path, mode, flags):
     from tinysplat_amd import _build
     lib = _build.build_variant(tmp_path / mode, flags, jobs=8)
@@ -22,3 +24,37 @@ def test_other_setting_of_the_app_c_switches(tmp_path, mode, flags):
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "variant_worker.py"), mode], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and f"variant {mode} ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_correct_viewdirs_flag_against_the_oracle():
+    """``GaussianRasterizer(correct_viewdirs=True)`` takes the SH view directions from the camera
+    centre instead of the view matrix's translation column (rasterize.py:77).  A rotated, displaced camera (the two
+    points differ), SH degree 3: the frame against the oracle frame with the same choice, and the two choices differ."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import assert_close_masked, check_grad, oracle_frame, scene_args
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    dev = "cuda:0"
+    n, sh, w, h = 5000, 3, 160, 96
+    model, cam = scene_args(n, sh, w, h, seed=81, scale_mult=3.0)
+    q = np.array([0.96, 0.05, 0.27, -0.03])
+    cam.update_view_matrix(np.array([0.8, -0.5, -0.6]), q / np.linalg.norm(q))
+    ref, _ = scene_args(n, sh, w, h, seed=81, scale_mult=3.0)
+    ref.requires_grad_(True)
+    f = oracle_frame(ref, cam, (w, h), depth=False, correct_viewdirs=True)
+    f0 = oracle_frame(ref, cam, (w, h), depth=False)
+    stable = f["aux"]["margin"] > 1e-4
+    g = torch.Generator().manual_seed(82)
+    w_rgb = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    (f["rgb"] * w_rgb).sum().backward()
+    md = model.to(dev).requires_grad_(True)
+    rgb, extras = GaussianRasterizer(md, None, device=torch.device(dev), correct_viewdirs=True)(cam, (w, h), sh)
+    (rgb * w_rgb.to(dev)).sum().backward()
+    assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb (view directions from the camera centre)")
+    for a, b, nm in [(md.means, ref.means, "means"), (md.colors_dc, ref.colors_dc, "colors_dc"), (md.colors_rest, ref.colors_rest, "rest")]:
+        check_grad(nm + " (correct_viewdirs)", a.grad, b.grad, rel=2e-5)
+    assert ((rgb.detach().cpu() - f0["rgb"].detach()).abs() * stable[..., None]).max() > 1e-3     # the quirk is visible
+    # the op-by-op recipe takes the same flag
+    rgb2, _ = GaussianRasterizer(md, None, device=torch.device(dev), fused_colors=False, correct_viewdirs=True)(cam, (w, h), sh)
+    assert_close_masked(rgb2, f["rgb"], 1e-5, stable, what="rgb (op-by-op recipe, camera centre)")

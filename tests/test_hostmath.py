@@ -103,6 +103,45 @@ def test_project_bwd_fov_clamp_branch(hostmath):
     assert err < 2e-4, err
 
 
+def test_project_bwd_fov_clamp_ungated_build(tmp_path):
+    """SURVEY App. C #4, the OTHER setting: splat_math.h built with -DTS_FOV_CLAMP_BWD_UNGATED=1 (upstream's EWA VJP as
+    App. A.6 recalls it: the clamp is invisible to the backward pass) against the oracle with the same switch - and the
+    two settings really differ on the clamped Gaussians."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    so = tmp_path / "_hostmath_ungated.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DTS_FOV_CLAMP_BWD_UNGATED=1",
+                    str(root / "tests" / "hostmath" / "hostmath.cpp"), "-o", str(so)], check=True)
+    hm = ctypes.CDLL(str(so))
+    n, w, h = 400, 64, 64
+    model, cam = scene_args(n, 0, w, h, seed=9, scale_mult=30.0)
+    model.means[:, 0] *= 1.6
+    pa = project_args(model, cam, (w, h), "cpu")
+    means, scales, quats = pa[0], pa[1], pa[3]
+    v_conic = torch.randn(n, 3, generator=torch.Generator().manual_seed(1))
+    grads = {}
+    try:
+        for flag in (False, True):
+            O.FOV_CLAMP_BWD_UNGATED = flag
+            m64, s64, q64 = (t.double().requires_grad_(True) for t in (means, scales, quats))
+            conics = O.project_gaussians(*([m64, s64, pa[2], q64] + pa[4:]))[3]
+            (conics * v_conic.double()).sum().backward()
+            grads[flag] = m64.grad
+    finally:
+        O.FOV_CLAMP_BWD_UNGATED = False
+    (_, _, radii32, _, _, _), hcam = _hm_project(hm, pa)
+    v_means = torch.empty(n, 3); v_scales = torch.empty(n, 3); v_quats = torch.empty(n, 4)
+    zeros2, zeros1 = torch.zeros(n, 2), torch.zeros(n)
+    mc, sc, qc, vmc, pmc = (t.contiguous() for t in (means, scales, quats, pa[4], pa[5]))
+    hm.hm_project_bwd(n, fptr(mc), fptr(sc), fptr(qc), fptr(vmc), fptr(pmc), ctypes.byref(hcam), fptr(radii32),
+                      fptr(zeros2), fptr(zeros1), fptr(v_conic), None, fptr(v_means), fptr(v_scales), fptr(v_quats))
+    live = radii32 > 0
+    ref = grads[True][live]
+    assert (v_means[live].double() - ref).abs().max() / ref.abs().max() < 2e-4
+    assert (grads[True][live] - grads[False][live]).abs().max() / ref.abs().max() > 1e-2      # the switch matters here
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
 def test_sh_basis(hostmath, deg):
     d = torch.randn(500, 3, generator=torch.Generator().manual_seed(deg))

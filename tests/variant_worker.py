@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_variants.py: runs in a process of its own with TS_LIB_PATH pointing at a build of the HIP
-library with the OTHER setting of one of SURVEY App. C's two compile-time switches, and checks that build against the
-oracle with the same constant (usage: python tests/variant_worker.py pixoff | bwdclamp)."""
+library with the OTHER setting of one of SURVEY App. C's compile-time switches, and checks that build against the
+oracle with the same constant (usage: python tests/variant_worker.py pixoff | bwdclamp | fovclamp)."""
 import sys
 from pathlib import Path
 
@@ -88,5 +88,57 @@ elif mode == "bwdclamp":
         got = leaves[i].grad
         check_grad(nm + " (upstream backward clamp)", got.reshape(ref.shape), ref, rel=1e-5)
     print("variant bwdclamp ok")
+elif mode == "fovclamp":
+    # SURVEY App. C #4, upstream's reading: the EWA backward does not see the 1.3 tan(fov) clamp (kernels built with
+    # -DTS_FOV_CLAMP_BWD_UNGATED=1, oracle with FOV_CLAMP_BWD_UNGATED) - through the drop-in op and through the frame
+    assert "-DTS_FOV_CLAMP_BWD_UNGATED=1" in stamp
+    from tinysplat_amd.rasterizer import project_args
+    n, w, h = 400, 64, 64
+    model, cam = scene_args(n, 0, w, h, seed=9, scale_mult=30.0)
+    model.means[:, 0] *= 1.6                              # far outside the frustum sideways: the clamp acts
+    pa = project_args(model, cam, (w, h), "cpu")
+    g = torch.Generator().manual_seed(75)
+    # (the clamp only enters through the conic's dependence on the view-space mean: its upstream gradient dominates here)
+    v_xy, v_d, v_c = 1e-4 * torch.randn(n, 2, generator=g), 1e-4 * torch.randn(n, generator=g), torch.randn(n, 3, generator=g)
+    grads = {}
+    for flag in (False, True):
+        O.FOV_CLAMP_BWD_UNGATED = flag
+        m64, s64, q64 = (t.double().requires_grad_(True) for t in (pa[0], pa[1], pa[3]))
+        xys, depths, radii, conics, nth, _ = O.project_gaussians(*([m64, s64, pa[2], q64] + pa[4:]))
+        ((xys * v_xy.double()).sum() + (depths * v_d.double()).sum() + (conics * v_c.double()).sum()).backward()
+        grads[flag] = (m64.grad, s64.grad, q64.grad, radii)
+    O.FOV_CLAMP_BWD_UNGATED = True
+    da = to_dev(pa)
+    leaves = {i: da[i].clone().requires_grad_(True) for i in (0, 1, 3)}
+    for i, t in leaves.items():
+        da[i] = t
+    xys, depths, radii, conics, nth, _ = ops.project_gaussians(*da)
+    ((xys * v_xy.to(DEV)).sum() + (depths * v_d.to(DEV)).sum() + (conics * v_c.to(DEV)).sum()).backward()
+    assert torch.equal(radii.cpu(), grads[True][3]) and int((radii > 0).sum()) > 20
+    live = (grads[True][3] > 0)
+    for i, nm, k in ((0, "v_means", 0), (1, "v_scales", 1), (3, "v_quats", 2)):
+        check_grad(nm + " (ungated fov clamp)", leaves[i].grad.cpu()[live], grads[True][k][live], rel=2e-5)
+    d = (grads[True][0][live] - grads[False][0][live]).abs().max() / grads[True][0][live].abs().max()
+    assert d > 1e-2, d                                    # ... and the two settings differ on this scene
+    # the whole frame (one autograd node) against the oracle frame with the same switch
+    n, sh, w, h = 3000, 1, 96, 64
+    model, cam = scene_args(n, sh, w, h, seed=76, scale_mult=6.0)
+    model.means[:, 0] *= 2.5
+    m64, _ = scene_args(n, sh, w, h, seed=76, scale_mult=6.0)
+    m64.means[:, 0] *= 2.5
+    m64.requires_grad_(True)
+    f = oracle_frame(m64, cam, (w, h), depth=True)
+    stable = f["aux"]["margin"] > 1e-4
+    w_rgb = torch.rand(h, w, 3, generator=g) * stable[..., None]
+    w_d = torch.rand(h, w, generator=g) * stable
+    ((f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()).backward()
+    md = model.to(DEV).requires_grad_(True)
+    rgb, extras = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), sh)
+    ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
+    assert torch.equal(extras["radii"].cpu(), f["radii"])
+    assert_close_masked(rgb, f["rgb"], 1e-5, stable, what="rgb (ungated fov clamp)")
+    for a, b, nm in [(md.means, m64.means, "means"), (md.scales, m64.scales, "scales"), (md.quats, m64.quats, "quats")]:
+        check_grad(nm + " (ungated fov clamp, frame)", a.grad, b.grad, rel=2e-5)
+    print("variant fovclamp ok")
 else:
     raise SystemExit(f"unknown mode {mode}")

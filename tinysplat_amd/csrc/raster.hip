@@ -1847,7 +1847,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     // a row holds data of THIS pass iff its flag equals the pass's value (legacy value 1 on a zeroed array, or
     // the caller's generation on a persistent one: TS_RASTER_FLAG_GEN)
     const unsigned int gen = ((unsigned int)flags >> 8) & 0xffu ? ((unsigned int)flags >> 8) & 0xffu : 1u;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    // The rows of a Gaussian are summed in DOUBLE precision and rounded once (round 6).  A large Gaussian has rows in
+    // 100+ tiles whose moments S v dx, S v dx dy, ... carry both signs, and the running float32 sum lost ~sqrt(rows) ulps of
+    // the largest partial sum - which the projection's VJP then amplifies wherever its terms cancel (a near-isotropic
+    // Gaussian's quaternion gradient: tools/vjp_probe.py, fuzz seed 52).  The kernel waits for memory; the ten
+    // conversions and double adds per row are free (config 3: 57 us either way).
+    double s[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) s[c] = 0.0;
+    auto add_row = [&](const float4& p0, const float4& p1, const float4& p2) {
+        s[0] += (double)p0.x; s[1] += (double)p0.y; s[2] += (double)p0.z; s[3] += (double)p0.w;
+        s[4] += (double)p1.x; s[5] += (double)p1.y; s[6] += (double)p1.z; s[7] += (double)p1.w;
+        s[8] += (double)p2.x; s[9] += (double)p2.y;
+    };
     if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
         const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
         for (long long s = end - cnt; s < end; ++s) {
@@ -1866,11 +1878,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (f & (0xffu << (8 * k))) {
-                    a0.x += p0[k].x; a0.y += p0[k].y; a0.z += p0[k].z; a0.w += p0[k].w;
-                    a1.x += p1[k].x; a1.y += p1[k].y; a1.z += p1[k].z; a1.w += p1[k].w;
-                    a2.x += p2[k].x; a2.y += p2[k].y;
-                }
+                if (f & (0xffu << (8 * k))) add_row(p0[k], p1[k], p2[k]);
             }
         }
     } else {
@@ -1892,14 +1900,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             }
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                if (f[u]) {
-                    a0.x += p0[u].x; a0.y += p0[u].y; a0.z += p0[u].z; a0.w += p0[u].w;
-                    a1.x += p1[u].x; a1.y += p1[u].y; a1.z += p1[u].z; a1.w += p1[u].w;
-                    a2.x += p2[u].x; a2.y += p2[u].y;
-                }
+                if (f[u]) add_row(p0[u], p1[u], p2[u]);
             }
         }
     }
+    float4 a0 = make_float4((float)s[0], (float)s[1], (float)s[2], (float)s[3]);
+    float4 a1 = make_float4((float)s[4], (float)s[5], (float)s[6], (float)s[7]);
+    float4 a2 = make_float4((float)s[8], (float)s[9], 0.f, 0.f);
     float vx = 0.f, vy = 0.f, vop = 0.f;
     if (cnt > 0) {
         const float4 q0 = splats[3 * (size_t)i], q1 = splats[3 * (size_t)i + 1];

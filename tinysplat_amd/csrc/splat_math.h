@@ -20,9 +20,10 @@
 namespace ts {
 
 constexpr float kBlur = 0.3f;          // low-pass added to the cov2d diagonal
-// SURVEY App. C's two open choices are compile-time switches, so that vectors from a pinned gsplat are a one-line
-// flip; the other setting of each is built and checked against the oracle with the same constants once per test
-// session (tests/test_gpu_variants.py):
+// SURVEY App. C's open choices in the device code are compile-time switches, so that vectors from a pinned gsplat are
+// a one-line flip; the other setting of each is built and checked against the oracle with the same constants once per
+// test session (tests/test_gpu_variants.py).  (App. C #9, the SH view directions, is a run-time flag of the adapter:
+// GaussianRasterizer(correct_viewdirs=True).)
 //   TS_PIX_OFF (0 | 0.5f)          pixel (j, i) sampled at (j + off, i + off); 0.1.3-era: 0
 //   TS_BWD_CLAMP_UPSTREAM (0 | 1)  0: the backward pass differentiates the forward pass (alpha clamped at 0.999, no
 //                                  gradient through a clamped alpha); 1: upstream's rasterize_backward as SURVEY App. C
@@ -32,6 +33,14 @@ constexpr float kBlur = 0.3f;          // low-pass added to the cov2d diagonal
 #endif
 #ifndef TS_BWD_CLAMP_UPSTREAM
 #define TS_BWD_CLAMP_UPSTREAM 0
+#endif
+//   TS_FOV_CLAMP_BWD_UNGATED (0 | 1)  App. C #4.  0: the projection's backward pass differentiates the forward pass - a
+//                                  view-space coordinate the 1.3 tan(fov) clamp caught passes no gradient (its value
+//                                  lim * z sends it to z instead); 1: upstream's project_cov3d_ewa_vjp as SURVEY App. A.6
+//                                  recalls it - J is evaluated at the clamped t and v_t goes to the view-space mean as if
+//                                  no clamp had acted (a straight-through clamp)
+#ifndef TS_FOV_CLAMP_BWD_UNGATED
+#define TS_FOV_CLAMP_BWD_UNGATED 0
 #endif
 constexpr float kAlphaMax = 0.999f;    // forward (and, by default, backward) alpha clamp
 constexpr float kAlphaMaxBwd = TS_BWD_CLAMP_UPSTREAM ? 0.99f : kAlphaMax;
@@ -272,8 +281,12 @@ TS_HD void project_one_vjp(const Cam& C, const float m[3], const float sc[3], co
     float v_pz = -C.fx * o.rz2 * vj00 - C.fy * o.rz2 * vj11
                  + 2.0f * C.fx * o.tx * rz3 * vj02 + 2.0f * C.fy * o.ty * rz3 * vj12;
     float v_px = 0.0f, v_py = 0.0f;
-    if (o.clamp_x) v_pz += o.sgn_x * v_tx; else v_px = v_tx;
-    if (o.clamp_y) v_pz += o.sgn_y * v_ty; else v_py = v_ty;
+    if (TS_FOV_CLAMP_BWD_UNGATED) {
+        v_px = v_tx; v_py = v_ty;               // App. C #4, upstream's reading: the clamp is invisible to the VJP
+    } else {
+        if (o.clamp_x) v_pz += o.sgn_x * v_tx; else v_px = v_tx;
+        if (o.clamp_y) v_pz += o.sgn_y * v_ty; else v_py = v_ty;
+    }
     v_pz += v_depth;
     vm0 += V[0] * v_px + V[4] * v_py + V[8] * v_pz;
     vm1 += V[1] * v_px + V[5] * v_py + V[9] * v_pz;

@@ -8,7 +8,7 @@ recipe: project -> retain xys grad -> SH -> clamp(rgb+0.5, min 0) -> rasterize R
 
 Two reference quirks are reproduced on purpose (results parity with tinysplat):
   * SH view directions are ``means - view_matrix[:3,3]`` (the translation column, rasterize.py:77),
-    not ``means - camera_position``;
+    not ``means - camera_position`` (``correct_viewdirs=True`` switches to the camera centre: SURVEY App. C #9);
   * the depth image is composited with ``model.background`` (rasterize.py:86), so it contains
     ``T_final * background[0]``.
 The ``sh_degree`` argument is accepted and ignored, as in the reference (model.active_sh_degree is
@@ -36,18 +36,28 @@ def tile_bounds(dims: Tuple[int, int]) -> Tuple[int, int, int]:
 _cam_cache = {}
 
 
-def camera_on_device(camera, device):
+def sh_origin(view_matrix, correct_viewdirs: bool = False):
+    """The point the SH view directions are taken from.  Reference (rasterize.py:77): ``view_matrix[:3, 3]`` - the
+    TRANSLATION column of the world-to-camera transform, not the camera; ``correct_viewdirs``: the
+    camera centre ``-R^T t`` (= ``inv(view_matrix)[:3, 3]``, the `position` of scene.py:96-107)."""
+    t = view_matrix[:3, 3]
+    if not correct_viewdirs:
+        return t.contiguous()
+    return (-(view_matrix[:3, :3].T @ t)).contiguous()
+
+
+def camera_on_device(camera, device, correct_viewdirs: bool = False):
     """(view[4,4], proj @ view [4,4], origin[3]) on `device`, memoised on the identity/version of the
     camera's two matrices: the reference re-uploads them every frame (rasterize.py:70-71), which on
     a GPU is two pageable host->device copies and a 4x4 GEMM launch per frame."""
     vm, pm = camera.view_matrix, camera.proj_matrix
-    key = (id(camera), str(device))
+    key = (id(camera), str(device), bool(correct_viewdirs))
     sig = (vm.data_ptr(), vm._version, pm.data_ptr(), pm._version)
     hit = _cam_cache.get(key)
     if hit is not None and hit[0] == sig:
         return hit[1]
     view = vm.to(device)
-    out = (view, pm.to(device) @ view, view[:3, 3].contiguous())
+    out = (view, pm.to(device) @ view, sh_origin(vm, correct_viewdirs).to(device))
     if len(_cam_cache) > 64:
         _cam_cache.clear()
     _cam_cache[key] = (sig, out, vm, pm)     # keep the tensors alive so data_ptr stays unique
@@ -64,9 +74,9 @@ def project_args(model, camera, dims, device):
             camera.f_x, camera.f_y, w / 2, h / 2, h, w, tile_bounds(dims)]
 
 
-def sh_args(model, camera, device):
+def sh_args(model, camera, device, correct_viewdirs: bool = False):
     """[active degree, view directions, coefficients[N,K,3]] (rasterize.py:75-81)."""
-    origin = camera.view_matrix[:3, 3].to(device)     # reference quirk: translation column
+    origin = sh_origin(camera.view_matrix, correct_viewdirs).to(device)     # reference quirk: translation column
     dirs = model.means - origin
     dirs = dirs / dirs.norm(dim=-1, keepdim=True)
     coeffs = torch.cat([model.colors_dc[:, None, :], model.colors_rest], dim=1)
@@ -85,10 +95,14 @@ class GaussianRasterizer:
     BLOCK_Y = TILE
 
     def __init__(self, model, cameras: Optional[Sequence] = None, device=torch.device("cuda:0"),
-                 fused_colors: bool = True):
+                 fused_colors: bool = True, correct_viewdirs: bool = False):
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.model = model
         self.global_scale = torch.tensor([1.0])
+        # the reference takes the SH view directions from the view matrix's translation column
+        # (rasterize.py:77), which is the camera position only for an unrotated camera; True = from the camera centre
+        # (what gsplat's own examples feed the op).  Default: the reference's results.
+        self.correct_viewdirs = bool(correct_viewdirs)
         # fused_colors: compute rasterize.py:75-81 + :38-39 (view dirs, cat, SH, +0.5, clamp) in one
         # HIP kernel when the ops namespace offers it; False = the reference's op-by-op recipe.
         # fused_prep: likewise fold exp(scales), quats/|quats| (rasterize.py:72-73) and
@@ -119,7 +133,7 @@ class GaussianRasterizer:
                 and getattr(ops, "render_frame", None) is not None):
             # everything above in one autograd node (frame.py): same kernels, a fraction of the
             # host-side cost per frame
-            view, projview, origin = camera_on_device(camera, self.device)
+            view, projview, origin = camera_on_device(camera, self.device, self.correct_viewdirs)
             w, h = dims
             # under torch.no_grad() (the viewer, viewer.py:89-93) nothing is kept for backward
             planes = getattr(ops, "render_frame_planes", None)
@@ -194,7 +208,7 @@ class GaussianRasterizer:
         fused = getattr(self.ops, "sh_colors", None) if self.fused_colors else None
         if fused is not None:
             m = self.model
-            origin = camera_on_device(camera, self.device)[2]
+            origin = camera_on_device(camera, self.device, self.correct_viewdirs)[2]
             return fused(m.active_sh_degree, m.means, origin, m.colors_dc, m.colors_rest)
         colors = self.ops.spherical_harmonics(*self.spherical_harmonics_inputs(camera))
         return torch.clamp(colors + 0.5, min=0.0)
@@ -204,7 +218,7 @@ class GaussianRasterizer:
         return project_args(self.model, camera, dims, self.device)
 
     def spherical_harmonics_inputs(self, camera):
-        return sh_args(self.model, camera, self.device)
+        return sh_args(self.model, camera, self.device, self.correct_viewdirs)
 
     def rasterize_forward_inputs(self, xys, depths, radii, conics, num_tiles, rgbs, dims):
         return raster_args(self.model, xys, depths, radii, conics, num_tiles, rgbs, dims)

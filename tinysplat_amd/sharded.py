@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import numpy as np
 from typing import List, Optional, Sequence, Tuple
@@ -147,16 +148,18 @@ def row_work(tile_bins: Tensor, tile_bounds_x: int, row0: int = 0) -> List[float
 
 
 def balanced_stripes(work: Sequence[float], world: int) -> List[int]:
-    """Cuts the tile rows 0 .. len(work) into ``world`` CONTIGUOUS stripes (some may be empty) such that the largest
-    stripe's work is minimal -> world + 1 ascending row indices (ShardLayout's ``stripes``).  Exact: dynamic
-    programme over (row, stripe), O(rows^2 world) on a few dozen rows."""
+    """Cuts the tile rows 0 .. len(work) into ``world`` CONTIGUOUS stripes such that the largest stripe's work is
+    minimal and, among the cuts that reach that bottleneck, the loads are as even as possible (smallest sum of squares:
+    no rank is left idle - or handed everything that remains - just because one heavy row fixes the bottleneck; ADVICE
+    r5: [10, 1, 1] over three ranks is [0, 1, 2, 3], not [0, 1, 3, 3]) -> world + 1 ascending row indices (ShardLayout's
+    ``stripes``; stripes are empty only when there are fewer rows than ranks).  Exact: two dynamic programmes over
+    (row, stripe), O(rows^2 world) on a few dozen rows."""
     rows = len(work)
     pre = [0.0]
     for v in work:
         pre.append(pre[-1] + float(v))
     INF = float("inf")
     best = [[INF] * (rows + 1) for _ in range(world + 1)]     # best[k][r]: rows 0..r in k stripes, minimal bottleneck
-    cut = [[0] * (rows + 1) for _ in range(world + 1)]
     best[0][0] = 0.0
     for k in range(1, world + 1):
         for r in range(rows + 1):
@@ -164,8 +167,22 @@ def balanced_stripes(work: Sequence[float], world: int) -> List[int]:
                 if best[k - 1][q] == INF:
                     continue
                 v = max(best[k - 1][q], pre[r] - pre[q])
-                if v < best[k][r] or (v == best[k][r] and q > cut[k][r]):
-                    best[k][r], cut[k][r] = v, q
+                if v < best[k][r]:
+                    best[k][r] = v
+    cap = best[world][rows] * (1.0 + 1e-12)
+    # second pass: smallest sum of squared loads (then fewest empty stripes) with no stripe above the bottleneck
+    even = [[(INF, 0)] * (rows + 1) for _ in range(world + 1)]
+    cut = [[0] * (rows + 1) for _ in range(world + 1)]
+    even[0][0] = (0.0, 0)
+    for k in range(1, world + 1):
+        for r in range(rows + 1):
+            for q in range(r + 1):
+                load = pre[r] - pre[q]
+                if even[k - 1][q][0] == INF or load > cap:
+                    continue
+                v = (even[k - 1][q][0] + load * load, even[k - 1][q][1] + (1 if q == r else 0))
+                if v < even[k][r]:
+                    even[k][r], cut[k][r] = v, q
     out, r = [rows], rows
     for k in range(world, 0, -1):
         r = cut[k][r]
@@ -732,12 +749,13 @@ class _RankState:
                  "counts", "caps", "send_caps", "recv_caps", "send", "recv", "grad_rows", "back", "list_cap",
                  "s_cam", "hints0", "split", "segs", "mode", "num_tiles", "rows", "fin_floats", "stripe_ws", "s_offs", "fs",
                  "bucket", "partials", "busy", "count_host", "count_event", "total", "bg", "bg_key", "m", "tiles16", "fxy",
-                 "frames", "count_np")
+                 "frames", "count_np", "frame_id", "token", "last_used")
 
     def __init__(self, lib, dev, layout: ShardLayout, n: int, nb: int, ch: int, fx, fy):
         w, h = layout.dims
         self.dev, self.layout, self.n, self.nb, self.ch = dev, layout, n, nb, ch
         self.busy, self.caps, self.list_cap, self.partials, self.bg_key, self.frames = False, None, 0, None, None, 0
+        self.frame_id, self.token, self.last_used = 0, None, 0
         world = layout.world
         # ---- owner side (sizes follow the layout only)
         self.o_cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0)
@@ -840,15 +858,38 @@ class _RankState:
             self.size(lib, caps, list_cap)
 
 
+class _FrameToken:
+    """Lives on the autograd ctx of the frame that holds a _RankState: when the graph is freed - with or without a
+    backward pass - the token dies with it, and the state sees that through its weak reference (`busy` was
+    cleared by backward only, so a grad-enabled forward whose backward never came left the state busy for good)."""
+    __slots__ = ("__weakref__",)
+
+
+_rank_clock = [0]        # frames started through _rank_state (any layout): the age of a state = clock - last_used
+RANK_STATE_MAX_AGE = 64  # a busy state that no frame has touched for this long is dropped by the purge with the others
+
+
+def _state_in_use(st: "_RankState") -> bool:
+    """busy AND its frame's graph is still alive; a state whose frame was dropped without a backward pass is reclaimed"""
+    if st.busy and (st.token is None or st.token() is None):
+        st.busy, st.token = False, None
+    return st.busy
+
+
 def _rank_state(lib, dev, layout: ShardLayout, n, nb, ch, fx, fy, stream_handle) -> Optional["_RankState"]:
     key = (layout.key, dev.index, n, nb, ch, float(fx), float(fy), stream_handle)
+    _rank_clock[0] += 1
     st = _rank_states.get(key)
     if st is None:
         if len(_rank_states) > 16:                    # layouts come and go with densification: no unbounded growth
-            for k in [k for k, v in _rank_states.items() if not v.busy]:
+            for k in [k for k, v in _rank_states.items()
+                      if not _state_in_use(v) or _rank_clock[0] - v.last_used > RANK_STATE_MAX_AGE]:
+                # (a dropped state that a retained graph still points at keeps its buffers alive through that graph;
+                # its backward pass still finds them untouched - no later frame can reach the state any more)
                 del _rank_states[k]
         st = _rank_states[key] = _RankState(lib, dev, layout, n, nb, ch, fx, fy)
         st.key = key
+    st.last_used = _rank_clock[0]
     return st
 
 
@@ -993,7 +1034,7 @@ class _ShardedFrame(torch.autograd.Function):
                 and not _frame.CAPACITY_ALLOC and not PADDED_EXCHANGE:
             cur = torch.cuda.current_stream(dev)
             st = _rank_state(lib, dev, layout, means.shape[0], colors_rest.shape[1] + 1, ch, fx, fy, cur.cuda_stream)
-            if st.busy:
+            if _state_in_use(st):
                 st = None                                    # (a frame still waits for its backward pass: stage functions)
         if st is not None and st.caps is not None:
             with torch.cuda.device(dev):
@@ -1010,6 +1051,10 @@ class _ShardedFrame(torch.autograd.Function):
                     ctx.mark_non_differentiable(st.xys, st.radii)
                     return out, st.xys, st.radii
                 st.busy = True
+                st.frame_id += 1
+                ctx.token = _FrameToken()                    # the state is this frame's for as long as its graph lives
+                st.token = weakref.ref(ctx.token)
+                ctx.frame_id = st.frame_id
                 ctx.state, ctx.layout, ctx.exchange = st, layout, exchange
                 ctx.inputs = inputs
                 ctx.caps_next = (mat, total)
@@ -1065,6 +1110,11 @@ class _ShardedFrame(torch.autograd.Function):
         st = ctx.state
         if st is not None:                                  # the rank executor's frame
             dev = st.dev
+            if not st.busy or ctx.frame_id != st.frame_id:
+                # a second backward pass over a retained graph: the state's buffers have been handed to later frames (or
+                # resized by this frame's own first pass) - silently wrong gradients otherwise
+                raise RuntimeError("this sharded frame's buffers were released by its first backward pass (the rank "
+                                   "executor keeps one frame per layout); for retain_graph=True set TS_RANK_EXECUTOR=0")
             try:
                 with torch.cuda.device(dev):
                     if v_img is None:
@@ -1074,7 +1124,7 @@ class _ShardedFrame(torch.autograd.Function):
                     st.renew(lib, *ctx.caps_next)
                     _frame._mark("rank bwd: capacities renewed")
             finally:
-                st.busy = False
+                st.busy, st.token = False, None
             xo = ctx.xys_out
             v_xy = v_xy.clone()                             # (the gradients share one allocation; xys.grad outlives them)
             xo.grad = v_xy if xo.grad is None else xo.grad + v_xy

@@ -131,24 +131,37 @@ def vjp_float32_floor(model, cam, dims, f64, r64):
     hcam = HmCamera(fx, fy, cx, cy, W, H, tb[0], tb[1], 0, tb[1], gs, 0.01)
     means, scales, quats = means.contiguous(), scales.contiguous(), quats.contiguous()
     radii = f64["radii"].to(torch.int32).contiguous()
-    v_xy, v_d, v_c = (f64[k].grad.float().contiguous() for k in ("xys", "depths", "conics"))
-    v_m, v_s, v_q = torch.empty(n, 3), torch.empty(n, 3), torch.empty(n, 4)
-    hm.hm_project_bwd(n, fptr(means), fptr(scales), fptr(quats), fptr(vm.contiguous()), fptr(pm.contiguous()),
-                      ctypes.byref(hcam), fptr(radii), fptr(v_xy), fptr(v_d), fptr(v_c), None,
-                      fptr(v_m), fptr(v_s), fptr(v_q))
-    # the host function differentiates w.r.t. exp(scales); the model holds log-scales (d/dlog s = s d/ds)
-    g_s = r64.scales.grad
-    e_s = float((v_s.double() * torch.exp(r64.scales.detach()) - g_s).abs().max()) / max(1.0, float(g_s.abs().max()))
-    g_m = r64.means.grad
-    e_m = float((v_m.double() - g_m).abs().max()) / max(1.0, float(g_m.abs().max()))
-    # the host function differentiates w.r.t. the normalised quaternion it is handed; the model holds the raw
-    # one: g_raw = (g - q_hat (q_hat . g)) / |q|
+    vm, pm = vm.contiguous(), pm.contiguous()
+    exact = [f64[k].grad for k in ("xys", "depths", "conics")]
     q = r64.quats.detach()
     qn = q / q.norm(dim=1, keepdim=True)
-    g_n = v_q.double()
-    g_raw = (g_n - qn * (qn * g_n).sum(dim=1, keepdim=True)) / q.norm(dim=1, keepdim=True)
-    g_q = r64.quats.grad
-    e_q = float((g_raw - g_q).abs().max()) / max(1.0, float(g_q.abs().max()))
+    g_s, g_m, g_q = r64.scales.grad, r64.means.grad, r64.quats.grad
+    e_m = e_s = e_q = 0.0
+    # On a needle the float32 VJP's error is CHAOTIC in the last bits of its inputs (seed 42, one Gaussian: 0.07 % ... 1.4 %
+    # of the gradient over twelve 1-ulp nudges of the exact 2-D gradients, 0.39 % on the un-nudged ones - round 6), so one
+    # evaluation understates what float32 costs: the floor is the LARGEST error over the exact inputs and eight
+    # evaluations with every input entry moved by +-1 ulp (fixed seed; the nudges stand for the rounding of ANY float32
+    # compositing pass, never for the HIP results under test).
+    gen = torch.Generator().manual_seed(4242)
+    for trial in range(9):
+        def nudged(t):
+            if trial == 0:
+                return t.float().contiguous()
+            sign = torch.randint(0, 2, t.shape, generator=gen).double() * 2.0 - 1.0
+            return (t * (1.0 + 6e-8 * sign)).float().contiguous()
+        v_xy, v_d, v_c = (nudged(t) for t in exact)
+        v_m, v_s, v_q = torch.empty(n, 3), torch.empty(n, 3), torch.empty(n, 4)
+        hm.hm_project_bwd(n, fptr(means), fptr(scales), fptr(quats), fptr(vm), fptr(pm),
+                          ctypes.byref(hcam), fptr(radii), fptr(v_xy), fptr(v_d), fptr(v_c), None,
+                          fptr(v_m), fptr(v_s), fptr(v_q))
+        # the host function differentiates w.r.t. exp(scales); the model holds log-scales (d/dlog s = s d/ds)
+        e_s = max(e_s, float((v_s.double() * torch.exp(r64.scales.detach()) - g_s).abs().max()) / max(1.0, float(g_s.abs().max())))
+        e_m = max(e_m, float((v_m.double() - g_m).abs().max()) / max(1.0, float(g_m.abs().max())))
+        # the host function differentiates w.r.t. the normalised quaternion it is handed; the model holds the raw
+        # one: g_raw = (g - q_hat (q_hat . g)) / |q|
+        g_n = v_q.double()
+        g_raw = (g_n - qn * (qn * g_n).sum(dim=1, keepdim=True)) / q.norm(dim=1, keepdim=True)
+        e_q = max(e_q, float((g_raw - g_q).abs().max()) / max(1.0, float(g_q.abs().max())))
     return {"means": max(e_m, e_s), "scales": e_s, "quats": max(e_q, e_s)}
 
 

@@ -458,6 +458,12 @@ def main():
                          "torch.autograd.backward - the timed step is the render path's forward + backward and nothing "
                          "else.  'loss': the loss is evaluated by torch kernels inside the step (rocBLAS dot, fill, mul: "
                          "~33 us per frame on config 3 that belong to no row of SURVEY 8(a)) - rounds 1-4 timed this")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed steps run for this long BEFORE the W warm-up steps, so that the K timed steps see the GPU's "
+                         "steady state: the driver's W = 5 warm-up steps are 5 ms of GPU work behind seconds of host-side "
+                         "scene set-up, i.e. the timed 20 ms sat inside the clock / power ramp (round 6: 1.06 - 1.13 ms from "
+                         "run to run on one box with W = 5 .. 10, 1.043 - 1.046 after 200 frames).  0 = none.  The timed "
+                         "region is unchanged: exactly K steps between barrier + synchronize")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="leave the process's CPU affinity alone (default: the cores of the GPU's NUMA node)")
     args = ap.parse_args()
@@ -639,6 +645,19 @@ def main():
     def time_steps():
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides -> (max over ranks of
         the wall time, every rank's own time)."""
+        if args.prewarm_ms > 0:          # steady state first (clocks, allocator pools): untimed, see --prewarm-ms
+            t_pw = time.perf_counter()
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            est = (time.perf_counter() - t_pw) / 4
+            if world > 1:                # every rank must run the SAME number of steps (they hold collectives)
+                tt = torch.tensor([est], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                est = float(tt.item())
+            for _ in range(max(0, min(2000, int(args.prewarm_ms * 1e-3 / max(est, 1e-5)) - 4))):
+                step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         barrier()
@@ -944,7 +963,7 @@ def main():
                       "Gaussians*pixels/s fwd+bwd" if not args.train_step else
                       "Gaussians*pixels/s of a full training step (render RGB+depth, loss, backward, Adam)",
             "value": value, "unit": "Gaussians*pixels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "warmup": args.warmup, "prewarm_ms": args.prewarm_ms, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} random Gaussians, SH degree {sh}, {w}x{h}, fwd+bwd "

@@ -360,12 +360,15 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         for sz in sizes:
             offs.append(off)
             off += (sz + 255) & ~255
+        _mark("fwd:sizes")
         F.wf = torch.empty((off,), dtype=torch.uint8, device=dev)
+        _mark("fwd:workspace allocated")
         base = F.wf.data_ptr()
         ptr = [base + o for o in offs]
         F.planes = bool(planes and with_depth)
         F.out_img = torch.empty((rows, w, 3 if F.planes else ch), **f32)
         F.out_depth = torch.empty((rows, w), **f32) if F.planes else None
+        _mark("fwd:image allocated")
 
         def view(k, dtype, count, shape):
             return F.wf[offs[k]:offs[k] + count * dtype.itemsize].view(dtype).view(shape)

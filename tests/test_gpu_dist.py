@@ -104,5 +104,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert mg["shard_mode"] == "gaussians" and mg["shard_mode_requested"] == "both" and mg["shard_mode_fallback"] is False
     assert mg["preflight"] == "ok" and mg["ranks"] == 2 and mg["backend"] == "gloo" and mg["rccl_ranks"] is None
     assert 0 < mg["rank_ms_min"] <= mg["rank_ms_max"] and mg["collective_calls_per_step"] == 3
+    cb = mg["collective_bytes_per_step"]                  # bytes per collective, by name
+    assert set(cb) == {"all_to_all(records)", "all_gather(counts)", "all_to_all(gradient rows)"} and all(v > 0 for v in cb.values())
     rep = mg["replicated_mode"]
     assert rep["shard_mode"] == "replicated" and rep["value"] > 0 and rep["collective_calls_per_step"] == 1
+    assert list(rep["collective_bytes_per_step"]) == ["all_reduce(2-D gradients)"]

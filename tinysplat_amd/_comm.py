@@ -17,9 +17,10 @@ class CollectiveTimer:
         self.enabled = False
         self._pairs: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         self.calls = 0
+        self.bytes = []            # (label, bytes this rank hands to the collective) per call since start()
 
     def start(self) -> None:
-        self.enabled, self._pairs, self.calls = True, [], 0
+        self.enabled, self._pairs, self.calls, self.bytes = True, [], 0, []
 
     def stop(self) -> Tuple[float, int]:
         """-> (milliseconds inside collectives since start(), number of collective calls)."""
@@ -31,7 +32,11 @@ class CollectiveTimer:
         return ms, calls
 
     @contextlib.contextmanager
-    def span(self, on_device: bool = True):
+    def span(self, on_device: bool = True, label: str = "", nbytes: int = 0):
+        """``label`` / ``nbytes``: what the call is and how many bytes THIS rank hands to it (its send buffer; for an
+        all-reduce the buffer itself) - bench.py's N > 1 line reports them per step beside the time."""
+        if self.enabled and label:
+            self.bytes.append((label, int(nbytes)))
         if not self.enabled or not on_device or not torch.cuda.is_available():
             if self.enabled:
                 self.calls += 1

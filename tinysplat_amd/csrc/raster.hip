@@ -67,7 +67,12 @@ namespace {
 #endif                                 // chunk level with TS_LDS_DMA; they took 107 / 115).  Round 5: raster_bwd 465 -> 450 us
 
 #ifndef TS_ABLATE
-#define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0)
+#define TS_ABLATE 0                    // timing experiments only (results are wrong when != 0): 3 = no per-entry loop at all
+                                       // (what remains: prologue, sort, staging, epilogue); 4 = backward: the row's lane sums
+                                       // added within the lane, no cross-lane reduction; 5 = the per-entry loop (record read,
+                                       // mask dispatch, backward: `any` test) WITHOUT the block bodies and flushes; 6 = no
+                                       // in-kernel sort (forward); 7 = backward: bodies, no flush at all
+                                       // (tools/ablate_frame.sh; profiles/r06d_compositing_ablation.txt)
 #endif
 
 // TS_STATS=1 (developer build, tools/raster_stats.py; slow): dynamic work counters of the compositing kernels,
@@ -522,6 +527,90 @@ struct LocLds {
     }
 };
 
+// The per-pixel update of the forward pass behind the exponent, hand-scheduled (round 6, TS_FWD_ASM).  The compiler's
+// code for the C++ form below spent 5 wait states (s_nop 0 / 1 / 1) and one register copy on every block body:
+// it folds the negation of `-ae` and the `-|T|` of the stop into v_cndmask_b32_e64 source modifiers, and a VOP3 select
+// that reads vcc as a CONSTANT needs two wait states behind the v_cmp that wrote it (an e32 select, which reads vcc
+// implicitly, needs none); the new T was built in a temporary and moved.  Here: both value selects are e32 (the
+// negation moves into the FMA, vis becomes the select of T - nT - the same bits as |T| - |Tn|: an unfinished pixel has
+// T, nT > 0, and a stopping or finished one selects 0), the one select that keeps its modifiers (T <- -|T| on a stop)
+// stands three instructions behind its compare, and T is updated in place: 21 VALU issues + 1 wait state per body where
+// the compiler had 24 + 5.  Same operations on the same operands: image, final_Ts and final_index are bit for bit the
+// C++ form's (tests/test_gpu_parity.py compares the frame with the oracle; tools/variant_check.py the two builds).
+#ifndef TS_FWD_ASM
+#define TS_FWD_ASM 1
+#endif
+// ae = exp2(-sgl) >= 1/255 ? exp2(-sgl) : 0
+__device__ __forceinline__ float fwd_alpha(float sgl) {
+#if TS_FWD_ASM
+    float a, ae;
+    asm("v_exp_f32_e64 %0, -%2\n\t"
+        "s_nop 0\n\t"
+        "v_cmp_le_f32_e32 vcc, %3, %0\n\t"
+        "v_cndmask_b32_e32 %1, 0, %0, vcc"
+        : "=&v"(a), "=v"(ae)
+        : "v"(sgl), "s"(ts::kAlphaMin)
+        : "vcc");
+    return ae;
+#else
+    const float a = __builtin_amdgcn_exp2f(-sgl);
+    return a >= ts::kAlphaMin ? a : 0.0f;
+#endif
+}
+// the lean path (no clamp, no sigma >= 0 test between the two): ONE block, so that the compiler puts no wait state of
+// its own between two asm statements
+__device__ __forceinline__ float fwd_alpha_update(float sgl, float& T, int& fidx, int idx, float& a0, float& a1, float& a2,
+                                                  float c0, float c1, float c2) {
+    float a, ae, nT, d, vis;
+    asm("v_exp_f32_e64 %0, -%10\n\t"
+        "s_nop 0\n\t"
+        "v_cmp_le_f32_e32 vcc, %15, %0\n\t"
+        "v_cndmask_b32_e32 %1, 0, %0, vcc\n\t"
+        "v_fma_f32 %2, -%1, %5, %5\n\t"
+        "v_sub_f32_e32 %3, %5, %2\n\t"
+        "v_cmp_nge_f32_e32 vcc, %16, %2\n\t"
+        "v_cndmask_b32_e32 %4, 0, %3, vcc\n\t"
+        "v_fmac_f32_e32 %6, %11, %4\n\t"
+        "v_fmac_f32_e32 %7, %12, %4\n\t"
+        "v_cndmask_b32_e64 %5, -|%5|, %2, vcc\n\t"
+        "v_fmac_f32_e32 %8, %13, %4\n\t"
+        "v_cmp_lt_f32_e32 vcc, 0, %4\n\t"
+        "v_cndmask_b32_e32 %9, %9, %14, vcc"
+        : "=&v"(a), "=&v"(ae), "=&v"(nT), "=&v"(d), "=&v"(vis), "+v"(T), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(fidx)
+        : "v"(sgl), "v"(c0), "v"(c1), "v"(c2), "v"(idx), "s"(ts::kAlphaMin), "s"(ts::kTEps)
+        : "vcc");
+    return vis;
+}
+// T, fidx and the first three channels of acc updated for one pixel; returns vis (the weight of the colour)
+__device__ __forceinline__ float fwd_update(float ae, float& T, int& fidx, int idx, float& a0, float& a1, float& a2,
+                                            float c0, float c1, float c2) {
+#if TS_FWD_ASM
+    float nT, d, vis;
+    asm("v_fma_f32 %0, -%8, %3, %3\n\t"                    // nT = T - ae T
+        "v_sub_f32_e32 %1, %3, %0\n\t"                      // d = T - nT
+        "v_cmp_nge_f32_e32 vcc, %13, %0\n\t"                // vcc = !(nT <= kTEps): the pixel goes on
+        "v_cndmask_b32_e32 %2, 0, %1, vcc\n\t"              // vis = goes on ? d : 0
+        "v_fmac_f32_e32 %4, %9, %2\n\t"
+        "v_fmac_f32_e32 %5, %10, %2\n\t"
+        "v_cndmask_b32_e64 %3, -|%3|, %0, vcc\n\t"          // T = goes on ? nT : -|T|   (three issues behind the v_cmp)
+        "v_fmac_f32_e32 %6, %11, %2\n\t"
+        "v_cmp_lt_f32_e32 vcc, 0, %2\n\t"                   // composited <=> vis > 0
+        "v_cndmask_b32_e32 %7, %7, %12, vcc"
+        : "=&v"(nT), "=&v"(d), "=&v"(vis), "+v"(T), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(fidx)
+        : "v"(ae), "v"(c0), "v"(c1), "v"(c2), "v"(idx), "s"(ts::kTEps)
+        : "vcc");
+    return vis;
+#else
+    const float nT = __builtin_fmaf(-ae, T, T);
+    const float Tn = nT <= ts::kTEps ? -__builtin_fabsf(T) : nT;   // the stopping Gaussian is not composited
+    const float vis = __builtin_fabsf(T) - __builtin_fabsf(Tn);
+    a0 = __builtin_fmaf(c0, vis, a0); a1 = __builtin_fmaf(c1, vis, a1); a2 = __builtin_fmaf(c2, vis, a2);
+    fidx = vis > 0.0f ? idx : fidx;
+    T = Tn;
+    return vis;
+#endif
+}
+
 template <int CH, bool GENERAL, int NBX, class Loc>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
@@ -547,14 +636,18 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
 #pragma unroll
         for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
+            if (TS_ABLATE == 5) { asm volatile("" ::: "memory"); continue; }
             TS_STAT(1, 1);
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k % NBX], r0.y - fpy[k / NBX]);
-            float a = __builtin_amdgcn_exp2f(-sgl);
             // Every decision below is ONE compare feeding ONE select, with no scalar mask arithmetic in between:
             // a v_cmp -> s_and / s_xor -> v_cndmask chain costs a wave 36 cycles and a select on a vcc that the
             // scalar unit wrote 19 (tools/micro/lat_bench.hip), a compare -> select pair 11.
-            float ae = a >= ts::kAlphaMin ? a : 0.0f;
+            float vis;
+            if (TS_FWD_ASM && !GENERAL) {
+                vis = fwd_alpha_update(sgl, T[k], fidx[k], idx, acc[k][0], acc[k][1], acc[k][2], col[0], col[1], col[2]);
+            } else {
+            float ae = fwd_alpha(sgl);                                // alpha >= 1/255 ? alpha : 0
             if (GENERAL) {
                 ae = fminf(ts::kAlphaMax, ae);
                 ae = sgl >= neg_lo ? ae : 0.0f;                       // sigma >= 0
@@ -562,15 +655,11 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             // A finished pixel (T < 0) needs no test of its own: nT = T (1 - ae) stays negative, `stop` fires and
             // -|T| puts T back; vis is 0.  An unfinished pixel always has T > kTEps (it would have stopped
             // otherwise), so with ae = 0 (Gaussian below 1/255) nT = T and `stop` cannot fire: no `& ok` needed.
-            const float nT = __builtin_fmaf(-ae, T[k], T[k]);
-            const float Tn = nT <= ts::kTEps ? -__builtin_fabsf(T[k]) : nT;   // the stopping Gaussian is not composited
-            const float vis = __builtin_fabsf(T[k]) - __builtin_fabsf(Tn);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) acc[k][c] = __builtin_fmaf(col[c], vis, acc[k][c]);
-            if (LOC) loc.add(k, col, vis);      // the same contribution summed per list segment (LIST SEGMENTS)
             // composited <=> alpha >= 1/255 and not stopped <=> vis = alpha T > 0 (alpha >= 1/255, T > 1e-4)
-            fidx[k] = vis > 0.0f ? idx : fidx[k];
-            T[k] = Tn;
+            vis = fwd_update(ae, T[k], fidx[k], idx, acc[k][0], acc[k][1], acc[k][2], col[0], col[1], col[2]);
+            }
+            if (CH == 4) acc[k][CH - 1] = __builtin_fmaf(col[CH - 1], vis, acc[k][CH - 1]);
+            if (LOC) loc.add(k, col, vis);      // the same contribution summed per list segment (LIST SEGMENTS)
         }
         TS_SEG_ADD(ts_seg_, 2, tseg_b);
     }
@@ -655,23 +744,22 @@ __device__ __forceinline__ void fwd_body1(const float4 r0, const float4 r1, cons
     col[0] = r1.z; col[1] = r1.w; col[2] = r2.x;
     if (CH == 4) col[CH - 1] = r2.y;
     const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx, r0.y - fpy);
-    float a = __builtin_amdgcn_exp2f(-sgl);
-    float ae = a >= ts::kAlphaMin ? a : 0.0f;
-    if (GENERAL) {
-        ae = fminf(ts::kAlphaMax, ae);
-        ae = sgl >= neg_lo ? ae : 0.0f;
+    float vis;
+    if (TS_FWD_ASM && !GENERAL) {
+        vis = fwd_alpha_update(sgl, T, fidx, idx, acc[0], acc[1], acc[2], col[0], col[1], col[2]);
+    } else {
+        float ae = fwd_alpha(sgl);
+        if (GENERAL) {
+            ae = fminf(ts::kAlphaMax, ae);
+            ae = sgl >= neg_lo ? ae : 0.0f;
+        }
+        vis = fwd_update(ae, T, fidx, idx, acc[0], acc[1], acc[2], col[0], col[1], col[2]);
     }
-    const float nT = __builtin_fmaf(-ae, T, T);
-    const float Tn = nT <= ts::kTEps ? -__builtin_fabsf(T) : nT;
-    const float vis = __builtin_fabsf(T) - __builtin_fabsf(Tn);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = __builtin_fmaf(col[c], vis, acc[c]);
+    if (CH == 4) acc[CH - 1] = __builtin_fmaf(col[CH - 1], vis, acc[CH - 1]);
     if (LOC) {          // the same contribution summed per list segment (LIST SEGMENTS)
 #pragma unroll
         for (int c = 0; c < CH; ++c) loc[c] = __builtin_fmaf(col[c], vis, loc[c]);
     }
-    fidx = vis > 0.0f ? idx : fidx;
-    T = Tn;
 }
 
 // one sorted run of a cooperative tile's list: n_run <= 64 E keys of g[] sorted in registers, position lane * E + e
@@ -794,6 +882,11 @@ __device__ __forceinline__ void coop_fwd_tile(
     int idr[4] = {0, 0, 0, 0};               // shared sort: this lane's ids of rounds 0 .. 3
     bool from_lds = false;
     TS_SEG_T0(tseg_s);
+    if (SORT && TS_ABLATE == 6 && n <= kWaveSortMax) {       // timing experiment: a copy instead of the sort
+        for (int i = threadIdx.x; i < n; i += 256) ids_rw[range.x + i] = bucket_ids[range.x + i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+    } else
     if (SORT && n > 0 && n <= kWaveSortMax) {
         const int* g = bucket_ids + range.x;
         int* out = ids_rw + range.x;
@@ -1048,6 +1141,9 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
         static_assert(!SORT || (!WL && NBX == 2), "16x16 lists");
         TS_SEG_T0(tseg_s);                // (timeline builds: the sort is segment 3 of the forward kernel)
         const int n = range.y - range.x;
+        if (TS_ABLATE == 6 && n <= kWaveSortMax && (!SPLIT || wave == 0)) {      // timing experiment: a copy instead of the sort
+            for (int i = lane; i < n; i += 64) ids_rw[range.x + i] = bucket_ids[range.x + i];
+        } else
         if (n > 0 && n <= kWaveSortMax && (!SPLIT || wave == 0)) {
             const int* g = bucket_ids + range.x;
             int* out = ids_rw + range.x;
@@ -1384,10 +1480,34 @@ __device__ __forceinline__ float wave_sum10_masked(const float v[10], int lane, 
 #ifndef TS_FLUSH_ZERO_EARLY
 #define TS_FLUSH_ZERO_EARLY 1
 #endif
+// ROWS THROUGH LDS (round 6, TS_ROWS_LDS).  The ablation table of round 6 (profiles/r06d_compositing_ablation.txt) put
+// a number on the flush for the first time: raster_bwd 453 us, without any flush 183 us, with the stores but without the
+// cross-lane butterfly 383 us - the two scattered stores per row (ten dwords from ten lanes + a flag byte: 4.85 M
+// vector-memory instructions per launch, each one a trip through the CU's one address unit at a quarter rate for
+// 64-bit addresses) cost THREE times what the 24-issue butterfly costs.  So a row is no longer stored when it is
+// reduced: the writer lanes park it in LDS - in the 48 bytes of the entry's own staged record, which is dead once its
+// bodies have read it; the row slot stays where the record keeps it (word 11), word 10 (the list index) becomes the
+// mark "this entry has a row" - and when the chunk is done lane j stores row j with three 16-byte stores and its flag
+// byte: four vector-memory instructions per chunk of up to 64 rows instead of two per row.  Same values in the same
+// places: gradients bit for bit.
+#ifndef TS_ROWS_LDS
+#define TS_ROWS_LDS 1
+#endif
+constexpr int kRowMark = -1;               // word 10 of a staged record once its row has been parked there
+// word of the record this lane fills when a row is parked (-1: none): the reduction leaves value w in the first lane of
+// ten quads (see wave_sum10_masked); lane 36 - first lane of an idle quad - writes the mark
+__device__ __forceinline__ int row_word_of_lane(int lane, int values) {
+    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1;
+    const int w = (lane & 32) ? 8 + b3 : 4 * b4 + 2 * b2 + b3;
+    const bool writer = (lane & 3) == 0 && ((lane & 32) == 0 || (lane & 0x14) == 0);
+    if (lane == 36) return 10;
+    return (writer && w < values) ? w : -1;
+}
 template <int CH>
 __device__ __forceinline__ void flush_row(float (&v)[6 + CH], int slot_i, long long num_isects,
                                           float* __restrict__ partials,
-                                          unsigned char* __restrict__ row_flags, int lane) {
+                                          unsigned char* __restrict__ row_flags, int lane,
+                                          float* lds_row = nullptr, int row_word = -1) {
     // num_isects carries the row-flag value in its top byte (see ts_raster_bwd: TS_RASTER_FLAG_GEN)
     const unsigned char flag_val = (unsigned char)((unsigned long long)num_isects >> 56);
     float r;
@@ -1410,6 +1530,10 @@ __device__ __forceinline__ void flush_row(float (&v)[6 + CH], int slot_i, long l
         };
         if (TS_FLUSH_ASM) r = wave_sum10_masked<(CH == 4)>(v10, lane, zero);
         else { r = wave_sum10<(CH == 4)>(v10, lane); zero(); }
+    }
+    if (TS_ROWS_LDS && TS_FLUSH_ASM && lds_row != nullptr) {   // park the row in the entry's staged record
+        if (row_word >= 0) lds_row[row_word] = row_word == 10 ? __int_as_float(kRowMark) : r;
+        return;
     }
     const long long slot = (long long)slot_i;                  // < num_isects by construction (pack_splats)
     (void)num_isects;
@@ -1443,7 +1567,14 @@ __device__ __forceinline__ void flush_row(float (&v)[6 + CH], int slot_i, long l
 //   vo = v_out, fidx = index of the last Gaussian the forward pass composited.
 // Inside a block the body is full-exec and branch free: a lane that is not valid uses alpha = 0
 // (ra = 1, fac = 0, v_sig = 0) and changes nothing.
-template <int CH, bool GENERAL, int NBX>
+// STARTED (round 6, TS_BWD_STARTED): every pixel of every block that takes part in this chunk has its whole list in
+// front of it (fidx >= the chunk's highest index - true for all but the last one or two chunks of a list, since nearly
+// every pixel's last contribution lies there), so `idx <= fidx[k]` holds for every entry and lane: the body drops the
+// compare and the s_and_b64 of the two ballots (2 of its ~43 issue slots).  Same sums, bit for bit.
+#ifndef TS_BWD_STARTED
+#define TS_BWD_STARTED 0          // measured (round 6, config 3): raster_bwd 447 - 453 us either way; off
+#endif
+template <int CH, bool GENERAL, int NBX, bool STARTED = false>
 __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], float (&R)[2 * NBX],
                                           const float (&vo)[2 * NBX][CH], const int (&fidx)[2 * NBX],
@@ -1460,6 +1591,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
     // row flush of this one - its registers are dead by then, and the flush (no LDS access in it) would cover the round
     // trip that the wave waits out at the top of every iteration (7.6 % of a backward wave's cycles); slower (above)
     constexpr int RS = CH == 3 ? 3 : 4;
+    const int row_word = row_word_of_lane(lane, 6 + CH);      // (TS_ROWS_LDS) the word of a parked row this lane writes
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     float bm_f = 0.0f;
     if (TS_BWD_EARLY_RECORD && cnt > 0 && TS_ABLATE != 3) {
@@ -1489,12 +1621,14 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
 #pragma unroll
         for (int k = 0; k < 2 * NBX; ++k) {
             if (!(bm & (1 << k))) continue;                           // wave-uniform
+            if (TS_ABLATE == 5) { asm volatile("" ::: "memory"); continue; }
             TS_STAT(3, 1);
             const float dx = r0.x - fpx[k % NBX], dy = r0.y - fpy[k / NBX];
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, dx, dy);
             const float araw = __builtin_amdgcn_exp2f(-sgl);           // opacity * exp(-sigma)
             float a = araw;
-            mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin) & TS_BALLOT(idx <= fidx[k]);
+            mask64 validm = TS_BALLOT(araw >= ts::kAlphaMin);
+            if (!STARTED) validm &= TS_BALLOT(idx <= fidx[k]);
             if (GENERAL) {
                 a = fminf(ts::kAlphaMaxBwd, araw);
                 validm &= TS_BALLOT(sgl >= neg_lo);                    // sigma >= 0
@@ -1555,15 +1689,20 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
         asm volatile("" : "+s"(any));
         TS_SEG_ADD(ts_seg_, 2, tseg_b);
         TS_SEG_T0(tseg_c);
-        const int row_slot = __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
+        constexpr bool kRowsLds = TS_ROWS_LDS && TS_FLUSH_ASM && TS_ABLATE == 0;
+        const int row_slot = kRowsLds ? 0 : __builtin_amdgcn_readfirstlane(__float_as_int(r2.w));
         if (TS_BWD_EARLY_RECORD && j + 1 < cnt) {
             r0 = lds[RS * (j + 1)]; r1 = lds[RS * (j + 1) + 1]; r2 = lds[RS * (j + 1) + 2];
             bm_f = CH == 3 ? r2.y : lds[RS * (j + 1) + 3].x;
         }
-        if (any) {
+        if (any && TS_ABLATE != 7) {
             TS_STAT(5, 1);
             TS_WORK(2, 1);
-            flush_row<CH>(acc, row_slot, num_isects, partials, row_flags, lane);
+            if (kRowsLds)
+                flush_row<CH>(acc, row_slot, num_isects, partials, row_flags, lane,
+                              reinterpret_cast<float*>(const_cast<float4*>(lds) + RS * j), row_word);
+            else
+                flush_row<CH>(acc, row_slot, num_isects, partials, row_flags, lane);
             if (!TS_FLUSH_ZERO_EARLY || TS_ABLATE == 4) {
                 // zero the accumulators two at a time (v_mov_b64 on a register pair)
 #pragma unroll
@@ -1576,6 +1715,23 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ lds, int cn
             }
         }
         TS_SEG_ADD(ts_seg_, 3, tseg_c);
+    }
+    if (TS_ROWS_LDS && TS_FLUSH_ASM && TS_ABLATE == 0) {
+        // the chunk's rows, parked in LDS by the flushes above: lane j stores the row of staged entry j
+        TS_WAVE_SYNC();
+        if (lane < cnt) {
+            float4 p2 = lds[RS * lane + 2];
+            if (__float_as_int(p2.z) == kRowMark) {
+                const long long slot = (long long)__float_as_int(p2.w);      // < num_isects by construction (pack_splats)
+                const float4 p0 = lds[RS * lane], p1 = lds[RS * lane + 1];
+                if (CH == 3) p2.y = 0.0f;
+                p2.z = 0.0f; p2.w = 0.0f;
+                float4* dst = reinterpret_cast<float4*>(partials) + slot * kRowF4;
+                dst[0] = p0; dst[1] = p1; dst[2] = p2;
+                row_flags[slot] = (unsigned char)((unsigned long long)num_isects >> 56);
+            }
+        }
+        TS_WAVE_SYNC();          // the records are dead now: the caller's next chunk stages over them
     }
 }
 
@@ -1818,9 +1974,23 @@ __global__ __launch_bounds__(64 * kBwdWaves, NBX == 2 ? TS_BWD_MIN_WAVES_16 : TS
         TS_STAT(2, cnt);
         TS_STAT(7, min(64, hi - sb + 1));
         TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
-        if (__ballot(keep && (s.mask & (1 << NB))) != 0ull)
+        // every block that takes part (a pixel's list reaches into the chunk) has ALL its pixels' lists in front of the
+        // chunk's last entry: no per-entry `idx <= fidx` test (see STARTED)
+        bool started = TS_BWD_STARTED && NBX == 2 && !SPLIT;
+        if (started) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const unsigned long long all = __ballot(fidx[k] >= hi);
+                if ((blocks & (1 << k)) && all != ~0ull) started = false;
+            }
+        }
+        const bool general = __ballot(keep && (s.mask & (1 << NB))) != 0ull;
+        if (general)
             bwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
                                      row_flags, lane TS_SEG_ARG);
+        else if (started)
+            bwd_chunk<CH, false, NBX, true>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
+                                            row_flags, lane TS_SEG_ARG);
         else
             bwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, R, vo, fidx, acc, num_isects, partials,
                                       row_flags, lane TS_SEG_ARG);
@@ -1833,6 +2003,21 @@ __global__ __launch_bounds__(64 * kBwdWaves, NBX == 2 ? TS_BWD_MIN_WAVES_16 : TS
 // with d = xy - pixel.  The conic / opacity factors are applied once per Gaussian here.
 // color_mask (may be NULL): clamp mask of the colour stage, applied here (bit c clear -> v_colors[c] = 0)
 // when the gradients are summed over ranks before the colour stage's backward runs.
+// LANES per Gaussian (TS_REDUCE_LANES, round 6): one lane per Gaussian walked ALL its slots, so a wave took as long as the
+// largest of its 64 Gaussians (6 slots on average, 100+ for a large one) and every lane's walk was a chain of dependent
+// flag -> row loads.  Now LANES consecutive lanes share a Gaussian: lane j takes the slots j, j + LANES, ... of its
+// range in ascending order (the flags of LANES neighbouring slots are neighbouring bytes), sums them in double, and the
+// LANES partial sums are combined pairwise (j ^ 1, then j ^ 2, ...) - a fixed order, so the gradients stay
+// bit-reproducible run to run.
+#ifndef TS_REDUCE_LANES
+#define TS_REDUCE_LANES 1          // measured (config 3 / 5, us): 1: 59 / 431, 2: 56 / -, 4: 58 / 452, 8: 87 / 571, 16: 183 / 985 - the walk is bound by its row gathers, not by its longest lane
+#endif
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
 template <int CH>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     int n, int flags, const int* __restrict__ num_tiles_hit, const int* __restrict__ cum_tiles_hit,
@@ -1840,8 +2025,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     const float4* __restrict__ splats, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_opacity, float* __restrict__ v_depth,
     const unsigned char* __restrict__ color_mask, float4* __restrict__ grad_rows) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    constexpr int L = TS_REDUCE_LANES;
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "lanes per Gaussian: a power of two within a row of 16");
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(gi / L), j = (int)(gi % L);
+    if (i >= n) return;                           // (all L lanes of a Gaussian leave together)
     const int cnt = num_tiles_hit[i];
     const long long end = cum_tiles_hit[i];
     // a row holds data of THIS pass iff its flag equals the pass's value (legacy value 1 on a zeroed array, or
@@ -1851,7 +2039,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     // 100+ tiles whose moments S v dx, S v dx dy, ... carry both signs, and the running float32 sum lost ~sqrt(rows) ulps of
     // the largest partial sum - which the projection's VJP then amplifies wherever its terms cancel (a near-isotropic
     // Gaussian's quaternion gradient: tools/vjp_probe.py, fuzz seed 52).  The kernel waits for memory; the ten
-    // conversions and double adds per row are free (config 3: 57 us either way).
+    // conversions and double adds per row are free.
     double s[10];
 #pragma unroll
     for (int c = 0; c < 10; ++c) s[c] = 0.0;
@@ -1862,8 +2050,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
     };
     if (flags & TS_RASTER_SPLIT_BLOCKS) {         // four rows per (tile, Gaussian): one flag word per pair
         const unsigned int* flags4 = reinterpret_cast<const unsigned int*>(row_flags);
-        for (long long s = end - cnt; s < end; ++s) {
-            const unsigned int fw = flags4[s];
+        for (long long sl = end - cnt + j; sl < end; sl += L) {
+            const unsigned int fw = flags4[sl];
             unsigned int f = 0u;                      // byte k set: row k of the slot was written in this pass
 #pragma unroll
             for (int k = 0; k < 4; ++k) f |= (((fw >> (8 * k)) & 0xffu) == gen) ? (0xffu << (8 * k)) : 0u;
@@ -1872,8 +2060,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (f & (0xffu << (8 * k))) {
-                    p0[k] = partials[kRowF4 * (4 * s + k)]; p1[k] = partials[kRowF4 * (4 * s + k) + 1];
-                    p2[k] = partials[kRowF4 * (4 * s + k) + 2];
+                    p0[k] = partials[kRowF4 * (4 * sl + k)]; p1[k] = partials[kRowF4 * (4 * sl + k) + 1];
+                    p2[k] = partials[kRowF4 * (4 * sl + k) + 2];
                 }
             }
 #pragma unroll
@@ -1882,20 +2070,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             }
         }
     } else {
-        // four slots per step: their flags, then the rows of the flagged ones, are all requested before the
-        // first addition, which happens in slot order as before (same sums, bit for bit) - a lane's walk is
-        // otherwise a chain of dependent flag -> row -> flag loads
+        // kAhead slots per lane and step: their flags, then the rows of the flagged ones, are all requested before the
+        // first addition, which happens in slot order - a lane's walk is otherwise a chain of dependent
+        // flag -> row -> flag loads
         constexpr int kAhead = TS_REDUCE_AHEAD;
-        for (long long s0 = end - cnt; s0 < end; s0 += kAhead) {
+        for (long long s0 = end - cnt + j; s0 < end; s0 += kAhead * L) {
             bool f[kAhead];
             float4 p0[kAhead], p1[kAhead], p2[kAhead];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) f[u] = (s0 + u < end) && row_flags[s0 + u] == gen;   // else: not written in this pass (stale)
+            for (int u = 0; u < kAhead; ++u) f[u] = (s0 + u * L < end) && row_flags[s0 + u * L] == gen;   // else: not written in this pass (stale)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 if (f[u]) {
-                    p0[u] = partials[kRowF4 * (s0 + u)]; p1[u] = partials[kRowF4 * (s0 + u) + 1];
-                    p2[u] = partials[kRowF4 * (s0 + u) + 2];
+                    p0[u] = partials[kRowF4 * (s0 + u * L)]; p1[u] = partials[kRowF4 * (s0 + u * L) + 1];
+                    p2[u] = partials[kRowF4 * (s0 + u * L) + 2];
                 }
             }
 #pragma unroll
@@ -1904,6 +2092,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
             }
         }
     }
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 10; ++c) s[c] += shfl_xor_f64(s[c], m);
+    }
+    if (j != 0) return;
     float4 a0 = make_float4((float)s[0], (float)s[1], (float)s[2], (float)s[3]);
     float4 a1 = make_float4((float)s[4], (float)s[5], (float)s[6], (float)s[7]);
     float4 a2 = make_float4((float)s[8], (float)s[9], 0.f, 0.f);
@@ -2158,7 +2352,7 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
     hipStream_t s = (hipStream_t)stream;
     const float4* pr = reinterpret_cast<const float4*>(partials);
     const float4* sp = reinterpret_cast<const float4*>(splats);
-    const int grid = (n + 255) / 256;
+    const int grid = (int)(((long long)n * TS_REDUCE_LANES + 255) / 256);
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
                            cum_tiles_hit, pr, row_flags, sp, v_xy, v_conic, v_colors, v_opacity, v_depth, color_mask,
@@ -2180,7 +2374,7 @@ int ts_reduce_partials_rows(int32_t n, int32_t channels, int32_t flags, const in
     const float4* pr = reinterpret_cast<const float4*>(partials);
     const float4* sp = reinterpret_cast<const float4*>(splats);
     float4* gr = reinterpret_cast<float4*>(grad_rows);
-    const int grid = (n + 255) / 256;
+    const int grid = (int)(((long long)n * TS_REDUCE_LANES + 255) / 256);
     if (channels == 3)
         hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3(grid), dim3(256), 0, s, n, (int)flags, num_tiles_hit,
                            cum_tiles_hit, pr, row_flags, sp, (float*)nullptr, (float*)nullptr, (float*)nullptr,

@@ -651,7 +651,8 @@ class _RenderFrame(torch.autograd.Function):
             else:
                 _lib.check(lib.ts_frame_bwd_composite(ctypes.byref(fr), s), "ts_frame_bwd_composite")
             if ctx.group is not None:                          # tile-stripe sharding: sum over ranks
-                with collective_timer.span(on_device=flat.is_cuda and dist.get_backend(ctx.group) != "gloo"):
+                with collective_timer.span(on_device=flat.is_cuda and dist.get_backend(ctx.group) != "gloo",
+                                           label="all_reduce(2-D gradients)", nbytes=flat.numel() * flat.element_size()):
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
             if timed:
                 _steps_bwd_params(lib, fr, s)

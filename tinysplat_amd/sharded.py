@@ -181,7 +181,7 @@ def balanced_stripes(work: Sequence[float], world: int) -> List[int]:
                 if even[k - 1][q][0] == INF or load > cap:
                     continue
                 v = (even[k - 1][q][0] + load * load, even[k - 1][q][1] + (1 if q == r else 0))
-                if v < even[k][r]:
+                if v <= even[k][r]:                           # (ties: the later cut - empty stripes go to the LAST ranks)
                     even[k][r], cut[k][r] = v, q
     out, r = [rows], rows
     for k in range(world, 0, -1):
@@ -281,11 +281,11 @@ class DistExchange(Exchange):
         if self.via_host:
             mine = counts_dev.cpu()
             got = [torch.empty_like(mine) for _ in range(self.world)]
-            with collective_timer.span(on_device=False):
+            with collective_timer.span(on_device=False, label="all_gather(counts)", nbytes=mine.numel() * 4):
                 dist.all_gather(got, mine, group=self.group)
             return torch.stack(got).to(counts_dev.device)
         out = torch.empty((self.world, counts_dev.shape[0]), dtype=counts_dev.dtype, device=counts_dev.device)
-        with collective_timer.span():
+        with collective_timer.span(label="all_gather(counts)", nbytes=counts_dev.numel() * 4):
             dist.all_gather_into_tensor(out.view(-1), counts_dev, group=self.group)
         return out
 
@@ -293,11 +293,11 @@ class DistExchange(Exchange):
         if self.via_host:
             mine = counts_dev.cpu()
             got = torch.empty_like(mine)
-            with collective_timer.span(on_device=False):
+            with collective_timer.span(on_device=False, label="all_to_all(counts)", nbytes=mine.numel() * 4):
                 dist.all_to_all_single(got, mine, group=self.group)
             return mine.tolist(), got.tolist()
         got = torch.empty_like(counts_dev)
-        with collective_timer.span():
+        with collective_timer.span(label="all_to_all(counts)", nbytes=counts_dev.numel() * 4):
             dist.all_to_all_single(got, counts_dev, group=self.group)
         both = torch.stack([counts_dev, got]).cpu()              # the frame's host read of the record counts
         return both[0].tolist(), both[1].tolist()
@@ -307,7 +307,8 @@ class DistExchange(Exchange):
         if self.via_host:
             src = send.cpu()
             got = torch.empty((m, send.shape[1]), dtype=send.dtype)
-            with collective_timer.span(on_device=False):
+            with collective_timer.span(on_device=False, label="all_to_all(gradient rows)" if backward else "all_to_all(records)",
+                                       nbytes=int(sum(send_counts)) * send.shape[1] * send.element_size()):
                 dist.all_to_all_single(got, src, output_split_sizes=list(recv_counts),
                                        input_split_sizes=list(send_counts), group=self.group)
             if out is not None:
@@ -315,7 +316,8 @@ class DistExchange(Exchange):
                 return out
             return got.to(send.device)
         got = send.new_empty((m, send.shape[1])) if out is None else out
-        with collective_timer.span():
+        with collective_timer.span(label="all_to_all(gradient rows)" if backward else "all_to_all(records)",
+                                   nbytes=int(sum(send_counts)) * send.shape[1] * send.element_size()):
             dist.all_to_all_single(got, send, output_split_sizes=list(recv_counts),
                                    input_split_sizes=list(send_counts), group=self.group)
         return got

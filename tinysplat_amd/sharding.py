@@ -58,11 +58,13 @@ class _SumGradsAcrossRanks(torch.autograd.Function):
             return (None,) + grads
         base = _shared_flat_base(live)
         if base is not None:          # already one contiguous buffer (ops._RasterizeGaussians.backward)
-            with collective_timer.span(on_device=base.is_cuda):
+            with collective_timer.span(on_device=base.is_cuda, label="all_reduce(2-D gradients)",
+                                       nbytes=base.numel() * base.element_size()):
                 dist.all_reduce(base, op=dist.ReduceOp.SUM, group=ctx.group)
             return (None,) + grads
         flat = torch.cat([g.reshape(-1) for g in live])
-        with collective_timer.span(on_device=flat.is_cuda):
+        with collective_timer.span(on_device=flat.is_cuda, label="all_reduce(2-D gradients)",
+                                   nbytes=flat.numel() * flat.element_size()):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
         out, off = [], 0
         for g in grads:

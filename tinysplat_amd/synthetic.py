@@ -212,10 +212,17 @@ def morton_order(points: torch.Tensor) -> torch.Tensor:
 
 
 def make_scene(n: int, sh_degree: int, width: int, height: int, seed: int = 0,
-               scale_mult: float = 1.0, fov_x_deg: float = 60.0, top_third: float = 0.0):
+               scale_mult: float = 1.0, fov_x_deg: float = 60.0, top_third: float = 0.0,
+               clustered: float = 0.0, opacity_logit_mean: float = 0.0):
     """Seeded random-Gaussian scene of SURVEY.md 8(d) D2.  Generated on CPU in float32.
     ``top_third`` > 0: that share of the Gaussians is moved into the top third of the image (a SKEWED scene for the
     work-balanced stripes of a multi-GPU frame; 0 = the uniform scene, unchanged).
+
+    ``clustered`` > 0: that share of the Gaussians is moved into a window of 5 % of the image area around (0.3, 0.4) of
+    the frame (a CLUSTERED scene: a few tiles carry very long lists, most are nearly empty); ``opacity_logit_mean``:
+    mean of the opacity logits (3: nearly opaque Gaussians, every pixel saturates early - the forward pass stops after a
+    fraction of its lists).  Both draw from generators of their own, so the default scene is unchanged (the launch
+    policy's constants were fitted on it: tools/policy_regret.py times them on these scenes).
 
     z ~ U(2,10); x,y = z*tan_fov*U(-1.1,1.1) (~17 % off-screen); per-axis log-scale =
     log z + U(log 8e-4, log 4e-3) (+ log scale_mult: the high-overlap stress variant uses 4);
@@ -238,10 +245,18 @@ def make_scene(n: int, sh_degree: int, width: int, height: int, seed: int = 0,
         move = torch.rand((n,), generator=g2) < top_third
         y_top = z * tan_y * (-1.1 + (1.1 - 1.0 / 3.0) * torch.rand((n,), generator=g2))      # image rows 0 .. H/3
         y = torch.where(move, y_top, y)
+    if clustered > 0.0:
+        g3 = torch.Generator(device="cpu").manual_seed(seed + 104729)
+        move = torch.rand((n,), generator=g3) < clustered
+        side = math.sqrt(0.05)                                   # window of 5 % of the image area (in [-1, 1] units: 2 * side)
+        cx, cy = -0.4, -0.2                                      # centred at (0.3, 0.4) of the frame
+        xc = z * tan_x * (cx + side * (2.0 * torch.rand((n,), generator=g3) - 1.0))
+        yc = z * tan_y * (cy + side * (2.0 * torch.rand((n,), generator=g3) - 1.0))
+        x, y = torch.where(move, xc, x), torch.where(move, yc, y)
     means = torch.stack([x, y, z], dim=-1)
     scales = torch.log(z)[:, None] + U((n, 3), math.log(8e-4), math.log(4e-3)) + math.log(scale_mult)
     quats = torch.randn((n, 4), generator=g, dtype=torch.float32)
-    opacities = 1.5 * torch.randn((n, 1), generator=g, dtype=torch.float32)
+    opacities = 1.5 * torch.randn((n, 1), generator=g, dtype=torch.float32) + float(opacity_logit_mean)
     k = num_sh_bases(sh_degree)
     colors_dc = torch.randn((n, 3), generator=g, dtype=torch.float32)
     colors_rest = 0.1 * torch.randn((n, k - 1, 3), generator=g, dtype=torch.float32)

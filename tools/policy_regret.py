@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Policy regret of the launch policy (frame.py: list shape by the previous frame's pairs per tile, hybrid launch and
+cooperative tiles by tile count) on scenes its constants were NOT fitted on.  For every
+(scene, resolution): the frame time under the automatic policy, and under every setting of a small grid of
+(list mode, S, W16, C16) forced through the module's knobs - regret = auto / best - 1.  Developer tool, GPU box.
+
+scenes: d2 (the i.i.d. scene of SURVEY 8(d) D2, what the constants were fitted on), overlap (D3's high-overlap variant:
+log-scale range x4), clustered (80 % of the Gaussians in 5 % of the image), opaque (opacity logits N(3, 1.5): early
+termination everywhere)
+usage: python tools/policy_regret.py [--scenes d2,overlap,clustered,opaque] [--res 1280x720,1920x1080,3840x2160] [--n N]"""
+import argparse
+import sys
+import time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from tinysplat_amd import frame
+from tinysplat_amd.frame import render_frame
+from tinysplat_amd.synthetic import loss_weights, make_scene
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scenes", default="d2,overlap,clustered,opaque")
+ap.add_argument("--res", default="1280x720,1920x1080,3840x2160")
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--steps", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+SCENES = {"d2": {}, "overlap": {"scale_mult": 4.0}, "clustered": {"clustered": 0.8}, "opaque": {"opacity_logit_mean": 3.0}}
+# (mode, S, W16, C16): 16x16 lists with the full-frame policy's neighbours, no hybrid launch at all, wide lists
+GRID = [(0, 8, 13, 3), (0, 8, 12, 3), (0, 8, 14, 3), (0, 8, 10, 4), (0, 8, 13, 0), (0, 8, 13, 6), (0, 4, 12, 3), (0, 1, 0, 0),
+        (0, 8, 6, 6), (2, 1, 0, 0)]
+
+
+def timed(step, k):
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k * 1e3
+
+
+auto = dict(WIDE_TILES=frame.WIDE_TILES, HYBRID_SEGS=frame.HYBRID_SEGS, HYBRID_WHOLE16=frame.HYBRID_WHOLE16,
+            HYBRID_COOP16=frame.HYBRID_COOP16, HYBRID_MID_WHOLE16=frame.HYBRID_MID_WHOLE16,
+            HYBRID_MID_COOP16=frame.HYBRID_MID_COOP16)
+print(f"# n = {args.n}; columns: ms per frame (forward + backward, RGB) under the automatic policy | the best forced setting "
+      "(mode, S, W16, C16) | regret")
+for sc in args.scenes.split(","):
+    for res in args.res.split(","):
+        w, h = (int(v) for v in res.split("x"))
+        model, cam = make_scene(args.n, 3, w, h, seed=0, **SCENES[sc])
+        model = model.to(dev).requires_grad_(True)
+        w_rgb = loss_weights(w, h)[0].to(dev)
+        params = list(model.parameters())
+        view34 = cam.view_matrix[:3, :].to(dev).contiguous()
+        projview = (cam.proj_matrix @ cam.view_matrix).to(dev).contiguous()
+        origin = cam.view_matrix[:3, 3].to(dev).contiguous()
+
+        def step():
+            for p in params:
+                p.grad = None
+            out, _, _ = render_frame(model, view34, projview, origin, cam.f_x, cam.f_y, w, h, with_depth=False)
+            torch.autograd.backward([out], [w_rgb])
+
+        for k_, v in auto.items():
+            setattr(frame, k_, v)
+        frame._pairs_per_tile.clear()
+        t_auto = timed(step, args.steps)
+        b = frame.last_binning[dev.index]
+        tiles16 = b.cam.tile_rows * b.cam.tile_bounds_x
+        per_tile = b.num_intersects / max(1, tiles16)
+        mode_auto = frame._list_mode(dev.index, tiles16)
+        lens = (b.tile_bins[:, 1] - b.tile_bins[:, 0]).float()
+        results = []
+        for mode, S, W16, C16 in GRID:
+            frame.WIDE_TILES = mode
+            frame.HYBRID_SEGS, frame.HYBRID_WHOLE16, frame.HYBRID_COOP16 = S, max(W16, 1), C16
+            frame.HYBRID_MID_WHOLE16, frame.HYBRID_MID_COOP16 = max(W16, 1), C16
+            try:
+                results.append((timed(step, args.steps), (mode, S, W16, C16)))
+            except Exception as e:                              # noqa: BLE001 - a setting a launch shape does not take
+                results.append((float("inf"), (mode, S, W16, C16)))
+        best = min(results)
+        print(f"{sc:10s} {w}x{h:<5d} bbox pairs/tile {per_tile:7.0f}  longest list {int(lens.max()):6d}  auto (mode {mode_auto}) "
+              f"{t_auto:7.3f} ms | best {best[1]} {best[0]:7.3f} ms | regret {100.0 * (t_auto / best[0] - 1.0):+5.1f} %   all: "
+              + " ".join(f"{r[1]}={r[0]:.3f}" for r in results), flush=True)
+        del model, params
+        torch.cuda.empty_cache()

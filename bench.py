@@ -58,7 +58,7 @@ STAGE_OF = {
     "ts_project_fwd": "project_fwd", "ts_project_bwd": "project_bwd",
     "ts_sh_fwd": "sh_fwd", "ts_sh_colors_fwd": "sh_fwd",
     "ts_colors_pack_fwd": "sh_fwd",          # colour stage + record packing in one launch (frame path)
-    "ts_sh_bwd": "sh_bwd", "ts_sh_colors_bwd": "sh_bwd",
+    "ts_sh_bwd": "sh_bwd", "ts_sh_colors_bwd": "sh_bwd", "ts_sh_colors_bwd_adam": "sh_bwd", "ts_project_bwd_adam": "project_bwd",
     "ts_scan_tiles": "bin_sort", "ts_bin_count": "bin_sort", "ts_tile_offsets": "bin_sort",
     "ts_bin_scatter": "bin_sort", "ts_sort_tiles": "bin_sort", "ts_pack_splats": "bin_sort",
     "ts_raster_fwd": "raster_fwd",
@@ -1020,6 +1020,25 @@ def main():
             "stages_ms": {k_: round(v, 4) for k_, v in sorted(stage_ms.items())},
             "entries_ms": {k_: round(v, 4) for k_, v in sorted(per_step.items())},
         }
+        if args.train_step:
+            # what the optimiser part of the step costs against what it must move.  Fused (default): the
+            # parameter-stage backward kernels update p, m, v in place from the gradient in registers - per Gaussian the
+            # 2-D gradients in (52 B + 4 B radii + 12 B means for the view directions) and p, m, v of all 14 + 3 K
+            # parameters read and written (24 B each); the two-launch form writes and re-reads the gradients on top.
+            npar = 14 + 3 * k
+            fused = "ts_project_bwd_adam" in per_step
+            ents = [e for e in ("ts_sh_colors_bwd_adam", "ts_project_bwd_adam", "ts_sh_colors_bwd", "ts_project_bwd",
+                                "ts_adam_step") if e in per_step]
+            t_ms = sum(per_step[e] for e in ents)
+            b_alg = n * (68.0 + 24.0 * npar + (0.0 if fused else 8.0 * npar))
+            out["train_step_roofline"] = {
+                "fused_adam": fused, "entries": {e: round(per_step[e], 4) for e in ents}, "ms": t_ms,
+                "alg_bytes": b_alg, "achieved": b_alg / (t_ms * 1e-3) / 1e9 if t_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (b_alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ms > 0 else None,
+                "photometric_loss_ms": per_step.get("ts_photometric_loss_rgbd", per_step.get("ts_photometric_loss_planes")),
+                "note": "parameter-stage backward + Adam of the training step: algorithmic bytes (p, m, v read and written, "
+                        "the 2-D gradients read" + ("" if fused else ", the six gradient tensors written and read") +
+                        ") over the time of the entries listed"}
         if world > 1 or args.force_dist:
             # what ran, said by the line itself: the design, whether the preflight sent the ranks to the other one,
             # how many ranks the backend saw, the spread over the ranks and the time inside collectives

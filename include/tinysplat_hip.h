@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 6
+#define TS_ABI_VERSION 7
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -550,6 +550,39 @@ int ts_adam_step(int32_t num_tensors, float* const* params_host, const float* co
                  float* const* exp_avg_host, float* const* exp_avg_sq_host, const int64_t* numel_host,
                  const float* lr_host, const int32_t* steps_host, float beta1, float beta2, float eps,
                  void* stream);
+
+/* FUSED ADAM (round 6; scripts/train.py:93-97): the parameter-stage backward kernels apply the optimiser to the gradient
+ * they hold in registers - the very update of ts_adam_step, bit for bit - instead of writing six gradient tensors that
+ * the optimiser launch reads once.  ts_adam: the six groups in the order of the model's parameters() (model_gaussian.py:
+ * 112-120): means, colors_dc, colors_rest, scales, quats, opacities; step[k] >= 1 is group k's own 1-based step count.
+ *   ts_sh_colors_bwd_adam   ts_sh_colors_bwd with colors_dc / colors_rest (and their moments) updated in place
+ *   ts_project_bwd_adam     ts_project_bwd (no v_cov3d) with means3d / scales / quats updated in place - the RAW tensors:
+ *                           pass the flags the forward pass used (TS_PROJECT_LOG_SCALES | TS_PROJECT_RAW_QUATS) - and,
+ *                           when `opacities` is not NULL, the opacity logits from v_opacity (ts_reduce_partials with
+ *                           TS_RASTER_LOGIT_OPACITY)
+ *   ts_frame_bwd_params_adam  what ts_frame_bwd_params enqueues, with the two entries above: no parameter gradient is
+ *                           written (f->v_means ... f->v_colors_rest are not read); f->v_xy - xys.grad - still is */
+#define TS_ADAM_MEANS 0
+#define TS_ADAM_COLORS_DC 1
+#define TS_ADAM_COLORS_REST 2
+#define TS_ADAM_SCALES 3
+#define TS_ADAM_QUATS 4
+#define TS_ADAM_OPACITIES 5
+typedef struct ts_adam {
+    float* exp_avg[6];
+    float* exp_avg_sq[6];
+    float lr[6];
+    int32_t step[6];
+    float beta1, beta2, eps;
+} ts_adam;
+int ts_sh_colors_bwd_adam(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                          const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                          float* colors_dc, float* colors_rest, const ts_adam* adam_host, void* stream);
+int ts_project_bwd_adam(int32_t n, float* means3d, float* scales, float* quats, const float* viewmat,
+                        const float* projmat, const ts_camera* cam_host, int32_t flags, const int32_t* radii,
+                        const float* v_xy, const float* v_depth, const float* v_conic, float* opacities,
+                        const float* v_opacity, const ts_adam* adam_host, void* stream);
+int ts_frame_bwd_params_adam(const ts_frame* f, const ts_adam* adam_host, void* stream);
 
 /* ================== densification hooks (model_gaussian.py:130-242) ========= */
 /* Call order of one densify_and_prune (model_gaussian.py:138-195):

@@ -160,3 +160,38 @@ def test_fit_loop_follows_the_reference_schedule():
     pick = CameraSampler(4, np.random.default_rng(1))
     seq = [pick(s) for s in range(1, 10)]
     assert all(0 <= i < 4 for i in seq)
+
+
+@pytest.mark.parametrize("sh,n,w,h", [(3, 20000, 320, 208), (0, 3000, 160, 112)])
+def test_fused_adam_step_is_bitwise_the_two_launch_step(sh, n, w, h):
+    """SURVEY 8(f) F1 (train.py:93-97): TrainStep(fused_adam=True) - the frame's backward pass applies the Adam update to
+    the gradients its parameter-stage kernels hold in registers, no gradient tensor is written - against backward +
+    ts_adam_step: parameters and both moments bit for bit after three steps, xys.grad too; the fused path really ran."""
+    from tinysplat_amd.rasterizer import GaussianRasterizer
+    target_model, cam = make_scene(n, sh, w, h, seed=11, scale_mult=3.0)
+    with torch.no_grad():
+        tgt, extras = GaussianRasterizer(target_model.to(DEV), None, device=torch.device(DEV))(cam, None, sh)
+    tgt, tgt_d = tgt.clone(), extras["depth"].clone()
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    start, _ = make_scene(n, sh, w, h, seed=11, scale_mult=3.0)
+    start.colors_dc = start.colors_dc + 0.3 * torch.randn(n, 3, generator=gen)
+    start.means = start.means + 0.02 * torch.randn(n, 3, generator=gen)
+    runs = {}
+    for fused in (False, True):
+        model = start.to(DEV)
+        for nm in ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities"):
+            setattr(model, nm, getattr(model, nm).detach().clone())
+        step = TrainStep(model, DEV, fused_adam=fused)
+        outs = [step(cam, tgt, tgt_d) for _ in range(3)]
+        assert step.optimizer.fused_steps == (3 if fused else 0)
+        if fused:
+            assert all(p.grad is None for p in model.parameters())
+        runs[fused] = (model, step.optimizer, outs)
+    (m0, o0, r0), (m1, o1, r1) = runs[False], runs[True]
+    for a, b in zip(r0, r1):
+        assert torch.equal(a["loss"], b["loss"]) and torch.equal(a["xys_grad"], b["xys_grad"])
+    for nm in ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities"):
+        assert torch.equal(getattr(m0, nm), getattr(m1, nm)), nm
+        assert torch.equal(o0.exp_avg[nm], o1.exp_avg[nm]) and torch.equal(o0.exp_avg_sq[nm], o1.exp_avg_sq[nm]), nm
+        assert o0.steps[nm] == o1.steps[nm] == 3
+    assert not torch.equal(m1.means, start.means.to(DEV))

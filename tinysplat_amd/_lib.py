@@ -14,7 +14,7 @@ from pathlib import Path
 # compile-time switches in a process of their own); a variant build needs TS_ALLOW_VARIANT_LIB=1 as usual
 LIB_PATH = Path(os.environ["TS_LIB_PATH"]) if os.environ.get("TS_LIB_PATH") else \
     Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
 HINT_COOP_SPLIT = 1 << 20        # ts_camera.hints: TS_HINT_COOP_SPLIT
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
@@ -63,6 +63,16 @@ class TsFrame(ctypes.Structure):
 
 
 _FRAME = POINTER(TsFrame)
+
+
+class TsAdam(ctypes.Structure):
+    """struct ts_adam: the optimiser state the fused parameter-stage backward updates (groups in the order of
+    SplatModel.parameters(): means, colors_dc, colors_rest, scales, quats, opacities)."""
+    _fields_ = [("exp_avg", c_void_p * 6), ("exp_avg_sq", c_void_p * 6), ("lr", c_float * 6), ("step", c_int32 * 6),
+                ("beta1", c_float), ("beta2", c_float), ("eps", c_float)]
+
+
+_ADAM = POINTER(TsAdam)
 
 MAX_RANKS = 16
 
@@ -121,6 +131,9 @@ SIGNATURES = {
     "ts_photometric_loss_planes": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P,
                                              _P]),
     "ts_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
+    "ts_sh_colors_bwd_adam": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _ADAM, _P]),
+    "ts_project_bwd_adam": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P, _P, _P, _ADAM, _P]),
+    "ts_frame_bwd_params_adam": (c_int32, [_FRAME, _ADAM, _P]),
     "ts_grad_accum": (c_int32, [c_int32, _P, _P, _P]),
     "ts_densify_classify": (c_int32, [c_int32, _P, _P, _P, POINTER(TsDensifyPolicy), _P, _P]),
     "ts_densify_ws_ints": (c_int64, [c_int32]),

@@ -184,6 +184,19 @@ int ts_frame_bwd_params(const ts_frame* f, void* stream) {
                           f->v_xy, f->v_depth, f->v_conic, nullptr, f->v_means, f->v_scales, f->v_quats, stream);
 }
 
+int ts_frame_bwd_params_adam(const ts_frame* f, const ts_adam* adam, void* stream) {
+    TsRange range_("ts_frame_bwd_params_adam");
+    if (bad(f) || !adam) return TS_E_BADARG;
+    // (the colour stage reads the means for its view directions: it runs BEFORE the projection's pass moves them)
+    TS_TRY(ts_sh_colors_bwd_adam(f->n, f->sh_degree, f->num_bases, f->means, f->origin,
+                                 (f->flags & TS_FRAME_STRIPE) ? nullptr : f->sh_mask, f->v_colors,
+                                 const_cast<float*>(f->colors_dc), f->num_bases > 1 ? const_cast<float*>(f->colors_rest) : nullptr,
+                                 adam, stream));
+    return ts_project_bwd_adam(f->n, const_cast<float*>(f->means), const_cast<float*>(f->scales), const_cast<float*>(f->quats),
+                               f->view34, f->projview, &f->cam, 3, f->radii, f->v_xy, f->v_depth, f->v_conic,
+                               const_cast<float*>(f->opacities), f->v_opacity, adam, stream);
+}
+
 // ---- Gaussian-sharded frame (csrc/shard.hip, tinysplat_amd/sharded.py): the same executor idea -----------------
 // Two ts_frame describe a rank's frame: `fo` its OWNED Gaussians with the full-frame camera, `fs` the records its
 // stripe imported (n = records, cam = the stripe); the per-stage entries are called in the order sharded.py

@@ -13,6 +13,7 @@
 #include "../../include/tinysplat_hip.h"
 #include "pack.h"
 #include "splat_math.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -87,23 +88,46 @@ __global__ __launch_bounds__(kThreads) void project_fwd_kernel(
     }
 }
 
+// FUSED ADAM (round 6; SURVEY 8(f) F1: scripts/train.py:93-97, model_gaussian.py:112-120).  A training step used to
+// write the six parameter gradients (236 bytes per Gaussian at SH degree 3) only for ts_adam_step to read them once.
+// With ADAM the kernels that hold a gradient in registers apply the update there (adam_math.h: the very update of
+// ts_adam_step, bit for bit): the projection's backward pass updates means / scales / quats - and the opacity logits,
+// whose gradient ts_reduce_partials left in v_opacity -, the colour stage's backward pass colors_dc / colors_rest.
+// No parameter gradient is materialised; xys.grad (what densification reads, model_gaussian.py:130-132) still is.
+// A culled Gaussian has a zero gradient and is updated with it, as torch.optim.Adam does with a dense gradient.
+struct ProjAdam {
+    float *means, *scales, *quats, *opacities;            // the model's raw parameter tensors (log-scales, raw quaternions, logits)
+    const float* v_opacity;                                // dL / d logit (ts_reduce_partials with TS_RASTER_LOGIT_OPACITY)
+    float *m_means, *v_means, *m_scales, *v_scales, *m_quats, *v_quats, *m_opac, *v_opac;
+    ts::AdamCoef c_means, c_scales, c_quats, c_opac;
+};
+template <bool ADAM>
 __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
     int n, const float* __restrict__ means3d, const float* __restrict__ scales,
     const float* __restrict__ quats, const float* __restrict__ viewmat,
     const float* __restrict__ projmat, const ts_camera cam, const int flags,
     const int* __restrict__ radii, const float* __restrict__ v_xy, const float* __restrict__ v_depth,
     const float* __restrict__ v_conic, const float* __restrict__ v_cov3d,
-    float* __restrict__ v_means3d, float* __restrict__ v_scales, float* __restrict__ v_quats) {
+    float* __restrict__ v_means3d, float* __restrict__ v_scales, float* __restrict__ v_quats, const ProjAdam ad) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     ts::ProjGrad g;
     for (int k = 0; k < 3; ++k) { g.v_mean[k] = 0.0f; g.v_scale[k] = 0.0f; }
     for (int k = 0; k < 4; ++k) g.v_quat[k] = 0.0f;
+    float pm[3] = {0.f, 0.f, 0.f}, ps[3] = {0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};      // (ADAM) the raw parameters
+    if (ADAM) {
+        pm[0] = means3d[3 * i]; pm[1] = means3d[3 * i + 1]; pm[2] = means3d[3 * i + 2];
+        ps[0] = scales[3 * i]; ps[1] = scales[3 * i + 1]; ps[2] = scales[3 * i + 2];
+        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+        pq[0] = qv.x; pq[1] = qv.y; pq[2] = qv.z; pq[3] = qv.w;
+    }
     if (radii[i] > 0) {
         const ts::Cam C = load_cam(viewmat, projmat, cam);
-        const float m[3] = {means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2]};
-        float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+        const float m[3] = {ADAM ? pm[0] : means3d[3 * i], ADAM ? pm[1] : means3d[3 * i + 1], ADAM ? pm[2] : means3d[3 * i + 2]};
+        float s[3] = {ADAM ? ps[0] : scales[3 * i], ADAM ? ps[1] : scales[3 * i + 1], ADAM ? ps[2] : scales[3 * i + 2]};
+        float4 qv;
+        if (ADAM) qv = make_float4(pq[0], pq[1], pq[2], pq[3]);
+        else qv = reinterpret_cast<const float4*>(quats)[i];
         float q[4] = {qv.x, qv.y, qv.z, qv.w};
         float inv_n = 1.0f;
         prep_inputs(flags, s, q, &inv_n);
@@ -123,6 +147,35 @@ __global__ __launch_bounds__(kThreads) void project_bwd_kernel(
                                q[3] * g.v_quat[3];
             for (int k = 0; k < 4; ++k) g.v_quat[k] = (g.v_quat[k] - q[k] * dotp) * inv_n;
         }
+    }
+    if (ADAM) {
+        float mo[3], vo[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mo[k] = ad.m_means[3 * i + k]; vo[k] = ad.v_means[3 * i + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ts::adam_update(pm[k], g.v_mean[k], mo[k], vo[k], ad.c_means);
+            ad.means[3 * i + k] = pm[k]; ad.m_means[3 * i + k] = mo[k]; ad.v_means[3 * i + k] = vo[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mo[k] = ad.m_scales[3 * i + k]; vo[k] = ad.v_scales[3 * i + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ts::adam_update(ps[k], g.v_scale[k], mo[k], vo[k], ad.c_scales);
+            ad.scales[3 * i + k] = ps[k]; ad.m_scales[3 * i + k] = mo[k]; ad.v_scales[3 * i + k] = vo[k];
+        }
+        float4 mq = reinterpret_cast<float4*>(ad.m_quats)[i], vq = reinterpret_cast<float4*>(ad.v_quats)[i];
+        ts::adam_update(pq[0], g.v_quat[0], mq.x, vq.x, ad.c_quats); ts::adam_update(pq[1], g.v_quat[1], mq.y, vq.y, ad.c_quats);
+        ts::adam_update(pq[2], g.v_quat[2], mq.z, vq.z, ad.c_quats); ts::adam_update(pq[3], g.v_quat[3], mq.w, vq.w, ad.c_quats);
+        reinterpret_cast<float4*>(ad.quats)[i] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+        reinterpret_cast<float4*>(ad.m_quats)[i] = mq;
+        reinterpret_cast<float4*>(ad.v_quats)[i] = vq;
+        if (ad.opacities) {
+            float po = ad.opacities[i], mo1 = ad.m_opac[i], vo1 = ad.v_opac[i];
+            ts::adam_update(po, ad.v_opacity[i], mo1, vo1, ad.c_opac);
+            ad.opacities[i] = po; ad.m_opac[i] = mo1; ad.v_opac[i] = vo1;
+        }
+        return;
     }
 #if TS_NT_GRADS
     __builtin_nontemporal_store(g.v_mean[0], v_means3d + 3 * i); __builtin_nontemporal_store(g.v_mean[1], v_means3d + 3 * i + 1);
@@ -343,11 +396,15 @@ __global__ __launch_bounds__(kThreads) void sh_colors_fwd_sparse_kernel(
     if (pk.splats) ts::pack_one(pk, i, c0, c1, c2, pk.channels == 4 ? pk.depths[i] : 0.0f);
 }
 
-template <int DEG>
+struct ShAdam {             // FUSED ADAM (see project_bwd_kernel): colors_dc / colors_rest updated from the gradient rows in registers
+    float *dc, *rest, *m_dc, *v_dc, *m_rest, *v_rest;
+    ts::AdamCoef c_dc, c_rest;
+};
+template <int DEG, bool ADAM>
 __global__ __launch_bounds__(kShThreadsBwd) void sh_colors_bwd_kernel(
     int n, int num_bases, const float* __restrict__ means, const float* __restrict__ origin,
     const unsigned char* __restrict__ mask, const float* __restrict__ v_colors,
-    float* __restrict__ v_dc, float* __restrict__ v_rest) {
+    float* __restrict__ v_dc, float* __restrict__ v_rest, const ShAdam ad) {
     constexpr int KA = (DEG + 1) * (DEG + 1);
     extern __shared__ __align__(16) float lds[];
     const int RS = 3 * (num_bases - 1);
@@ -363,7 +420,17 @@ __global__ __launch_bounds__(kShThreadsBwd) void sh_colors_bwd_kernel(
         const int m = mask ? mask[i] : 7;      // NULL: the clamp was applied upstream (ts_reduce_partials)
         const float v0 = (m & 1) ? v_colors[3 * i] : 0.0f, v1 = (m & 2) ? v_colors[3 * i + 1] : 0.0f,
                     v2 = (m & 4) ? v_colors[3 * i + 2] : 0.0f;
-        v_dc[3 * i] = Y[0] * v0; v_dc[3 * i + 1] = Y[0] * v1; v_dc[3 * i + 2] = Y[0] * v2;
+        if (ADAM) {
+            const float gd[3] = {Y[0] * v0, Y[0] * v1, Y[0] * v2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float p_ = ad.dc[3 * i + c], m_ = ad.m_dc[3 * i + c], s_ = ad.v_dc[3 * i + c];
+                ts::adam_update(p_, gd[c], m_, s_, ad.c_dc);
+                ad.dc[3 * i + c] = p_; ad.m_dc[3 * i + c] = m_; ad.v_dc[3 * i + c] = s_;
+            }
+        } else {
+            v_dc[3 * i] = Y[0] * v0; v_dc[3 * i + 1] = Y[0] * v1; v_dc[3 * i + 2] = Y[0] * v2;
+        }
         float* r = lds + tid * RSP;
 #pragma unroll
         for (int k = 1; k < KA; ++k) {
@@ -373,9 +440,10 @@ __global__ __launch_bounds__(kShThreadsBwd) void sh_colors_bwd_kernel(
     }
     if (RS == 0) return;
     __syncthreads();
-    float* dst = v_rest + (size_t)g0 * RS;
+    const size_t off = (size_t)g0 * RS;
+    float* dst = ADAM ? nullptr : v_rest + off;
     const int total = cnt * RS;
-    if ((total & 3) == 0 && (((size_t)g0 * RS) & 3) == 0) {
+    if ((total & 3) == 0 && ((off) & 3) == 0) {
         float4* dst4 = reinterpret_cast<float4*>(dst);
         for (int f4 = tid; f4 < total / 4; f4 += kShThreadsBwd) {
             float e[4];
@@ -384,10 +452,29 @@ __global__ __launch_bounds__(kShThreadsBwd) void sh_colors_bwd_kernel(
                 const int ff = 4 * f4 + u;
                 e[u] = lds[(ff / RS) * RSP + (ff % RS)];
             }
-            store4(dst4 + f4, e[0], e[1], e[2], e[3]);
+            if (ADAM) {       // the same 16-byte chunk of the parameter and of its two moments: updated where the gradient is
+                float4* p4 = reinterpret_cast<float4*>(ad.rest + off) + f4;
+                float4* m4 = reinterpret_cast<float4*>(ad.m_rest + off) + f4;
+                float4* s4 = reinterpret_cast<float4*>(ad.v_rest + off) + f4;
+                float4 pp = *p4, mm = *m4, ss = *s4;
+                ts::adam_update(pp.x, e[0], mm.x, ss.x, ad.c_rest); ts::adam_update(pp.y, e[1], mm.y, ss.y, ad.c_rest);
+                ts::adam_update(pp.z, e[2], mm.z, ss.z, ad.c_rest); ts::adam_update(pp.w, e[3], mm.w, ss.w, ad.c_rest);
+                *p4 = pp; *m4 = mm; *s4 = ss;
+            } else {
+                store4(dst4 + f4, e[0], e[1], e[2], e[3]);
+            }
         }
     } else {
-        for (int f = tid; f < total; f += kShThreadsBwd) dst[f] = lds[(f / RS) * RSP + (f % RS)];
+        for (int f = tid; f < total; f += kShThreadsBwd) {
+            const float e = lds[(f / RS) * RSP + (f % RS)];
+            if (ADAM) {
+                float p_ = ad.rest[off + f], m_ = ad.m_rest[off + f], s_ = ad.v_rest[off + f];
+                ts::adam_update(p_, e, m_, s_, ad.c_rest);
+                ad.rest[off + f] = p_; ad.m_rest[off + f] = m_; ad.v_rest[off + f] = s_;
+            } else {
+                dst[f] = e;
+            }
+        }
     }
 }
 
@@ -475,9 +562,39 @@ int ts_project_bwd(int32_t n, const float* means3d, const float* scales, const f
         !v_conic || !v_means3d || !v_scales || !v_quats)
         return TS_E_BADARG;
     const int grid = (n + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, viewmat, projmat, *cam, (int)flags, radii, v_xy, v_depth,
-                       v_conic, v_cov3d, v_means3d, v_scales, v_quats);
+                       v_conic, v_cov3d, v_means3d, v_scales, v_quats, ProjAdam{});
+    return launch_status();
+}
+
+static bool adam_group_ok(const ts_adam* a, int k) {
+    return a->exp_avg[k] && a->exp_avg_sq[k] && a->step[k] >= 1;
+}
+
+int ts_project_bwd_adam(int32_t n, float* means3d, float* scales, float* quats, const float* viewmat,
+                        const float* projmat, const ts_camera* cam, int32_t flags, const int32_t* radii,
+                        const float* v_xy, const float* v_depth, const float* v_conic, float* opacities,
+                        const float* v_opacity, const ts_adam* adam, void* stream) {
+    if (n < 0 || !cam || !adam) return TS_E_BADARG;
+    if (n == 0) return 0;
+    if (!means3d || !scales || !quats || !viewmat || !projmat || !radii || !v_xy || !v_conic) return TS_E_BADARG;
+    if (!adam_group_ok(adam, TS_ADAM_MEANS) || !adam_group_ok(adam, TS_ADAM_SCALES) || !adam_group_ok(adam, TS_ADAM_QUATS))
+        return TS_E_BADARG;
+    if (opacities && (!v_opacity || !adam_group_ok(adam, TS_ADAM_OPACITIES))) return TS_E_BADARG;
+    ProjAdam ad{};
+    ad.means = means3d; ad.scales = scales; ad.quats = quats; ad.opacities = opacities; ad.v_opacity = v_opacity;
+    ad.m_means = adam->exp_avg[TS_ADAM_MEANS]; ad.v_means = adam->exp_avg_sq[TS_ADAM_MEANS];
+    ad.m_scales = adam->exp_avg[TS_ADAM_SCALES]; ad.v_scales = adam->exp_avg_sq[TS_ADAM_SCALES];
+    ad.m_quats = adam->exp_avg[TS_ADAM_QUATS]; ad.v_quats = adam->exp_avg_sq[TS_ADAM_QUATS];
+    ad.m_opac = adam->exp_avg[TS_ADAM_OPACITIES]; ad.v_opac = adam->exp_avg_sq[TS_ADAM_OPACITIES];
+    auto coef = [&](int k) { return ts::adam_coef(adam->lr[k], adam->step[k], adam->beta1, adam->beta2, adam->eps); };
+    ad.c_means = coef(TS_ADAM_MEANS); ad.c_scales = coef(TS_ADAM_SCALES); ad.c_quats = coef(TS_ADAM_QUATS);
+    if (opacities) ad.c_opac = coef(TS_ADAM_OPACITIES);
+    const int grid = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, viewmat, projmat, *cam, (int)flags, radii, v_xy, v_depth,
+                       v_conic, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, ad);
     return launch_status();
 }
 
@@ -620,25 +737,25 @@ int ts_colors_pack_fwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, con
                              clamp_mask, live, pk, stream);
 }
 
-int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
-                     const float* origin, const uint8_t* clamp_mask, const float* v_colors,
-                     float* v_colors_dc, float* v_colors_rest, void* stream) {
-    const int chk = sh_check(n, degrees_to_use, num_bases);
-    if (chk) return chk;
-    if (n == 0) return 0;
-    if (!means3d || !origin || !v_colors || !v_colors_dc || (num_bases > 1 && !v_colors_rest))
-        return TS_E_BADARG;
+static int sh_colors_bwd_launch(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                                const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                                float* v_colors_dc, float* v_colors_rest, const ShAdam* ad, void* stream) {
     const int grid = (n + kShThreadsBwd - 1) / kShThreadsBwd;
     const size_t lds = (size_t)kShThreadsBwd * ((3 * (num_bases - 1)) | 1) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define TS_SHC_BWD(D)                                                                             \
-    do {                                                                                          \
-        if (lds > 48 * 1024)                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_bwd_kernel<D>),    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(sh_colors_bwd_kernel<D>, dim3(grid), dim3(kShThreadsBwd), lds, s, n,    \
-                           num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,         \
-                           v_colors_rest);                                                        \
+#define TS_SHC_BWD2(D, A)                                                                            \
+    do {                                                                                             \
+        if (lds > 48 * 1024)                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh_colors_bwd_kernel<D, A>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((sh_colors_bwd_kernel<D, A>), dim3(grid), dim3(kShThreadsBwd), lds, s, n, \
+                           num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,            \
+                           v_colors_rest, ad ? *ad : ShAdam{});                                      \
+    } while (0)
+#define TS_SHC_BWD(D)                                       \
+    do {                                                    \
+        if (ad) TS_SHC_BWD2(D, true);                       \
+        else TS_SHC_BWD2(D, false);                         \
     } while (0)
     switch (degrees_to_use) {
         case 0: TS_SHC_BWD(0); break;
@@ -648,7 +765,41 @@ int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const
         default: TS_SHC_BWD(4); break;
     }
 #undef TS_SHC_BWD
+#undef TS_SHC_BWD2
     return launch_status();
+}
+
+int ts_sh_colors_bwd(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                     const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                     float* v_colors_dc, float* v_colors_rest, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!means3d || !origin || !v_colors || !v_colors_dc || (num_bases > 1 && !v_colors_rest))
+        return TS_E_BADARG;
+    return sh_colors_bwd_launch(n, degrees_to_use, num_bases, means3d, origin, clamp_mask, v_colors, v_colors_dc,
+                                v_colors_rest, nullptr, stream);
+}
+
+int ts_sh_colors_bwd_adam(int32_t n, int32_t degrees_to_use, int32_t num_bases, const float* means3d,
+                          const float* origin, const uint8_t* clamp_mask, const float* v_colors,
+                          float* colors_dc, float* colors_rest, const ts_adam* adam, void* stream) {
+    const int chk = sh_check(n, degrees_to_use, num_bases);
+    if (chk) return chk;
+    if (n == 0) return 0;
+    if (!adam || !means3d || !origin || !v_colors || !colors_dc || (num_bases > 1 && !colors_rest)) return TS_E_BADARG;
+    if (!adam_group_ok(adam, TS_ADAM_COLORS_DC) || (num_bases > 1 && !adam_group_ok(adam, TS_ADAM_COLORS_REST)))
+        return TS_E_BADARG;
+    ShAdam ad{};
+    ad.dc = colors_dc; ad.rest = colors_rest;
+    ad.m_dc = adam->exp_avg[TS_ADAM_COLORS_DC]; ad.v_dc = adam->exp_avg_sq[TS_ADAM_COLORS_DC];
+    ad.m_rest = adam->exp_avg[TS_ADAM_COLORS_REST]; ad.v_rest = adam->exp_avg_sq[TS_ADAM_COLORS_REST];
+    ad.c_dc = ts::adam_coef(adam->lr[TS_ADAM_COLORS_DC], adam->step[TS_ADAM_COLORS_DC], adam->beta1, adam->beta2, adam->eps);
+    if (num_bases > 1)
+        ad.c_rest = ts::adam_coef(adam->lr[TS_ADAM_COLORS_REST], adam->step[TS_ADAM_COLORS_REST], adam->beta1, adam->beta2,
+                                  adam->eps);
+    return sh_colors_bwd_launch(n, degrees_to_use, num_bases, means3d, origin, clamp_mask, v_colors, nullptr, nullptr, &ad,
+                                stream);
 }
 
 int ts_bench_gather48(const float* records, const int32_t* ids, int64_t m, float* sink, void* stream) {

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -317,8 +318,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(const AdamTable t, float
     const float* __restrict__ g = t.g[ti];
     float* __restrict__ m = t.m[ti];
     float* __restrict__ v = t.v[ti];
-    const float step = t.step_size[ti];
-    const float bc2_sqrt = t.bc2_sqrt[ti];
+    const ts::AdamCoef coef = {beta1, beta2, eps, t.step_size[ti], t.bc2_sqrt[ti]};     // (adam_math.h: one update, every caller)
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * kThreads;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
@@ -327,22 +327,16 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(const AdamTable t, float
         float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
         float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            M[k] = beta1 * M[k] + (1.0f - beta1) * G[k];
-            V[k] = beta2 * V[k] + (1.0f - beta2) * G[k] * G[k];
-            P[k] -= step * (M[k] / (sqrtf(V[k]) / bc2_sqrt + eps));
-        }
+        for (int k = 0; k < 4; ++k) ts::adam_update(P[k], G[k], M[k], V[k], coef);
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
     }
     if (blockIdx.x == 0) {
         for (long long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) {
-            const float gi = g[i];
-            const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-            const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-            m[i] = mi; v[i] = vi;
-            p[i] -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+            float pi = p[i], mi = m[i], vi = v[i];
+            ts::adam_update(pi, g[i], mi, vi, coef);
+            p[i] = pi; m[i] = mi; v[i] = vi;
         }
     }
 }
@@ -422,10 +416,9 @@ int ts_adam_step(int32_t num_tensors, float* const* params, const float* const* 
             return TS_E_BADARG;
         // double-precision bias corrections as torch.optim.Adam computes them on the host; the step
         // count is per tensor because torch skips (and does not age) tensors without a gradient
-        const double b1p = __builtin_pow((double)beta1, (double)steps[i]);
-        const double b2p = __builtin_pow((double)beta2, (double)steps[i]);
-        t.step_size[i] = (float)((double)lr[i] / (1.0 - b1p));
-        t.bc2_sqrt[i] = (float)__builtin_sqrt(1.0 - b2p);
+        const ts::AdamCoef c = ts::adam_coef(lr[i], steps[i], beta1, beta2, eps);
+        t.step_size[i] = c.step_size;
+        t.bc2_sqrt[i] = c.bc2_sqrt;
         if (t.n[i] > maxn) maxn = t.n[i];
     }
     if (maxn == 0) return 0;

@@ -572,6 +572,38 @@ def _steps_bwd_params(lib, fr, s):
           fr.cam, 3, fr.radii, fr.v_xy, fr.v_depth, fr.v_conic, None, fr.v_means, fr.v_scales, fr.v_quats, s)
 
 
+# FUSED ADAM (training.TrainStep; csrc/project.hip: FUSED ADAM): inside ``with fused_adam(optimizer):`` the backward pass of
+# a single-GPU frame hands the optimiser's state to ts_frame_bwd_params_adam - the parameter-stage kernels update the
+# six tensors from the gradients they hold in registers - and returns no parameter gradients (xys.grad is still set).
+class _AdamHook:            # (a plain object, not thread-local: autograd runs a CUDA frame's backward on its device thread)
+    opt = None
+
+
+_adam_hook = _AdamHook()
+
+
+class fused_adam:
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
+
+    def __enter__(self):
+        self.prev = getattr(_adam_hook, "opt", None)
+        _adam_hook.opt = self.optimizer
+        return self
+
+    def __exit__(self, *exc):
+        _adam_hook.opt = self.prev
+        return False
+
+
+def _steps_bwd_params_adam(lib, fr, adam, s):
+    _call("ts_sh_colors_bwd_adam", lib.ts_sh_colors_bwd_adam, fr.n, fr.sh_degree, fr.num_bases, fr.means, fr.origin,
+          None if fr.flags & 16 else fr.sh_mask, fr.v_colors, fr.colors_dc,
+          fr.colors_rest if fr.num_bases > 1 else None, ctypes.byref(adam), s)
+    _call("ts_project_bwd_adam", lib.ts_project_bwd_adam, fr.n, fr.means, fr.scales, fr.quats, fr.view34, fr.projview,
+          fr.cam, 3, fr.radii, fr.v_xy, fr.v_depth, fr.v_conic, fr.opacities, fr.v_opacity, ctypes.byref(adam), s)
+
+
 class _RenderFrame(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacities, colors_dc, colors_rest, view34, projview,
@@ -625,11 +657,14 @@ class _RenderFrame(torch.autograd.Function):
             partials = torch.empty((rows, _lib.PARTIAL_ROW_FLOATS), **f32)
             row_flags, fr.flag_gen = row_flags_for(dev, rows)
             _mark("bwd:flat+partials+flags")
-            v_means = torch.empty((n, 3), **f32)
-            v_scales = torch.empty((n, 3), **f32)
-            v_quats = torch.empty((n, 4), **f32)
-            v_dc = torch.empty((n, 3), **f32)
-            v_rest = torch.empty(tuple(ctx.rest_shape), **f32)
+            opt = getattr(_adam_hook, "opt", None)
+            adam = opt.fused_begin(F.inputs[:6]) if (opt is not None and single) else None     # None: not this model's tensors
+            if adam is None:
+                v_means = torch.empty((n, 3), **f32)
+                v_scales = torch.empty((n, 3), **f32)
+                v_quats = torch.empty((n, 4), **f32)
+                v_dc = torch.empty((n, 3), **f32)
+                v_rest = torch.empty(tuple(ctx.rest_shape), **f32)
             p = flat.data_ptr()
             fr.v_out_img = None if v_img is None else v_img.data_ptr()
             fr.v_out_depth = None if (not F.planes or v_depth_img is None) else v_depth_img.data_ptr()
@@ -642,8 +677,9 @@ class _RenderFrame(torch.autograd.Function):
                 fr.v_xy, fr.v_conic, fr.v_colors = p, p + 8 * n, p + 20 * n
                 fr.v_depth = p + 32 * n if ch == 4 else None
                 fr.v_opacity = p + (20 + 4 * ch) * n
-            fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
-            fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
+            if adam is None:
+                fr.v_means, fr.v_scales, fr.v_quats = v_means.data_ptr(), v_scales.data_ptr(), v_quats.data_ptr()
+                fr.v_colors_dc, fr.v_colors_rest = v_dc.data_ptr(), v_rest.data_ptr()
             _mark("bwd:allocated")
             timed = kernel_timer.enabled
             if timed:
@@ -654,7 +690,13 @@ class _RenderFrame(torch.autograd.Function):
                 with collective_timer.span(on_device=flat.is_cuda and dist.get_backend(ctx.group) != "gloo",
                                            label="all_reduce(2-D gradients)", nbytes=flat.numel() * flat.element_size()):
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
-            if timed:
+            if adam is not None:
+                if timed:
+                    _steps_bwd_params_adam(lib, fr, adam, s)
+                else:
+                    _lib.check(lib.ts_frame_bwd_params_adam(ctypes.byref(fr), ctypes.byref(adam), s),
+                               "ts_frame_bwd_params_adam")
+            elif timed:
                 _steps_bwd_params(lib, fr, s)
             else:
                 _lib.check(lib.ts_frame_bwd_params(ctypes.byref(fr), s), "ts_frame_bwd_params")
@@ -669,6 +711,8 @@ class _RenderFrame(torch.autograd.Function):
         xo = ctx.xys_out
         xo.grad = v_xy if xo.grad is None else xo.grad + v_xy
         _mark("bwd:exit")
+        if adam is not None:          # the parameters were updated in place: no gradients to hand out
+            return (None,) * 19
         return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 13
 
 

@@ -193,6 +193,7 @@ class Adam:
         self.steps = {n: 0 for n in self.names}       # per tensor, as torch.optim.Adam's state['step']
         self.exp_avg = {n: torch.zeros_like(p) for n, p in self.params.items()}
         self.exp_avg_sq = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        self.fused_steps, self._fused_pending = 0, False
 
     @torch.no_grad()
     def step(self) -> None:
@@ -207,6 +208,9 @@ class Adam:
                 raise ValueError("Adam parameters must be contiguous float32")
         for n in names:
             self.steps[n] += 1
+        names = [n for n in names if self.params[n].numel() > 0]       # (colors_rest of an SH-0 model: nothing to update)
+        ps = [self.params[n] for n in names]
+        gs = [_f32c(self.params[n].grad) for n in names]
         k = len(names)
         PtrArr, LArr, FArr = ctypes.c_void_p * k, ctypes.c_int64 * k, ctypes.c_float * k
         IArr = ctypes.c_int32 * k
@@ -224,12 +228,39 @@ class Adam:
         for p in self.params.values():
             p.grad = None
 
+    # ---- FUSED ADAM (frame.fused_adam; csrc/project.hip): the frame's backward pass applies this optimiser's update itself
+    def fused_begin(self, tensors):
+        """Called by the frame's backward pass with the six tensors the frame rendered from, in the order (means,
+        scales, quats, opacities, colors_dc, colors_rest).  -> the ``ts_adam`` struct for ts_frame_bwd_params_adam with
+        every group's step advanced, or None when these are not this optimiser's own (contiguous float32) tensors."""
+        order = ("means", "scales", "quats", "opacities", "colors_dc", "colors_rest")
+        if any(n not in self.params for n in PARAM_ORDER):
+            return None
+        for n, t in zip(order, tensors):
+            p = self.params[n]
+            if t.data_ptr() != p.data_ptr() or t.shape != p.shape or not p.is_contiguous() or p.dtype != torch.float32:
+                return None
+        a = _lib.TsAdam()
+        for k, n in enumerate(PARAM_ORDER):
+            self.steps[n] += 1
+            a.exp_avg[k], a.exp_avg_sq[k] = self.exp_avg[n].data_ptr(), self.exp_avg_sq[n].data_ptr()
+            a.lr[k], a.step[k] = self.lrs.get(n, 1e-3), self.steps[n]
+        a.beta1, a.beta2, a.eps = self.betas[0], self.betas[1], self.eps
+        self.fused_steps += 1
+        self._fused_pending = True
+        return a
+
+    def consume_fused(self) -> bool:
+        """True once after a backward pass that applied the update itself (the caller then skips ``step()``)"""
+        done, self._fused_pending = self._fused_pending, False
+        return done
+
 
 class TrainStep:
     """render -> loss -> backward -> Adam, one call per iteration (train.py:45-106 minus policy)."""
 
     def __init__(self, model, device, lambda_dssim: float = 0.2, lambda_depth: float = 0.2,
-                 lrs: Optional[Dict[str, float]] = None, scene: Optional[Scene] = None):
+                 lrs: Optional[Dict[str, float]] = None, scene: Optional[Scene] = None, fused_adam: bool = True):
         self.model, self.device = model, torch.device(device)
         self.lambda_dssim, self.lambda_depth = lambda_dssim, lambda_depth
         # the reference's loop renders through scene.render(camera) (train.py:55 -> scene.py:222-223)
@@ -237,6 +268,10 @@ class TrainStep:
         self.rasterizer = self.scene.rasterizer
         model.requires_grad_(True)
         self.optimizer = Adam({n: getattr(model, n) for n in PARAM_ORDER}, lrs)
+        # fused_adam: the frame's backward pass applies the Adam update to the gradients it holds in registers (the same
+        # update, bit for bit: tests/test_gpu_training.py) and no parameter gradient tensor is written - model.<p>.grad
+        # stays None, extras['xys'].grad is set as always.  False: backward, then one ts_adam_step launch.
+        self.fused_adam = bool(fused_adam)
         _hold(model, "TrainStep")        # per-row state now exists outside the model: see SplatModel.spatial_sort_
 
     def __call__(self, camera, target_rgb: Tensor, target_depth: Optional[Tensor] = None,
@@ -262,8 +297,15 @@ class TrainStep:
             loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
             if target_depth is not None:                          # train.py:65-69
                 loss = loss + self.lambda_depth * (extras["depth"] - target_depth).abs().mean()
-        loss.backward()
-        self.optimizer.step()
+        if self.fused_adam:
+            from .frame import fused_adam
+            with fused_adam(self.optimizer):
+                loss.backward()
+            if not self.optimizer.consume_fused():          # a render path without the one-node frame: the two-launch step
+                self.optimizer.step()
+        else:
+            loss.backward()
+            self.optimizer.step()
         xys_grad = extras["xys"].grad                          # consumed by densification (F2)
         if densifier is not None:
             if step is None:

@@ -32,7 +32,7 @@ GRID = [(0, 8, 13, 3), (0, 8, 12, 3), (0, 8, 14, 3), (0, 8, 10, 4), (0, 8, 13, 0
 
 
 def timed(step, k):
-    for _ in range(4):
+    for _ in range(8):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -82,6 +82,12 @@ for sc in args.scenes.split(","):
                 results.append((timed(step, args.steps), (mode, S, W16, C16)))
             except Exception as e:                              # noqa: BLE001 - a setting a launch shape does not take
                 results.append((float("inf"), (mode, S, W16, C16)))
+        # the automatic policy once more BEHIND the grid: the first timing of a scene also carries its first-frame effects
+        # (allocator pools, the list mode settling, the clock ramp) - the smaller of the two counts
+        for k_, v in auto.items():
+            setattr(frame, k_, v)
+        frame._pairs_per_tile.clear()
+        t_auto = min(t_auto, timed(step, args.steps))
         best = min(results)
         print(f"{sc:10s} {w}x{h:<5d} bbox pairs/tile {per_tile:7.0f}  longest list {int(lens.max()):6d}  auto (mode {mode_auto}) "
               f"{t_auto:7.3f} ms | best {best[1]} {best[0]:7.3f} ms | regret {100.0 * (t_auto / best[0] - 1.0):+5.1f} %   all: "

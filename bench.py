@@ -401,7 +401,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=1_000_000,
+                    help="(--gaussians: the spelling to use behind torch.distributed.run, whose own parser takes --n for an "
+                         "ambiguous abbreviation of --nnodes / --nproc-per-node)")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

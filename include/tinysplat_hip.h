@@ -204,6 +204,11 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
  * with exact sizes.  NULL / -1: no guard. */
 int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
                     const int32_t* cum_tiles_hit, int64_t capacity, void* stream);
+/* ... and the length of the frame's LONGEST list stored to *longest_list (device-visible memory - e.g. the word behind
+ * the caller's mapped pinned count word; NULL: ts_tile_offsets): a scene statistic for the caller's launch policy
+ * (frame.py: list shape and hybrid shares), read a frame later, never waited for. */
+int ts_tile_offsets_stats(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
+                          const int32_t* cum_tiles_hit, int64_t capacity, int32_t* longest_list, void* stream);
 
 /* Writes the id of every Gaussian into the bucket of each tile its rectangle covers (bucket_ids[I];
  * order inside a bucket is arbitrary until ts_sort_tiles).  scratch: NULL, or I more int32 (the
@@ -342,6 +347,8 @@ int ts_reduce_partials(int32_t n, int32_t channels, int32_t flags, const int32_t
 #define TS_FRAME_DIRECT_SCATTER 32     /* one-hop ts_bin_scatter (scratch = NULL): A/B timing */
 #define TS_FRAME_PLANES 64             /* channels = 4: RGB and depth as two planes (out_img[P,3] + out_depth[P];
                                           v_out_img / v_out_depth, either may be NULL), see ts_raster_fwd_planes */
+#define TS_FRAME_LIST_STATS 256        /* total_host points at (at least) TWO mapped words: ts_frame_fwd_prepare stores the
+                                        * length of the frame's longest list into word 1 (ts_tile_offsets_stats) */
 #define TS_FRAME_SEPARATE_SORT 128     /* ts_sort_tiles + ts_raster_fwd_planes even where ts_raster_fwd_sort applies: A/B */
 #define TS_FRAME_STRIPE 16             /* one stripe of a multi-GPU frame: colour stage only for the Gaussians the
                                           stripe lists, clamp mask applied in reduce_partials (before the all-reduce) */

@@ -39,6 +39,8 @@ def _fresh_list_mode_history():
     fr = sys.modules.get("tinysplat_amd.frame")
     if fr is not None:
         fr._pairs_per_tile.clear()
+        fr._longest_list.clear()
+        fr._stats_mode.clear()
     yield
 
 

@@ -99,11 +99,12 @@ def test_row_flags_are_kept_through_alternating_pass_sizes(monkeypatch):
     t, g = frame.row_flags_for(DEV, small)                # the fifth: given back, a small fresh array, generation 1
     assert t.numel() < big // 8 and g == 1 and int(t.max()) == 0
     for k in range(40):                                   # (device, stream) keys of streams that are gone do not pile up:
-        frame._row_flags[(DEV.index, -1000 - k)] = [t, 1, 0]
+        frame._row_flags[(DEV.index, -1000 - k)] = [t, 1, 0, k]      # (last-used ticks 0 .. 39: the least recently used goes first)
     before = len(frame._row_flags)
     with torch.cuda.stream(torch.cuda.Stream(DEV)):       # a stream the table has not seen: one entry in, one out
         frame.row_flags_for(DEV, small)
     assert len(frame._row_flags) == before >= 32
+    assert (DEV.index, -1000) not in frame._row_flags and key in frame._row_flags      # the LEAST RECENTLY used entry went, not the oldest
     for k_ in [k_ for k_ in frame._row_flags if k_[1] <= -1000]:
         del frame._row_flags[k_]
 

@@ -169,3 +169,28 @@ def test_config5_weight_checksum_and_high_overlap_variant(scene5):
         print(f"scale_mult {mult}: N {n}, I {b.num_intersects}, max per tile {per_tile}")
         if mult == 4.0:
             assert per_tile > 2048          # lists far beyond one 64-entry LDS chunk / one sort network
+
+
+def test_longest_list_statistic_reaches_the_policy():
+    """ts_tile_offsets_stats (TS_FRAME_LIST_STATS): the frame's longest list lands in the word behind the pinned count
+    word and the NEXT frame's policy sees it - checked against the lists themselves, on 16x16 and on wide lists."""
+    import ctypes
+    from tinysplat_amd import frame
+    from tinysplat_amd.synthetic import make_scene
+    dev = torch.device(DEV)
+    model, cam = make_scene(60000, 1, 640, 368, seed=21, scale_mult=3.0, clustered=0.6)
+    model = model.to(dev)
+    for mode in (0, 2):
+        frame.WIDE_TILES = mode
+        try:
+            with torch.no_grad():
+                GaussianRasterizer(model, None, device=dev)(cam, None, 1)
+                torch.cuda.synchronize()
+                b = frame.last_binning[dev.index]
+                want = int((b.tile_bins[:, 1] - b.tile_bins[:, 0]).max().item())
+                word = ctypes.c_int32.from_address(frame._pinned_total[dev.index][0].data_ptr() + 4).value
+                assert word == want and want > 0
+                GaussianRasterizer(model, None, device=dev)(cam, None, 1)          # the next frame reads it
+                assert frame._longest_list[dev.index] == (want, mode)
+        finally:
+            frame.WIDE_TILES = "auto"

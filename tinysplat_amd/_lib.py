@@ -108,6 +108,7 @@ SIGNATURES = {
     "ts_bin_ws_ints": (c_int64, [c_int32, c_int32]),
     "ts_bin_count": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P]),
     "ts_tile_offsets": (c_int32, [c_int32, c_int32, _P, _P, _P, c_int64, _P]),
+    "ts_tile_offsets_stats": (c_int32, [c_int32, c_int32, _P, _P, _P, c_int64, _P, _P]),
     "ts_bin_scatter": (c_int32, [c_int32, _P, _P, _P, _CAM, _P, _P, _P, _P]),
     "ts_sort_tiles": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "ts_sort_tiles_above": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P]),

@@ -475,11 +475,13 @@ __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_t
                                                                        int* __restrict__ tile_bins,
                                                                        int* __restrict__ spare,
                                                                        const int* __restrict__ total_ptr,
-                                                                       long long capacity) {
+                                                                       long long capacity, int* __restrict__ longest_out) {
     constexpr int kPer = 8;
-    __shared__ int carry, over;
+    __shared__ int carry, over, longest;
+    int my_longest = 0;
     if (threadIdx.x == 0) {
         carry = 0;
+        longest = 0;
         *spare = 0;                                       // the workspace's last word: ts_sort_tiles' tile counter
         over = (total_ptr && capacity >= 0 && ((long long)*total_ptr > capacity || *total_ptr < 0)) ? 1 : 0;
         spare[-1] = over;
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_t
         for (int e = 0; e < kPer; ++e) {
             v[e] = (t0 + e < num_tiles) ? tile_total[t0 + e] : 0;
             sum += v[e];
+            my_longest = max(my_longest, v[e]);
         }
         int total;
         const int inc = block_inclusive_scan<kOffsetsThreads / 64>(sum, &total);
@@ -517,6 +520,11 @@ __global__ __launch_bounds__(kOffsetsThreads) void tile_offsets_kernel(int num_t
         __syncthreads();
     }
     if (threadIdx.x == 0) tile_total[num_tiles] = carry;     // tile_start[T]: end of the last bucket
+    if (longest_out) {          // the longest list of the frame (a scene statistic for the caller's launch policy; may be mapped host memory)
+        atomicMax(&longest, my_longest);                     // (LDS)
+        __syncthreads();
+        if (threadIdx.x == 0) *longest_out = longest;
+    }
 }
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(
@@ -1027,6 +1035,11 @@ int ts_bin_count(int32_t n, const float* xys, const int32_t* radii, const float*
 
 int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
                     const int32_t* cum_tiles_hit, int64_t capacity, void* stream) {
+    return ts_tile_offsets_stats(n, num_tiles, bin_ws, tile_bins, cum_tiles_hit, capacity, nullptr, stream);
+}
+
+int ts_tile_offsets_stats(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile_bins,
+                          const int32_t* cum_tiles_hit, int64_t capacity, int32_t* longest_list, void* stream) {
     if (n < 0 || num_tiles < 0) return TS_E_BADARG;
     if (num_tiles == 0) return 0;
     if (!bin_ws || !tile_bins) return TS_E_BADARG;
@@ -1038,7 +1051,7 @@ int ts_tile_offsets(int32_t n, int32_t num_tiles, int32_t* bin_ws, int32_t* tile
                        dim3(kColTiles * kScanGroups), 0, s, num_tiles, chunks, per_group, bin_ws, tile_total);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kOffsetsThreads), 0, s, num_tiles, tile_total,
                        tile_bins, bin_ws + (ts_bin_ws_ints(n, num_tiles) - 1),
-                       (cum_tiles_hit && n > 0) ? cum_tiles_hit + (n - 1) : nullptr, (long long)capacity);
+                       (cum_tiles_hit && n > 0) ? cum_tiles_hit + (n - 1) : nullptr, (long long)capacity, longest_list);
     return launch_status();
 }
 

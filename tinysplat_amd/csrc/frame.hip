@@ -120,7 +120,14 @@ int ts_frame_fwd_prepare(const ts_frame* f, void* stream) {
                               &f->cam, f->channels == 4 ? f->depths : nullptr, f->splats, stream));
     const float* tight = (f->flags & TS_FRAME_TIGHT) ? f->splats : nullptr;
     TS_TRY(ts_bin_count(f->n, f->xys, f->radii, tight, &f->cam, f->bin_ws, stream));
-    TS_TRY(ts_tile_offsets(f->n, num_tiles(f), f->bin_ws, f->tile_bins, f->cum_tiles_hit, f->capacity, stream));
+    // (TS_FRAME_LIST_STATS: the longest list goes to the word behind the count word - read a frame later by the caller's
+    // launch policy, never waited for)
+    int32_t* longest = nullptr;
+    if ((f->flags & TS_FRAME_LIST_STATS) && f->total_host) {
+        int32_t* dev = mapped_pointer(f->total_host);
+        if (dev) longest = dev + 1;
+    }
+    TS_TRY(ts_tile_offsets_stats(f->n, num_tiles(f), f->bin_ws, f->tile_bins, f->cum_tiles_hit, f->capacity, longest, stream));
     return 0;
 }
 

@@ -94,26 +94,26 @@ HYBRID_COOP16 = max(0, min(15, int(os.environ.get("TS_HYBRID_COOP16", "3"))))
 COOP_SPLIT = os.environ.get("TS_COOP_SPLIT", "1") != "0"
 
 
-def set_launch_hints(cam, segs: int, w16: int, mode: int, split: bool) -> None:
+def set_launch_hints(cam, segs: int, w16: int, mode: int, split: bool, skewed: bool = False) -> None:
     """The compositing launches' fields of ``cam.hints``: list segments / whole-tile share (bits 8..15), cooperative
     tiles of the forward launch (bits 16..20)."""
     cam.hints = (cam.hints & ~0x1FFF00) | (((segs << 8) | (w16 << 12)) if segs > 1 else 0)
     tiles16 = cam.tile_rows * cam.tile_bounds_x
     if mode == 0 and not split and tiles16 >= HYBRID_FROM:
-        cam.hints |= HYBRID_COOP16 << 16
+        cam.hints |= (HYBRID_MID_COOP16 if skewed else HYBRID_COOP16) << 16
     elif mode == 0 and not split and tiles16 >= HYBRID_MID_FROM:
         cam.hints |= HYBRID_MID_COOP16 << 16
     if mode == 0 and split and COOP_SPLIT:
         cam.hints |= _lib.HINT_COOP_SPLIT
 
 
-def _list_segments(tiles16: int, mode: int, split: bool):
+def _list_segments(tiles16: int, mode: int, split: bool, skewed: bool = False):
     """-> (S, W16): list segments the forward pass prepares for (1 = none) and the whole-tile share of a hybrid launch"""
     if mode != 0 or tiles16 <= 0:
         return 1, 0
     if not split:
         if HYBRID_SEGS > 1 and tiles16 >= HYBRID_FROM:
-            return HYBRID_SEGS, HYBRID_WHOLE16
+            return HYBRID_SEGS, (HYBRID_MID_WHOLE16 if skewed else HYBRID_WHOLE16)
         if HYBRID_SEGS > 1 and tiles16 >= HYBRID_MID_FROM:
             return HYBRID_SEGS, HYBRID_MID_WHOLE16
         return 1, 0
@@ -169,13 +169,45 @@ BALANCED_WALK_FROM = float(os.environ.get("TS_BALANCED_WALK_FROM", "10"))     # 
 _pairs_per_tile = {}    # device index -> bounding-box pairs per 16x16 tile of the most recent frame
 
 
+# ROUND 6 (tools/policy_regret.py, profiles/r06e_policy_regret.txt): on scenes the constants above were not fitted on, the
+# policy was within 5 % of the best forced setting at 720p / 1080p, but at 4K (32 400 tiles) with SHORT lists - 500
+# pairs per tile - wide lists beat the 16x16 choice by 6 % (uniform scene) and 16 % (opaque scene): with that many lists
+# the per-list costs (offsets, sort launches, a wave's prologue / epilogue per tile) weigh more than the longer walks,
+# while a CLUSTERED scene (80 % of the Gaussians in 5 % of the image: longest list 5 900 at 567 pairs per tile) loses
+# 8 % with wide lists - its few very long lists leave the sorting networks - and wants more of its tiles cut.  The pair
+# count alone cannot tell these apart; the LONGEST list can: ts_tile_offsets_stats stores it behind the count word
+# (TS_FRAME_LIST_STATS), and the next frame's policy reads it - never waits for it:
+#   * many tiles (>= MANY_TILES_FROM) and no long list (< LONG_LIST on 16x16 lists, twice that on wide ones): wide lists;
+#   * a skewed scene (longest list >= SKEW_FROM x the bounding-box pairs per tile) on 16x16 lists: the hybrid launch
+#     cuts most tiles (the mid-range shares W16 = 6, C16 = 6) instead of the last 3/16.
+MANY_TILES_FROM = int(os.environ.get("TS_MANY_TILES_FROM", "20000"))
+LONG_LIST = int(os.environ.get("TS_LONG_LIST", "2048"))
+SKEW_FROM = float(os.environ.get("TS_SKEW_FROM", "4"))
+_stats_mode = {}        # device index -> list mode of the frame that last asked for the statistic (full frames only)
+_longest_list = {}      # device index -> (longest list of the most recent frame whose statistic has arrived, its list mode)
+
+
 def _list_mode(dev_index: int, tiles16: int) -> int:
     if WIDE_TILES != "auto":
         return int(WIDE_TILES)
     prev = _pairs_per_tile.get(dev_index)
     if prev is None:
-        return 2 if tiles16 >= 20000 else 0
-    return 2 if prev >= WIDE_LISTS_FROM else 0
+        return 2 if tiles16 >= MANY_TILES_FROM else 0
+    if prev >= WIDE_LISTS_FROM:
+        return 2
+    st = _longest_list.get(dev_index)
+    if tiles16 >= MANY_TILES_FROM and st is not None:
+        longest, mode = st
+        return 2 if longest < (2 * LONG_LIST if mode == 2 else LONG_LIST) else 0
+    return 0
+
+
+def _skewed(dev_index: int, mode: int) -> bool:
+    """a few lists are far longer than the average one (see above); decided from the previous frame's statistics"""
+    st, prev = _longest_list.get(dev_index), _pairs_per_tile.get(dev_index)
+    if WIDE_TILES != "auto" or mode != 0 or st is None or prev is None or st[1] != 0:
+        return False
+    return st[0] >= SKEW_FROM * max(prev, 1.0)
 
 # binning of the most recent frame per device index (scene statistics for bench.py / tools)
 last_binning = {}
@@ -192,6 +224,7 @@ def _mark(label):
 _pinned_total = {}      # device index -> (pinned int32[1], event): the path's one host read
 _row_flags = {}         # (device index, stream handle) -> [uint8 tensor, generation], see row_flags_for
 _row_flags_lock = threading.Lock()
+_row_flags_tick = [0]   # passes served (least-recently-used eviction of _row_flags)
 
 # Row flags of the backward pass (1 byte per partial row: written in THIS pass?).  Instead of zeroing I bytes per
 # frame (a 5-10 us fill launch on the critical path), one array per device lives across frames and every pass
@@ -224,9 +257,13 @@ def row_flags_for(dev: torch.device, rows: int):
         elif slot is not None:
             slot[2] = 0
         if slot is None or slot[0].numel() < rows:
-            if key not in _row_flags and len(_row_flags) >= 32:          # streams that are gone
-                _row_flags.pop(next(iter(_row_flags)))
-            slot = _row_flags[key] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0, 0]
+            if key not in _row_flags and len(_row_flags) >= 32:
+                # the entry that has gone unused the longest (the OLDEST entry may belong to a stream that is
+                # still rendering); its array stays alive through the frames that hold it until their kernels are done
+                _row_flags.pop(min(_row_flags, key=lambda k_: _row_flags[k_][3]))
+            slot = _row_flags[key] = [torch.zeros((int(rows * 1.25) + 4096,), dtype=torch.uint8, device=dev), 0, 0, 0]
+        _row_flags_tick[0] += 1
+        slot[3] = _row_flags_tick[0]
         slot[1] += 1
         if slot[1] > 255:
             slot[0].zero_()
@@ -279,7 +316,7 @@ def _total_slot(dev: torch.device):
     if slot is None:
         # the lock makes the word safe to share when two host threads render on one device (a viewer
         # thread beside the training loop): it is held from the sentinel store to the read of the count
-        slot = (torch.zeros((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), threading.Lock())
+        slot = (torch.zeros((4,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), threading.Lock())   # [count, longest list, -, -]
         _pinned_total[dev.index] = slot
     return slot
 
@@ -306,6 +343,11 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     view34, projview, origin = _f32c(view34), _f32c(projview), _f32c(origin)
     w, h = int(width), int(height)
     cam = _camera(fx, fy, w / 2, h / 2, h, w, _tile_bounds(h, w), 1.0, tile_rows=tile_rows)
+    slot_ = _pinned_total.get(dev.index)
+    if slot_ is not None and dev.index in _stats_mode:
+        # the longest list of the most recent frame on this device whose ts_tile_offsets_stats has run (normally the
+        # previous frame; read from the mapped word without waiting - a statistic, not a result)
+        _longest_list[dev.index] = (int(ctypes.c_int32.from_address(slot_[0].data_ptr() + 4).value), _stats_mode[dev.index])
     mode = _list_mode(dev.index, cam.tile_rows * cam.tile_bounds_x)
     cam.wide_tiles = 1 if mode else 0
     # hint for the scatter: the previous frame's bounding-box tiles per Gaussian (results do not depend on it)
@@ -335,8 +377,9 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
     F.split = 0 < cam.tile_rows * cam.tile_bounds_x <= SPLIT_BLOCKS_BELOW
     rows = _stripe_rows(cam)
     m = max(n, 1)
-    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split) if keep else (1, 0)
-    set_launch_hints(cam, segs, w16, mode, F.split)
+    skewed = _skewed(dev.index, mode)
+    segs, w16 = _list_segments(cam.tile_rows * cam.tile_bounds_x, mode, F.split, skewed) if keep else (1, 0)
+    set_launch_hints(cam, segs, w16, mode, F.split, skewed)
     F.segs = segs
     _mark("fwd:inputs checked")
     cur = torch.cuda.current_device()
@@ -378,12 +421,17 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         F.cum = view(7, torch.int32, n, (n,))
         F.tile_bins = view(10, torch.int32, 2 * max(num_tiles, 1), (max(num_tiles, 1), 2))
         host, event, count_lock = _total_slot(dev)
+        timed_ = kernel_timer.enabled        # (per-entry timing issues ts_tile_offsets itself: no statistic in those frames)
         fr = TsFrame()
         fr.n, fr.num_bases, fr.sh_degree, fr.channels = n, nb, int(sh_degree), ch
         # a proper stripe of the frame (one rank of a multi-GPU frame): TS_FRAME_STRIPE
         stripe = STRIPE_SPARSE and cam.tile_rows < cam.tile_bounds_y
+        full = cam.tile_rows == cam.tile_bounds_y
         fr.flags = ((1 if TIGHT_BINNING else 0) | (2 if F.split else 0) | (8 if mode == 2 else 0) | (16 if stripe else 0)
-                    | (0 if TWO_HOP_SCATTER else 32) | (64 if F.planes else 0) | (0 if INLINE_SORT else 128))
+                    | (0 if TWO_HOP_SCATTER else 32) | (64 if F.planes else 0) | (0 if INLINE_SORT else 128)
+                    | (256 if (full and not timed_) else 0))            # TS_FRAME_LIST_STATS (the slot holds four words)
+        if full and not timed_:
+            _stats_mode[dev.index] = mode
         fr.cam = cam
         fr.means, fr.scales, fr.quats, fr.opacities = means.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr()
         fr.colors_dc, fr.colors_rest = colors_dc.data_ptr(), colors_rest.data_ptr()
@@ -431,7 +479,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
             if timed:
                 _steps_project(lib, fr, s)
                 if n > 0:
-                    host.copy_(F.cum[-1:], non_blocking=True)
+                    host[:1].copy_(F.cum[-1:], non_blocking=True)
             else:
                 _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
             issued = n > 0

@@ -22,7 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", default="d2,overlap,clustered,opaque")
 ap.add_argument("--res", default="1280x720,1920x1080,3840x2160")
 ap.add_argument("--n", type=int, default=1_000_000)
-ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--steps", type=int, default=60)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 SCENES = {"d2": {}, "overlap": {"scale_mult": 4.0}, "clustered": {"clustered": 0.8}, "opaque": {"opacity_logit_mean": 3.0}}
@@ -32,7 +32,7 @@ GRID = [(0, 8, 13, 3), (0, 8, 12, 3), (0, 8, 14, 3), (0, 8, 10, 4), (0, 8, 13, 0
 
 
 def timed(step, k):
-    for _ in range(8):
+    for _ in range(20):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -66,7 +66,7 @@ for sc in args.scenes.split(","):
 
         for k_, v in auto.items():
             setattr(frame, k_, v)
-        frame._pairs_per_tile.clear()
+        frame._pairs_per_tile.clear(); frame._longest_list.clear(); frame._stats_mode.clear()
         t_auto = timed(step, args.steps)
         b = frame.last_binning[dev.index]
         tiles16 = b.cam.tile_rows * b.cam.tile_bounds_x
@@ -74,7 +74,12 @@ for sc in args.scenes.split(","):
         mode_auto = frame._list_mode(dev.index, tiles16)
         lens = (b.tile_bins[:, 1] - b.tile_bins[:, 0]).float()
         results = []
-        for mode, S, W16, C16 in GRID:
+        for gi, (mode, S, W16, C16) in enumerate(GRID):
+            if gi == len(GRID) // 2:            # ... and once in the middle of the grid
+                for k_, v in auto.items():
+                    setattr(frame, k_, v)
+                frame._pairs_per_tile.clear(); frame._longest_list.clear(); frame._stats_mode.clear()
+                t_auto = min(t_auto, timed(step, args.steps))
             frame.WIDE_TILES = mode
             frame.HYBRID_SEGS, frame.HYBRID_WHOLE16, frame.HYBRID_COOP16 = S, max(W16, 1), C16
             frame.HYBRID_MID_WHOLE16, frame.HYBRID_MID_COOP16 = max(W16, 1), C16
@@ -86,7 +91,7 @@ for sc in args.scenes.split(","):
         # (allocator pools, the list mode settling, the clock ramp) - the smaller of the two counts
         for k_, v in auto.items():
             setattr(frame, k_, v)
-        frame._pairs_per_tile.clear()
+        frame._pairs_per_tile.clear(); frame._longest_list.clear(); frame._stats_mode.clear()
         t_auto = min(t_auto, timed(step, args.steps))
         best = min(results)
         print(f"{sc:10s} {w}x{h:<5d} bbox pairs/tile {per_tile:7.0f}  longest list {int(lens.max()):6d}  auto (mode {mode_auto}) "

@@ -57,9 +57,9 @@ for N in 1 2 4 8; do
   if [ $DRY = 0 ] && [ "$N" -gt "$GPUS" ]; then echo "== skipping N = $N: $GPUS GPU(s) visible" >&2; continue; fi
   if [ $DRY = 1 ]; then
     [ "$N" -gt 4 ] && continue                                     # rehearsal: 1, 2, 4 ranks on one GPU
-    run "scale_c3_$N" $N --n 200000 --width 960 --height 544
-    [ "$N" -gt 1 ] && run "scale_c3_${N}_balanced" $N --n 200000 --width 960 --height 544 --balance-stripes --shard-mode gaussians
-    [ "$N" = 2 ] && run "scale_c5_$N" $N --n 400000 --width 1920 --height 1080 --depth
+    run "scale_c3_$N" $N --gaussians 200000 --width 960 --height 544
+    [ "$N" -gt 1 ] && run "scale_c3_${N}_balanced" $N --gaussians 200000 --width 960 --height 544 --balance-stripes --shard-mode gaussians
+    [ "$N" = 2 ] && run "scale_c5_$N" $N --gaussians 400000 --width 1920 --height 1080 --depth
   else
     run "scale_c3_$N" $N --config 3
     [ "$N" -gt 1 ] && run "scale_c3_${N}_balanced" $N --config 3 --balance-stripes --shard-mode gaussians

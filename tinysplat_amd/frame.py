@@ -221,6 +221,7 @@ def _mark(label):
         TRACE.append((label, time.perf_counter()))
 
 
+_layouts = {}           # shape key of a frame -> (section offsets, bytes) of its one workspace allocation
 _pinned_total = {}      # device index -> (pinned int32[1], event): the path's one host read
 _row_flags = {}         # (device index, stream handle) -> [uint8 tensor, generation], see row_flags_for
 _row_flags_lock = threading.Lock()
@@ -247,7 +248,7 @@ def row_flags_for(dev: torch.device, rows: int):
     megabytes at every switch - and the table holds at most 32 (device, stream) entries."""
     if not FLAG_GENERATIONS:
         return torch.empty((rows,), dtype=torch.uint8, device=dev), 0
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _stream(dev))
     with _row_flags_lock:
         slot = _row_flags.get(key)
         if slot is not None and slot[0].numel() > 8 * max(rows, 1 << 20):
@@ -392,17 +393,24 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         # frame used to make a dozen); 256-byte aligned sections:
         #   splats[12n] f32 | xys[2n] | conics[3n] | (unused) | depths[n] | radii[n] i32 | nth[n] | cum[n] |
         #   scan_ws | bin_ws | tile_bins[2T] | sh_mask[n] u8 | final_Ts[P] f32 | final_index[P] i32 | clamp_mask[P] u8
-        nscan = int(lib.ts_scan_ws_ints(n))
-        nbin = int(lib.ts_bin_ws_ints(n, num_tiles))
         px = rows * w
-        fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch)) if keep else px      # T_fin + the cut tiles' checkpoints
-        # (the colour stage keeps the colours in registers - ts_colors_pack_fwd - so no colors[n,3] section exists)
-        sizes = [48 * m, 8 * m, 12 * m, 0, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
-                 8 * max(num_tiles, 1)] + ([m, 4 * fin_floats, 4 * px, px] if keep else [])
-        offs, off = [], 0
-        for sz in sizes:
-            offs.append(off)
-            off += (sz + 255) & ~255
+        lkey = (n, num_tiles, w, rows, ch, keep, cam.hints & 0xFFFF00, cam.wide_tiles, cam.tile_rows, cam.tile_row0, cam.tile_bounds_x, cam.img_height)
+        lay = _layouts.get(lkey)
+        if lay is None:                                  # (the same few shapes come back every frame: ~10 us of host time)
+            nscan = int(lib.ts_scan_ws_ints(n))
+            nbin = int(lib.ts_bin_ws_ints(n, num_tiles))
+            fin_floats = int(lib.ts_final_floats(ctypes.byref(cam), ch)) if keep else px      # T_fin + the cut tiles' checkpoints
+            # (the colour stage keeps the colours in registers - ts_colors_pack_fwd - so no colors[n,3] section exists)
+            sizes = [48 * m, 8 * m, 12 * m, 0, 4 * m, 4 * m, 4 * m, 4 * m, 4 * nscan, 4 * nbin,
+                     8 * max(num_tiles, 1)] + ([m, 4 * fin_floats, 4 * px, px] if keep else [])
+            offs, off = [], 0
+            for sz in sizes:
+                offs.append(off)
+                off += (sz + 255) & ~255
+            if len(_layouts) > 64:
+                _layouts.clear()
+            lay = _layouts[lkey] = (offs, off)
+        offs, off = lay
         _mark("fwd:sizes")
         F.wf = torch.empty((off,), dtype=torch.uint8, device=dev)
         _mark("fwd:workspace allocated")
@@ -484,7 +492,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
                 _lib.check(lib.ts_frame_fwd_project(ctypes.byref(fr), s), "ts_frame_fwd_project")
             issued = n > 0
             _mark("fwd:call project")
-            event.record(torch.cuda.current_stream(dev))
+            event.record()                               # (torch's current stream of the current device = dev, set above)
             cap = None
             if est is not None:
                 # everything is enqueued against buffers of the estimated size; the device refuses to use them

@@ -597,6 +597,7 @@ def main():
             raise SystemExit("--train-step is a single-GPU mode")
         from tinysplat_amd.training import TrainStep
         trainer = TrainStep(model, dev)
+        train_snapshot = [p_.detach().clone() for p_ in model.parameters()]     # (see the pre-warm phase of time_steps)
         g_ = torch.Generator().manual_seed(2)
         tgt_rgb = torch.rand(h, w, 3, generator=g_).to(dev)
         tgt_depth = (2.0 + 8.0 * torch.rand(h, w, generator=g_)).to(dev)
@@ -648,6 +649,9 @@ def main():
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides -> (max over ranks of
         the wall time, every rank's own time)."""
         if args.prewarm_ms > 0:          # steady state first (clocks, allocator pools): untimed, see --prewarm-ms
+            for _ in range(4):           # (the first steps carry first-use costs - hundreds of ms: not a step time)
+                step()
+            torch.cuda.synchronize()
             t_pw = time.perf_counter()
             for _ in range(4):
                 step()
@@ -657,9 +661,18 @@ def main():
                 tt = torch.tensor([est], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 est = float(tt.item())
-            for _ in range(max(0, min(2000, int(args.prewarm_ms * 1e-3 / max(est, 1e-5)) - 4))):
+            for _ in range(max(0, min(4000, int(args.prewarm_ms * 1e-3 / max(est, 1e-5)) - 4))):
                 step()
             torch.cuda.synchronize()
+            if trainer is not None:      # a training step MOVES the scene: the timed steps start from the D2 scene again
+                with torch.no_grad():
+                    for p_, p0_ in zip(model.parameters(), train_snapshot):
+                        p_.copy_(p0_)
+                    for n_ in trainer.optimizer.names:
+                        trainer.optimizer.exp_avg[n_].zero_()
+                        trainer.optimizer.exp_avg_sq[n_].zero_()
+                        trainer.optimizer.steps[n_] = 0
+                torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         barrier()

@@ -312,6 +312,18 @@ COUNT_WAIT = os.environ.get("TS_COUNT_WAIT", "spin")
 _SPIN_LIMIT = 50_000_000
 
 
+def alloc_quantum(count: int) -> int:
+    """``count`` rounded up to one of eight sizes per octave (at least 65 536): the per-intersection buffers follow the
+    frame's pair count, which changes with every camera and every optimiser step - and a caching allocator asked for a
+    new size every frame keeps going back to hipMalloc (round 6: the first ~100 steps of a training run took 2.7 ms
+    instead of 1.65 until the pools had seen every size).  <= 12.5 % more than asked for, and sizes that repeat."""
+    count = max(int(count), 1)
+    if count <= 65536:
+        return 65536
+    g = 1 << (count.bit_length() - 4)
+    return (count + g - 1) // g * g
+
+
 def _total_slot(dev: torch.device):
     slot = _pinned_total.get(dev.index)
     if slot is None:
@@ -461,7 +473,7 @@ def _forward(means, scales, quats, opacities, colors_dc, colors_rest, view34, pr
         est = _capacity.get(cap_key) if (CAPACITY_ALLOC and n > 0) else None
 
         def lists(size):
-            cap = (max(int(size), 1) + 63) & ~63
+            cap = alloc_quantum(size)                             # (a multiple of 64; sizes that repeat from frame to frame)
             F.bucket_ids = torch.empty((2 * cap,), **i32)         # bucket_ids | gaussian_ids_sorted
             fr.bucket_ids, fr.gaussian_ids_sorted = F.bucket_ids.data_ptr(), F.bucket_ids.data_ptr() + 4 * cap
             return cap
@@ -710,7 +722,7 @@ class _RenderFrame(torch.autograd.Function):
                 v_opac = torch.empty(tuple(ctx.opacity_shape), **f32)
             F.segs = backward_segments(fr.cam, F.segs, F.total, dev.index)
             rows = max(F.total, 1) * (4 if (F.split and F.segs <= 1) else 1)
-            partials = torch.empty((rows, _lib.PARTIAL_ROW_FLOATS), **f32)
+            partials = torch.empty((alloc_quantum(rows), _lib.PARTIAL_ROW_FLOATS), **f32)
             row_flags, fr.flag_gen = row_flags_for(dev, rows)
             _mark("bwd:flat+partials+flags")
             opt = getattr(_adam_hook, "opt", None)

@@ -54,6 +54,7 @@ SQ_INSTANCES = 32          # SQ_BUSY_CYCLES is summed over 8 XCDs x 4 shader eng
 # C-ABI entry -> stage of SURVEY.md 8(d) D5.  "raster_bwd" is the compositing backward INCLUDING
 # the reduction of the per-(tile, Gaussian) rows (D5 counts the gradient scatter in that stage), so
 # the two entries are timed together when that stage is priced.
+CLASS_WEIGHT = {"ts_raster_fwd": 2.71, "ts_raster_bwd": 2.55}      # pipe cycles per VALU instruction, priced ISA (round 6)
 STAGE_OF = {
     "ts_project_fwd": "project_fwd", "ts_project_bwd": "project_bwd",
     "ts_sh_fwd": "sh_fwd", "ts_sh_colors_fwd": "sh_fwd",
@@ -990,6 +991,16 @@ def main():
                                 if "valu_wave_insts" in c else c["valu_active_quads"] * 4.0 / c["valu_insts"],
                                 "simd_cycles_per_valu_inst": SIMDS * cycles / c["valu_insts"],
                                 "resident_waves_per_simd": c.get("wave_quads", 0.0) * 4.0 / (SIMDS * cycles)})
+            if "frac" in ent:
+                # the same instructions charged what their CLASSES cost on the pipe instead of 2 cycles each (round 4's
+                # micro-benchmarks: v_cmp 4, v_exp / v_rcp 6.2, DPP / select ~3, lane swaps 6.5): the hot loops' ISA priced
+                # that way averages 2.71 (forward) / 2.55 (backward) cycles per instruction - a
+                # STATIC weight from the listing, applied to the counted instructions
+                wgt = CLASS_WEIGHT.get(e)
+                if wgt:
+                    ent["class_weighted"] = {"avg_pipe_cycles_per_inst": wgt, "frac": ent["frac"] * wgt / 2.0,
+                                             "note": "valu.frac with every instruction at its class's pipe cost (static "
+                                                     "weight from the priced ISA of the hot loops, DESIGN.md section 4)"}
             valu[e] = ent
         roofline["valu"] = valu.get(dom_entry)
         out = {

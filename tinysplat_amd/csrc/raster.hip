@@ -71,7 +71,7 @@ namespace {
                                        // (what remains: prologue, sort, staging, epilogue); 4 = backward: the row's lane sums
                                        // added within the lane, no cross-lane reduction; 5 = the per-entry loop (record read,
                                        // mask dispatch, backward: `any` test) WITHOUT the block bodies and flushes; 6 = no
-                                       // in-kernel sort (forward); 7 = backward: bodies, no flush at all
+                                       // in-kernel sort (forward); 7 = backward: bodies, no flush at all; 8 = forward: the exponent evaluated twice per body
                                        // (tools/ablate_frame.sh; profiles/r06d_compositing_ablation.txt)
 #endif
 
@@ -535,7 +535,8 @@ struct LocLds {
 // negation moves into the FMA, vis becomes the select of T - nT - the same bits as |T| - |Tn|: an unfinished pixel has
 // T, nT > 0, and a stopping or finished one selects 0), the one select that keeps its modifiers (T <- -|T| on a stop)
 // stands three instructions behind its compare, and T is updated in place: 21 VALU issues + 1 wait state per body where
-// the compiler had 24 + 5.  Same operations on the same operands: image, final_Ts and final_index are bit for bit the
+// the compiler had 21 + 5 (measured: no change of the launch - a wait state is an issue slot of one wave that its four
+// neighbours fill; what the launch pays for is the pipe cost of the 21 instructions, 56 cycles: DESIGN.md section 4).  Same operations on the same operands: image, final_Ts and final_index are bit for bit the
 // C++ form's (tests/test_gpu_parity.py compares the frame with the oracle; tools/variant_check.py the two builds).
 #ifndef TS_FWD_ASM
 #define TS_FWD_ASM 1
@@ -640,6 +641,11 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             TS_STAT(1, 1);
             // sgl = sigma*log2(e) - log2(opacity), so alpha = exp2(-sgl)
             const float sgl = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.x - fpx[k % NBX], r0.y - fpy[k / NBX]);
+            if (TS_ABLATE == 8) {          // timing experiment: the exponent's nine instructions once more per body (result unused)
+                float dup = sigma_l2(r0.z, r0.w, r1.x, neg_lo, r0.y - fpx[k % NBX], r0.x - fpy[k / NBX]);
+                dup = __builtin_amdgcn_exp2f(-dup);
+                asm volatile("" ::"v"(dup));
+            }
             // Every decision below is ONE compare feeding ONE select, with no scalar mask arithmetic in between:
             // a v_cmp -> s_and / s_xor -> v_cndmask chain costs a wave 36 cycles and a select on a vcc that the
             // scalar unit wrote 19 (tools/micro/lat_bench.hip), a compare -> select pair 11.

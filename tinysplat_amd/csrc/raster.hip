@@ -612,10 +612,54 @@ __device__ __forceinline__ float fwd_update(float ae, float& T, int& fidx, int i
 #endif
 }
 
+// FINISHED PIXELS AS A SCALAR MASK (round 6, TS_FWD_ALIVE).  With instructions priced per class a
+// forward body is 56 pipe cycles of which the three compare -> select decisions are 21: alpha >= 1/255, the stop test
+// with its TWO selects (vis, T), and "was it composited" for fidx.  A pixel stops ONCE in its life, and "finished" was
+// kept in the sign of T, which every body had to restore.  Now a block's unfinished pixels are a 64-bit mask in SGPRs:
+//   m1 = ballot(alpha >= 1/255) & alive            (scalar and)          ae = m1 ? alpha : 0
+//   nT = T - ae T,  d = T - nT  (= vis: 0 wherever ae = 0),   go = ballot(!(nT <= kTEps))
+//   common case, no pixel of the block stops in this body:  acc += colour * d;  fidx = m1 ? idx : fidx;  T = nT
+// - no select for vis or T, no compare for fidx (m1 is the answer): 46 cycles.  A body in which a pixel stops (wave-uniform
+// scalar branch) applies the selects and clears the pixel's alive bit.  Same operations on the same operands for every
+// pixel that is still alive, no update of the others: image, final_Ts, final_index bit for bit.
+// MEASURED (round 6, profiles/r06h_fwd_alive_mask.txt): bit for bit, and NO gain - raster_fwd 298 / 302 us against 295 / 300
+// (config 3), 311 against 307 (RGB + depth), 628 against 619 (config 5): the 8 pipe cycles a body loses are paid back by
+// two more scalar instructions and a v_cmp -> s_and -> select dependency in every body's chain.  Off; kept as a knob.
+#ifndef TS_FWD_ALIVE
+#define TS_FWD_ALIVE 0
+#endif
+template <int CH, bool LOC>
+__device__ __forceinline__ void fwd_update_alive(float a, mask64 m1, float& T, mask64& alive, int& fidx, int idx,
+                                                 float (&acc)[CH], const float (&col)[CH], float (&loc)[CH]) {
+#pragma clang fp contract(off)
+    float ae;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ae) : "v"(a), "s"(m1));
+    float nT = __builtin_fmaf(-ae, T, T);
+    float d = T - nT;
+    const mask64 go = TS_BALLOT(!(nT <= ts::kTEps));
+    if (__builtin_expect(~go != 0ull, 0)) {
+        // a pixel of this block stops here (once per pixel): d, nT and m1 are corrected IN PLACE (asm with "+v": the
+        // common path below must not be re-emitted with its values in fresh registers and copied at the join)
+        asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(d) : "s"(go));
+        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(nT) : "v"(T), "s"(go));
+        m1 &= go;
+        alive &= go;
+    }
+    asm volatile("" : "+v"(d), "+v"(nT), "+s"(m1));
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = __builtin_fmaf(col[c], d, acc[c]);
+    if (LOC) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) loc[c] = __builtin_fmaf(col[c], d, loc[c]);
+    }
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(fidx) : "v"(idx), "s"(m1));
+    T = nT;
+}
+
 template <int CH, bool GENERAL, int NBX, class Loc>
 __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cnt, const float (&fpx)[NBX],
                                           const float (&fpy)[2], float (&T)[2 * NBX], int (&fidx)[2 * NBX],
-                                          float (&acc)[2 * NBX][CH], Loc& loc TS_SEG_PARAM) {
+                                          float (&acc)[2 * NBX][CH], Loc& loc, mask64 (&alive)[2 * NBX] TS_SEG_PARAM) {
 #pragma clang fp contract(off)          // as in bwd_chunk: both instantiations must round alike
     constexpr bool LOC = Loc::on;
     TS_WORK(0, cnt);
@@ -650,6 +694,19 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ lds, int cn
             // a v_cmp -> s_and / s_xor -> v_cndmask chain costs a wave 36 cycles and a select on a vcc that the
             // scalar unit wrote 19 (tools/micro/lat_bench.hip), a compare -> select pair 11.
             float vis;
+            if constexpr (TS_FWD_ALIVE && !Loc::on) {
+                // (segment sums - Loc - keep the sign form: the cut tiles of a hybrid launch are a sixth of the frame)
+                const float a = __builtin_amdgcn_exp2f(-sgl);
+                mask64 m1 = TS_BALLOT(a >= ts::kAlphaMin) & alive[k];
+                float ag = a;
+                if (GENERAL) {
+                    ag = fminf(ts::kAlphaMax, a);
+                    m1 &= TS_BALLOT(sgl >= neg_lo);                   // sigma >= 0
+                }
+                float no_loc_[CH];
+                fwd_update_alive<CH, false>(ag, m1, T[k], alive[k], fidx[k], idx, acc[k], col, no_loc_);
+                continue;
+            }
             if (TS_FWD_ASM && !GENERAL) {
                 vis = fwd_alpha_update(sgl, T[k], fidx[k], idx, acc[k][0], acc[k][1], acc[k][2], col[0], col[1], col[2]);
             } else {
@@ -1124,6 +1181,7 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
 
     // T > 0: transmittance of an unfinished pixel; T < 0: finished or outside, final value |T|
     float T[NB], acc[NB][CH];
+    mask64 alive[NB];
     int fidx[NB];
     bool inside[NB];
     int live = 0;                                   // blocks that still have unfinished pixels
@@ -1131,6 +1189,7 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
     for (int k = 0; k < NB; ++k) {
         inside[k] = (px0 + 8 * (k % NBX) < W) && (py0 + 8 * (k / NBX) < H) && (!SPLIT || k == only);
         T[k] = inside[k] ? 1.0f : -1.0f;
+        alive[k] = TS_BALLOT(inside[k]);              // (TS_FWD_ALIVE: the unfinished pixels of block k)
         fidx[k] = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[k][c] = 0.0f;
@@ -1271,7 +1330,7 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
             // Gaussians, so late in the list most (Gaussian, block) pairs are culled here
             bool sel[NB];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) sel[k] = T[k] > 0.0f;
+            for (int k = 0; k < NB; ++k) sel[k] = (TS_FWD_ALIVE && !LOCP) ? TS_LANE(alive[k]) : T[k] > 0.0f;
             live = update_rects<NBX>(sel, X0, Y0, rects, lane);
             TS_WAVE_SYNC();
             if (live == 0) break;
@@ -1297,9 +1356,9 @@ __global__ __launch_bounds__(kThreads, (NBX == 2 && !SPLIT) ? (CH == 3 ? TS_FWD_
         // once per chunk so that the common case runs a loop without those tests
         TS_SEG_ADD(ts_wave_clock_.seg, 0, tseg_p);
         if (general)
-            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_ TS_SEG_ARG);
+            fwd_chunk<CH, true, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_, alive TS_SEG_ARG);
         else
-            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_ TS_SEG_ARG);
+            fwd_chunk<CH, false, NBX>(lds, cnt, fpx, fpy, T, fidx, acc, loc_, alive TS_SEG_ARG);
         TS_WAVE_SYNC();
     }
     };

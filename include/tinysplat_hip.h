@@ -230,9 +230,9 @@ int ts_sort_tiles(int32_t num_tiles, const int32_t* tile_bins, const float* dept
 int ts_sort_tiles_above(int32_t num_tiles, const int32_t* tile_bins, const float* depths,
                         const int32_t* bucket_ids, int32_t* gaussian_ids_sorted, int32_t* sort_ws,
                         int32_t* zeroed_counter, void* stream);
-/* zeroed_counter: NULL, or a device word known to be zero that the sort may use as its counter of oversized
- * tiles (it is left non-zero).  ts_tile_offsets zeroes the LAST word of its workspace,
- * bin_ws[ts_bin_ws_ints(n, num_tiles) - 1], for this purpose: passing it saves a 4-byte memset launch. */
+/* sort_ws, zeroed_counter: DEPRECATED and ignored (pass NULL) - every tile has its own workgroup now, there is
+ * no queue of oversized tiles.  ts_sort_tiles still uses them (its zeroed_counter: NULL, or a device word
+ * known to be zero; ts_tile_offsets zeroes bin_ws[ts_bin_ws_ints(n, num_tiles) - 1] for this purpose). */
 
 #define TS_RASTER_LOGIT_OPACITY 1 /* `opacity` holds logits: sigmoid (rasterize.py:86) is applied while */
                                   /* packing, and ts_reduce_partials returns the gradient w.r.t. logits */

@@ -179,6 +179,8 @@ struct GatherTable {
     int width[TS_GATHER_MAX_TENSORS];       // floats per row
 };
 
+struct __attribute__((packed, aligned(4))) Unaligned4 { float x, y, z, w; };
+
 // dst[r, :] = r < copy_rows ? src[src_of[r], :] : 0     (one thread per float, rows are 4..180 bytes)
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(GatherTable t, int dst_rows,
                                                                int copy_rows,
@@ -188,20 +190,47 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(GatherTable t, in
     float* __restrict__ dst = t.dst[blockIdx.y];
     const long long total = (long long)dst_rows * w;
     const long long stride = (long long)gridDim.x * kThreads;
-    auto fetch = [&](long long e) -> float {
-        const int r = (int)(e / w);
-        const int c = (int)(e - (long long)r * w);
-        return r < copy_rows ? src[(long long)src_of[r] * w + c] : 0.0f;
+    // element e -> (row, column): one double multiply and a +-1 fix-up instead of a 64-bit division per
+    // float (the division was most of this kernel's instructions), then the columns of a unit are walked
+    const double inv_w = 1.0 / (double)w;
+    auto split = [&](long long e, int& r, int& c) {
+        r = (int)((double)e * inv_w);
+        long long cc = e - (long long)r * w;
+        if (cc < 0) { --r; cc += w; } else if (cc >= w) { ++r; cc -= w; }
+        c = (int)cc;
+    };
+    auto row_base = [&](int r) -> long long {
+        return r < copy_rows ? (long long)src_of[r] * w : -1;
     };
     // four consecutive output floats per lane: one 16-byte store (the tensors are 16-byte aligned and
     // the unit starts at a multiple of four floats), four 4-byte gathers that mostly share a source row
     const long long units = total >> 2;
     for (long long u = (long long)blockIdx.x * kThreads + threadIdx.x; u < units; u += stride) {
-        const long long e = u << 2;
-        reinterpret_cast<float4*>(dst)[u] = make_float4(fetch(e), fetch(e + 1), fetch(e + 2), fetch(e + 3));
+        int r, c;
+        split(u << 2, r, c);
+        long long base = row_base(r);
+        if (c + 4 <= w) {
+            // the unit lies inside one source row (42 of 45 units of an SH row, every quaternion):
+            // one 16-byte load at 4-byte alignment
+            Unaligned4 q = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (base >= 0) q = *reinterpret_cast<const Unaligned4*>(src + base + c);
+            reinterpret_cast<float4*>(dst)[u] = make_float4(q.x, q.y, q.z, q.w);
+            continue;
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = base >= 0 ? src[base + c] : 0.0f;
+            if (++c == w) { c = 0; ++r; if (k < 3) base = row_base(r); }
+        }
+        reinterpret_cast<float4*>(dst)[u] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    for (long long e = (units << 2) + (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride)
-        dst[e] = fetch(e);
+    for (long long e = (units << 2) + (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride) {
+        int r, c;
+        split(e, r, c);
+        const long long base = row_base(r);
+        dst[e] = base >= 0 ? src[base + c] : 0.0f;
+    }
 }
 
 // means / scales of the 2S sampled rows (GaussianDistribution.sample, :547-557; utils.py:41-73)

@@ -67,6 +67,21 @@ def main():
            "wall_ms": round(ms, 3), "kernel_ms": round(kern, 3), "alg_GB": round(alg / 1e9, 3),
            "GBps_kernels": round(alg / kern / 1e6, 1), "frac_of_8TBps": round(alg / kern / 1e6 / 8000, 3),
            "entries_ms": {k.replace("ts_", ""): round(c * m, 4) for k, (c, m) in per.items()}}
+    # yardstick: what a straight device-to-device copy of one gather's bytes reaches on this box
+    # (read + write counted, like alg): the gathers cannot beat it
+    src = torch.empty(row * n2 // 4, device=dev)
+    dst = torch.empty_like(src)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(3):
+        dst.copy_(src)
+    ev[0].record()
+    for _ in range(10):
+        dst.copy_(src)
+    ev[1].record()
+    torch.cuda.synchronize()
+    out["copy_yardstick_GBps"] = round(2 * src.numel() * 4 * 10 / ev[0].elapsed_time(ev[1]) / 1e6, 1)
+    gather_bytes = row * (n2 + n2) + 2 * row * (K + n2) + 3 * 4 * n2
+    out["gather_GBps"] = round(gather_bytes / per["ts_gather_rows"][0] / per["ts_gather_rows"][1] / 1e6, 1)
     if "--cpu" in sys.argv:
         from oracle import densify_oracle as D       # baseline leg only
         torch.set_num_threads(min(16, torch.get_num_threads()))

@@ -103,6 +103,53 @@ def probe(seed):
         print(f"  2-D {k:8s} f32 oracle {share(a32, b)}  worst rel {rel(a32):.2e} | HIP ops {share(ah, b)} worst rel {rel(ah):.2e}"
               f"   |ref|inf {float(b.abs().max()):.3g}")
     print(f"  xys.grad frame path: {share(extras['xys'].grad, f['xys'].grad)}", flush=True)
+    # The compositing stage ALONE: the HIP 2-D tensors as leaves on both sides (oracle: float64 compositing), weights
+    # zero wherever either set of 2-D tensors leaves a discrete decision within the margin
+    from oracle import gsplat_oracle as O            # checker
+    leaf = lambda t: t.detach().cpu().clone().requires_grad_(True)
+    x2, d2, c2, col2 = leaf(xys), leaf(depths), leaf(conics), leaf(colors)
+    r_rgb, _, aux2 = O.rasterize_gaussians(*raster_args(ref, x2, d2, radii.cpu(), c2, nth.cpu(), col2, (w, h)),
+                                           return_aux=True, compute_dtype=torch.float64)
+    r_d, _ = O.rasterize_gaussians(*raster_args(ref, x2, d2, radii.cpu(), c2, nth.cpu(), d2[:, None].repeat(1, 3), (w, h)),
+                                   compute_dtype=torch.float64)
+    both = stable & (aux2["margin_f32"] > F.MARGIN)
+    w2, wd2 = w_rgb * both[..., None], w_d * both
+    ((torch.clamp(r_rgb, max=1.0) * w2).sum() + (r_d[:, :, 0] * wd2).sum()).backward()
+    x3, d3, c3, col3 = leaf(xys), leaf(depths), leaf(conics), leaf(colors)      # the all-float32 oracle on the same leaves
+    q_rgb, _ = O.rasterize_gaussians(*raster_args(ref, x3, d3, radii.cpu(), c3, nth.cpu(), col3, (w, h)))
+    q_d, _ = O.rasterize_gaussians(*raster_args(ref, x3, d3, radii.cpu(), c3, nth.cpu(), d3[:, None].repeat(1, 3), (w, h)))
+    ((torch.clamp(q_rgb, max=1.0) * w2).sum() + (q_d[:, :, 0] * wd2).sum()).backward()
+    f32_leaf = {"xys": x3, "depths": d3, "conics": c3, "colors": col3}
+    # float64 compositing of the conics AS THE KERNELS HOLD THEM: hA = fl(fl(0.5 log2 e) A), B' = fl(fl(log2 e) B), hC
+    # likewise (raster.hip stage_splat) - one rounding per coefficient, the same for every pixel of the Gaussian
+    k32 = torch.tensor(1.4426950408889634, dtype=torch.float32)
+    cq = conics.detach().cpu()
+    held = torch.stack([((0.5 * k32) * cq[:, 0]).double() / (0.5 * k32).double(),
+                        (k32 * cq[:, 1]).double() / k32.double(),
+                        ((0.5 * k32) * cq[:, 2]).double() / (0.5 * k32).double()], dim=1)
+    x4, d4, col4 = leaf(xys), leaf(depths), leaf(colors)
+    c4 = held.clone().requires_grad_(True)
+    p_rgb, _ = O.rasterize_gaussians(*raster_args(ref, x4, d4, radii.cpu(), c4, nth.cpu(), col4, (w, h)), compute_dtype=torch.float64)
+    p_d, _ = O.rasterize_gaussians(*raster_args(ref, x4, d4, radii.cpu(), c4, nth.cpu(), d4[:, None].repeat(1, 3), (w, h)),
+                                   compute_dtype=torch.float64)
+    ((torch.clamp(p_rgb, max=1.0) * w2).sum() + (p_d[:, :, 0] * wd2).sum()).backward()
+    held_leaf = {"xys": x4, "depths": d4, "conics": c4, "colors": col4}
+    gl = lambda t: t.detach().clone().requires_grad_(True)
+    xg, dg, cg, colg = gl(xys), gl(depths), gl(conics), gl(colors)
+    h_rgb, _ = ops.rasterize_gaussians(*raster_args(mo, xg, dg, radii, cg, nth, colg, (w, h)))
+    h_d, _ = ops.rasterize_gaussians(*raster_args(mo, xg, dg, radii, cg, nth, dg[:, None].repeat(1, 3), (w, h)))
+    ((torch.clamp(h_rgb, max=1.0) * w2.to(DEV)).sum() + (h_d[:, :, 0] * wd2.to(DEV)).sum()).backward()
+    print(f"  compositing stage alone (HIP 2-D tensors as leaves; {int((stable & ~both).sum())} more pixels masked):")
+    for k, a, b in (("xys", xg, x2), ("depths", dg, d2), ("conics", cg, c2), ("colors", colg, col2)):
+        bb = b.grad
+        rel = float(((a.grad.cpu().double() - bb.double()).abs().max()) / max(1.0, float(bb.abs().max())))
+        rel32 = float(((f32_leaf[k].grad.double() - bb.double()).abs().max()) / max(1.0, float(bb.abs().max())))
+        print(f"    2-D {k:8s} HIP {share(a.grad, bb)}  max err / |ref|inf {rel:.2e} | float32 oracle {share(f32_leaf[k].grad, bb)} "
+              f"max err / |ref|inf {rel32:.2e}   |ref|inf {float(bb.abs().max()):.3g}", flush=True)
+        hb = held_leaf[k].grad
+        relh = float(((a.grad.cpu().double() - hb.double()).abs().max()) / max(1.0, float(hb.abs().max())))
+        print(f"        against float64 compositing of the conics as held (one rounding per coefficient): HIP {share(a.grad, hb)} "
+              f"max err / |ref|inf {relh:.2e}", flush=True)
 
 
 if __name__ == "__main__":

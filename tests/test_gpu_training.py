@@ -82,6 +82,30 @@ def test_planes_loss_is_the_frame_loss_bit_for_bit(h, w, with_depth):
         assert dep.grad is None or torch.all(dep.grad == 0)
 
 
+@pytest.mark.parametrize("h,w", [(11, 11), (11, 75), (12, 11), (55, 139), (57, 74), (99, 75), (100, 203)])
+def test_frame_loss_on_sizes_around_the_sliding_windows_edges(h, w):
+    """The sliding-window SSIM pass (64 map columns x 44 map rows per wave, 10 halo columns / rows): one map pixel, one
+    more column than a wave's main part, exactly 64 map columns (W = 74), one map row more than two segments - the
+    loss, its three parts and the gradient of all four channels against autograd of the oracle in float64."""
+    g = torch.Generator().manual_seed(7 * h + w)
+    frame = torch.rand(h, w, 4, generator=g)
+    frame[:, :, 3] = 2.0 + 8.0 * frame[:, :, 3]
+    tgt = (frame[:, :, :3] + 0.2 * torch.randn(h, w, 3, generator=g)).clamp(0, 1)
+    dtgt = 2.0 + 8.0 * torch.rand(h, w, generator=g)
+    lam, lamd = 0.2, 0.3
+    x64 = frame.double().requires_grad_(True)
+    ref, ref_l1, ref_s = TO.photometric_loss(x64[:, :, :3], tgt.double(), lam)
+    ref_d = (x64[:, :, 3] - dtgt.double()).abs().mean()
+    (ref + lamd * ref_d).backward()
+    xd = frame.to(DEV).requires_grad_(True)
+    loss, l1, s, ld = frame_loss(xd * 1.0, tgt.to(DEV), dtgt.to(DEV), lam, lamd)
+    loss.backward()
+    assert abs(loss.item() - (ref + lamd * ref_d).item()) < 3e-6
+    assert abs(l1.item() - ref_l1.item()) < 2e-6 and abs(s.item() - ref_s.item()) < 2e-6 and abs(ld.item() - ref_d.item()) < 2e-6
+    err = (xd.grad.cpu().double() - x64.grad).abs().max().item()
+    assert err < 2e-8 + 1e-4 * x64.grad.abs().max().item(), err
+
+
 def test_ssim_of_identical_images_is_one():
     img = torch.rand(50, 70, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
     loss, l1, s = photometric_loss(img, img.clone(), 0.2)

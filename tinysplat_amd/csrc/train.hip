@@ -24,17 +24,14 @@ constexpr int kPatch = kTile + kHalo;          // 42
 constexpr int kThreads = 256;
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
+// pytorch_msssim._fspecial_gauss_1d(11, 1.5) as torch evaluates it in float32 (exp(-(i-5)^2 / 4.5), normalised by the
+// float32 sum): the eleven values the reference's SSIM module holds, as literals
+#define TS_GAUSS_WINDOW 0x1.0d957p-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c3ep-3f, 0x1.10656p-2f, \
+                        0x1.b43c3ep-3f, 0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f, 0x1.0d957p-10f
 __device__ __forceinline__ void gauss_window(float* g) {
-    // exp(-(i-5)^2 / (2 * 1.5^2)), normalised (pytorch_msssim._fspecial_gauss_1d(11, 1.5))
-    float s = 0.0f;
+    constexpr float w[kWin] = {TS_GAUSS_WINDOW};
 #pragma unroll
-    for (int i = 0; i < kWin; ++i) {
-        const float d = (float)(i - kWin / 2);
-        g[i] = expf(-(d * d) / (2.0f * 1.5f * 1.5f));
-        s += g[i];
-    }
-#pragma unroll
-    for (int i = 0; i < kWin; ++i) g[i] /= s;
+    for (int i = 0; i < kWin; ++i) g[i] = w[i];
 }
 
 constexpr int kStrip = 4;   // outputs per thread and pass: inputs are read from LDS once per strip
@@ -205,6 +202,187 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
     }
 }
 
+// Pass 1 as a SLIDING WINDOW (round 6; the tiled kernel above stays for -DTS_SSIM_ROWS=0).  One wave owns 64 columns
+// of the SSIM map for one colour channel and walks kSeg map rows from the top: a pixel row is read once (64 + 10
+// columns, the next rows already in flight), filtered horizontally through a wave-private LDS line - no workgroup
+// barrier anywhere - and the eleven most recent horizontally filtered rows of the five maps stay in REGISTERS (a ring,
+// the row loop unrolled by the window length so that every index is static), so the vertical pass costs no memory
+// traffic at all.  Image bytes read 1.16 x (columns) x (kSeg + 10) / kSeg (rows) instead of 1.72 x, a third of the
+// LDS traffic and none of the nine barriers of the tiled kernel, which ran at 1.8 TB/s of its own traffic (95 us at
+// 1920 x 1080: three workgroups per CU, 2.7 rounds).  The three channel waves of a column block share a workgroup (and
+// so the L1 lines of the interleaved pixels); its fourth wave sums the depth term.  sums: {ssim, l1, depth l1} per wave at
+// sums[3 * ((seg * column_blocks + block) * 4 + wave)]; every pixel's L1 term is counted by exactly one wave.
+#ifndef TS_SSIM_ROWS
+#define TS_SSIM_ROWS 1
+#endif
+constexpr int kCols = 64;              // map columns per wave
+constexpr int kSeg = 44;               // map rows per wave (1080p: 25 x 30 workgroups = 750 <= the 768 that are resident at once)
+constexpr int kLine = kCols + 16;      // LDS line: 74 pixels used
+constexpr int kRowsWaves = 4;          // waves per workgroup: three channels and the depth term
+
+#define TS_TRAIN_WAVE_SYNC()                                      \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct RowRegs { float xm, xe, ym, ye; };              // one pixel row of a wave: main / extra columns of X and Y
+
+__global__ __launch_bounds__(64 * kRowsWaves) void ssim_fwd_rows_kernel(int H, int W, int xs,
+                                                                         const float* __restrict__ X,
+                                                                         const float* __restrict__ Xd,
+                                                                         const float* __restrict__ Y,
+                                                                         const float* __restrict__ D,
+                                                                         float* __restrict__ dmaps,
+                                                                         float* __restrict__ sums) {
+    __shared__ float line[3][2][2][kLine];                     // [channel wave][parity][X | Y][column]
+    constexpr float g[kWin] = {TS_GAUSS_WINDOW};
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int Ho = H - kHalo, Wo = W - kHalo;
+    const int x0 = blockIdx.x * kCols, o0 = blockIdx.y * kSeg;
+    const int rows = min(kSeg, Ho - o0);                       // map rows of this wave (>= 1)
+    const bool last_block = blockIdx.x == gridDim.x - 1, last_seg = blockIdx.y == gridDim.y - 1;
+    const int xa = x0 + lane, xb = x0 + kCols + lane;
+    const bool in_a = xa < W, in_b = lane < kHalo && xb < W;
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kRowsWaves + c;
+    if (c == 3) {
+        // the fourth wave: the depth L1 of the pixels this workgroup owns (its own rows and main columns; the last
+        // segment / column block also takes the ten trailing rows / columns nobody else starts at)
+        float depth_sum = 0.0f;
+        if (D) {
+            // branch-free loads, eleven rows in flight: one row per round trip made this wave the slowest of the
+            // workgroup (a 44-row chain of dependent memory latencies)
+            const int own_rows = last_seg ? rows + kHalo : rows;
+            const int xa_d = min(xa, W - 1), xb_d = min(xb, W - 1);
+            const float* const da = xs == 4 ? X + (size_t)xa_d * 4 + 3 : Xd + xa_d;
+            const float* const db = xs == 4 ? X + (size_t)xb_d * 4 + 3 : Xd + xb_d;
+            const size_t stride = xs == 4 ? (size_t)W * 4 : (size_t)W;
+            const bool use_b = last_block && in_b;
+            for (int t0 = 0; t0 < own_rows; t0 += kWin) {
+                float va[kWin], vb[kWin], ta[kWin], tb[kWin];
+#pragma unroll
+                for (int i = 0; i < kWin; ++i) {
+                    const size_t y = (size_t)(o0 + min(t0 + i, own_rows - 1));
+                    va[i] = da[y * stride]; vb[i] = db[y * stride];
+                    ta[i] = D[y * W + xa_d]; tb[i] = D[y * W + xb_d];
+                }
+#pragma unroll
+                for (int i = 0; i < kWin; ++i) {
+                    if (t0 + i < own_rows) {
+                        depth_sum += in_a ? fabsf(va[i] - ta[i]) : 0.0f;
+                        depth_sum += use_b ? fabsf(vb[i] - tb[i]) : 0.0f;
+                    }
+                }
+            }
+        }
+        depth_sum = wave_sum(depth_sum);
+        if (lane == 0) { sums[3 * slot] = 0.0f; sums[3 * slot + 1] = 0.0f; sums[3 * slot + 2] = depth_sum; }
+        return;
+    }
+    float ssim_sum = 0.0f, l1_sum = 0.0f;
+    // branch-free loads (columns beyond the image read the last pixel of the row and are zeroed): a load inside a
+    // divergent branch makes the compiler wait for ALL outstanding memory operations before the next use, which
+    // serialises the rows in flight
+    const int xa_c = min(xa, W - 1), xb_c = min(xb, W - 1);
+    // the lane's part of every address once; a row adds a wave-uniform offset
+    const float* const xa_p = X + (size_t)xa_c * xs + c;
+    const float* const xb_p = X + (size_t)xb_c * xs + c;
+    const float* const ya_p = Y + (size_t)xa_c * 3 + c;
+    const float* const yb_p = Y + (size_t)xb_c * 3 + c;
+    float* const dmap_lane = dmaps + (size_t)c * Ho * Wo + min(xa, Wo - 1);
+    auto fetch = [&](int y) -> RowRegs {
+        const size_t rx = (size_t)y * W * xs, ry = (size_t)y * W * 3;
+        RowRegs r;
+        r.xm = xa_p[rx]; r.ym = ya_p[ry];
+        r.xe = xb_p[rx]; r.ye = yb_p[ry];
+        return r;                                              // (zeroed where they are consumed: a select here would wait for the load)
+    };
+
+    const int total = rows + kHalo;                            // pixel rows o0 .. o0 + total - 1 (all < H)
+    // Rows are fetched kBatch at a time into registers with STATIC indices (the row loop is unrolled by kRing = 12, one
+    // slot more than the window needs; 12 = 2 kBatch: two batches, one being filtered and one in flight).  On gfx9-class
+    // targets loads and stores share one counter and may complete out of order, so with the map stores of earlier rows
+    // in flight the compiler waits for EVERYTHING before the first use of a loaded register - a `cur = next` copy or a
+    // three-row ring end in s_waitcnt vmcnt(0) per row (111 us), one batch without look-ahead in a full round trip per
+    // batch (61 us).  So the NEXT batch is issued right after the first row of the current one has been consumed: the one
+    // wait per batch then finds loads that were issued a whole batch earlier.
+    constexpr int kBatch = 6, kRing = kWin + 1;
+    static_assert(kRing == 2 * kBatch, "two batches per unrolled body");
+    RowRegs rb[2 * kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) rb[i] = fetch(o0 + min(i, total - 1));
+    float ring[5][kRing];
+    const size_t plane = (size_t)Ho * Wo * 3;
+    for (int base = 0; base < total; base += kRing) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) {
+            const int t = base + s;
+            if (t >= total) continue;                          // wave-uniform (no break: the unrolled body keeps static ring indices)
+            const int y = o0 + t;
+            const RowRegs cur = rb[s];
+            // this wave's share of the L1 sums: its own rows and main columns; the last segment / column block also
+            // takes the ten trailing rows / columns nobody else starts at
+            const float xm = in_a ? cur.xm : 0.0f, ym = in_a ? cur.ym : 0.0f;
+            const float xe = in_b ? cur.xe : 0.0f, ye = in_b ? cur.ye : 0.0f;
+            if (t < rows || last_seg) l1_sum += fabsf(xm - ym) + (last_block ? fabsf(xe - ye) : 0.0f);
+            float* lx = line[c][t & 1][0];
+            float* ly = line[c][t & 1][1];
+            lx[lane] = xm; ly[lane] = ym;
+            if (lane < 16) { lx[kCols + lane] = xe; ly[kCols + lane] = ye; }
+            if (s % kBatch == 0 && t + kBatch < total) {       // the batch after this one, into the other half of rb
+#pragma unroll
+                for (int i = 0; i < kBatch; ++i) rb[(s + kBatch + i) % kRing] = fetch(o0 + min(t + kBatch + i, total - 1));
+            }
+            TS_TRAIN_WAVE_SYNC();
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float a = lx[lane + k], b = ly[lane + k];
+                const float wa = g[k] * a, wb = g[k] * b;
+                h0 += wa; h1 += wb;
+                h2 = __builtin_fmaf(wa, a, h2); h3 = __builtin_fmaf(wb, b, h3); h4 = __builtin_fmaf(wa, b, h4);
+            }
+            ring[0][s] = h0; ring[1][s] = h1; ring[2][s] = h2; ring[3][s] = h3; ring[4][s] = h4;
+            if (t >= kHalo) {
+                // map row o = y - 10: the rows y - 10 .. y sit in ring slots (s + 2 + k) % 12
+                float f[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < kWin; ++k) v = __builtin_fmaf(g[k], ring[m][(s + 2 + k) % kRing], v);
+                    f[m] = v;
+                }
+                if (xa < Wo) {
+                    const float m1 = f[0], m2 = f[1], q1 = f[2], q2 = f[3], r12 = f[4];
+                    const float s1 = q1 - m1 * m1, s2 = q2 - m2 * m2, s12 = r12 - m1 * m2;
+                    const float A1 = 2.0f * m1 * m2 + kC1, A2 = 2.0f * s12 + kC2;
+                    const float B1 = m1 * m1 + m2 * m2 + kC1, B2 = s1 + s2 + kC2;
+                    // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each): the maps
+                    // move by ~1e-7 relative, the loss by < 1e-7
+                    const float i1 = __builtin_amdgcn_rcpf(B1), i2 = __builtin_amdgcn_rcpf(B2);
+                    const float inv = i1 * i2;
+                    const float S = A1 * A2 * inv;
+                    ssim_sum += S;
+                    float* o = dmap_lane + (size_t)(y - kHalo) * Wo;              // planar per channel: coalesced in x
+                    o[0] = 2.0f * m2 * (A2 - A1) * inv - 2.0f * m1 * S * (i1 - i2);   // d/d filt(X)
+                    o[plane] = -S * i2;                                               // d/d filt(X^2)
+                    o[2 * plane] = 2.0f * A1 * inv;                                   // d/d filt(XY)
+                }
+            }
+        }
+    }
+    const float ts = wave_sum(ssim_sum), tl = wave_sum(l1_sum);
+    if (lane == 0) { sums[3 * slot] = ts; sums[3 * slot + 1] = tl; sums[3 * slot + 2] = 0.0f; }
+}
+
 // Pass 2: gradient w.r.t. X.  The transpose of the valid filter is a full correlation of the three
 // partial maps (zero outside the (Ho, Wo) map):  gX = F^T dm + 2 X F^T dq + Y F^T dr, scaled by
 // w_ssim, plus w_l1 * sign(X - Y).
@@ -350,9 +528,27 @@ extern "C" {
 int64_t ts_photometric_ws_floats(int32_t height, int32_t width) {
     if (height <= kHalo || width <= kHalo) return 0;
     const int64_t ho = height - kHalo, wo = width - kHalo;
-    const int64_t tiles = (int64_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    const int64_t tiles = TS_SSIM_ROWS ? kRowsWaves * ((wo + kCols - 1) / kCols) * ((ho + kSeg - 1) / kSeg)      // one triple per wave
+                                       : (int64_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
     return 3 * ho * wo * 3 + 3 * tiles;
 }
+
+namespace {
+// pass 1 of the loss: per-wave (per-tile) sums behind the three partial-derivative maps in ws
+void launch_ssim_fwd(int height, int width, int xs, const float* image, const float* depth, const float* target,
+                     const float* depth_target, float* ws, hipStream_t s) {
+    const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
+    if (TS_SSIM_ROWS) {
+        const dim3 grid((width - kHalo + kCols - 1) / kCols, (height - kHalo + kSeg - 1) / kSeg);
+        hipLaunchKernelGGL(ssim_fwd_rows_kernel, grid, dim3(64 * kRowsWaves), 0, s, height, width, xs, image, depth,
+                           target, depth_target, ws, ws + plane3);
+    } else {
+        const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);
+        hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, xs, image, depth, target,
+                           depth_target, ws, ws + plane3);
+    }
+}
+}  // namespace
 
 int ts_photometric_loss_rgbd(int32_t height, int32_t width, int32_t pixel_floats, const float* image,
                              const float* target, const float* depth_target, float w_l1,
@@ -364,8 +560,7 @@ int ts_photometric_loss_rgbd(int32_t height, int32_t width, int32_t pixel_floats
     const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);
     const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, (int)pixel_floats,
-                       image, (const float*)nullptr, target, depth_target, ws, ws + plane3);
+    launch_ssim_fwd(height, width, (int)pixel_floats, image, nullptr, target, depth_target, ws, s);
     if (v_image)
         hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width,
                            (int)pixel_floats, image, (const float*)nullptr, target, depth_target, ws, w_l1, w_ssim,
@@ -381,8 +576,7 @@ int ts_photometric_loss_planes(int32_t height, int32_t width, const float* image
     const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);
     const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kThreads), 0, s, height, width, 3, image, depth, target,
-                       depth_target, ws, ws + plane3);
+    launch_ssim_fwd(height, width, 3, image, depth, target, depth_target, ws, s);
     if (v_image)
         hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width, 3, image, depth, target,
                            depth_target, ws, w_l1, w_ssim, w_depth, v_image, v_depth);

@@ -9,8 +9,10 @@
 //   * Adam update of the six parameter tensors (torch.optim.Adam defaults, train.py:26) in ONE
 //     launch over a table of tensors with per-tensor learning rates (model_gaussian.py:112-120).
 //
-// Both are HBM-bound streaming kernels; the SSIM kernels stage a (32+10) x (32+10) pixel patch in
-// LDS and run the two 11-tap passes from there, so each image byte is read from HBM ~1.7x.
+// SSIM pass 1 (the five filtered maps, the SSIM sum, three partial-derivative maps) is a sliding window: one wave per
+// 64 map columns and channel, the filtered rows in a register ring (ssim_fwd_rows_kernel; the tiled kernel of rounds
+// 1 - 5 stays behind -DTS_SSIM_ROWS=0).  Pass 2 (the image gradient) stages a (32+10) x (32+10) patch of the maps in
+// LDS and runs the two 11-tap passes from there, so each map byte is read from HBM ~1.7x.  Adam streams at HBM rate.
 #include <hip/hip_runtime.h>
 
 #include "../../include/tinysplat_hip.h"

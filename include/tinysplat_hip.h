@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 7
+#define TS_ABI_VERSION 8
 
 #define TS_E_BADARG (-1)  /* null pointer / negative size / unsupported channel count */
 #define TS_E_DEGREE (-2)  /* SH degree out of range or exceeds stored coefficients */
@@ -528,8 +528,8 @@ int ts_shard_rank_bwd_b(const ts_frame* fo, const ts_rank_step* r, void* stream)
  * (2 floats per 32x32 tile: SSIM-map sum, |X-Y| sum) and, if v_image != NULL,
  *   v_image = w_l1 * sign(X - Y) + w_ssim * dSSIMsum/dX      (caller passes w_l1 = c_l1 / (3 H W),
  *                                                             w_ssim = -c_ssim / (3 (H-10)(W-10))).
- * ws: >= ts_photometric_ws_floats(H, W) floats; the partial sums ({ssim, l1, -} per 32x32 tile)
- * start at ws + 9 (H-10)(W-10). */
+ * ws: >= ts_photometric_ws_floats(H, W) floats; the partial sums ({ssim, l1, depth l1} per wave of pass 1; any
+ * number of triples: (ts_photometric_ws_floats - 9 (H-10)(W-10)) / 3) start at ws + 9 (H-10)(W-10). */
 int64_t ts_photometric_ws_floats(int32_t height, int32_t width);
 /* Same loss on the compositing kernels' own output: `image` has pixel_floats (3 or 4) floats per
  * pixel; with 4, channel 3 is the rendered depth and, when depth_target[H,W] != NULL, the depth L1 of
@@ -547,6 +547,12 @@ int ts_photometric_loss(int32_t height, int32_t width, const float* image, const
 int ts_photometric_loss_planes(int32_t height, int32_t width, const float* image, const float* depth,
                                const float* target, const float* depth_target, float w_l1, float w_ssim,
                                float w_depth, float* ws, float* v_image, float* v_depth, void* stream);
+/* ABI 8: the loss VALUE from the partial sums an entry above left in `ws` (same height, width and weights):
+ *   out4 = {loss, mean|X - Y|, SSIM, mean|depth - depth_target|}   (device floats; sums taken in double, fixed order)
+ * with loss = (1 - lambda) * out4[1] + lambda * (1 - out4[2]) + lambda_depth * out4[3] as the weights encode it
+ * (train.py:58-69).  One small launch instead of a dozen one-element tensor operations on the caller's side. */
+int ts_photometric_loss_reduce(int32_t height, int32_t width, float w_l1, float w_ssim, float w_depth,
+                               const float* ws, float* out4, void* stream);
 
 /* torch.optim.Adam (defaults: no amsgrad, no weight decay; train.py:26) on up to TS_ADAM_MAX_TENSORS
  * tensors with per-tensor learning rates (model_gaussian.py:112-120) in one launch.  The pointer

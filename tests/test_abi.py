@@ -36,7 +36,7 @@ def test_binding_covers_the_header_and_version_matches():
     from tinysplat_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.ts_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.ts_abi_version() == _lib.ABI_VERSION == 8
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
     # list segments (ts_camera.hints bits 8..11) and the whole-tile share of a hybrid launch (bits 12..15): floats
     # behind final_Ts = T_fin + one checkpoint block of S records of (1+channels) 256 floats per cut tile

@@ -14,7 +14,7 @@ from pathlib import Path
 # compile-time switches in a process of their own); a variant build needs TS_ALLOW_VARIANT_LIB=1 as usual
 LIB_PATH = Path(os.environ["TS_LIB_PATH"]) if os.environ.get("TS_LIB_PATH") else \
     Path(__file__).resolve().parent / "csrc" / "libtinysplat_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 HINT_BALANCED_WALK = 1           # ts_camera.hints: TS_HINT_BALANCED_WALK
 HINT_COOP_SPLIT = 1 << 20        # ts_camera.hints: TS_HINT_COOP_SPLIT
 PARTIAL_ROW_FLOATS = 12          # TS_PARTIAL_ROW_FLOATS: floats per (tile, Gaussian) gradient row slot
@@ -131,6 +131,7 @@ SIGNATURES = {
     "ts_photometric_loss_rgbd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),
     "ts_photometric_loss_planes": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P,
                                              _P]),
+    "ts_photometric_loss_reduce": (c_int32, [c_int32, c_int32, c_float, c_float, c_float, _P, _P, _P]),
     "ts_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
     "ts_sh_colors_bwd_adam": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _ADAM, _P]),
     "ts_project_bwd_adam": (c_int32, [c_int32, _P, _P, _P, _P, _P, _CAM, c_int32, _P, _P, _P, _P, _P, _P, _ADAM, _P]),

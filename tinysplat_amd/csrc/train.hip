@@ -521,6 +521,37 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(const AdamTable t, float
     }
 }
 
+// The loss value from the partial sums of pass 1 (ABI 8): {loss, mean|X - Y|, SSIM, mean|depth - D|} as four floats,
+// summed in double in a fixed order by one workgroup.  Replaces a dozen one-element PyTorch launches per training step
+// (reduce, three divisions, the weighted sum, four casts) that sat between the loss kernels and the frame's backward.
+__global__ __launch_bounds__(kThreads) void loss_reduce_kernel(int H, int W, int triples, float w_l1, float w_ssim,
+                                                               float w_depth, const float* __restrict__ sums,
+                                                               float* __restrict__ out) {
+    __shared__ double part[3][kThreads];
+    double a = 0.0, b = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < triples; i += kThreads) {
+        a += (double)sums[3 * i]; b += (double)sums[3 * i + 1]; d += (double)sums[3 * i + 2];
+    }
+    part[0][threadIdx.x] = a; part[1][threadIdx.x] = b; part[2][threadIdx.x] = d;
+    __syncthreads();
+    for (int step = kThreads / 2; step >= 1; step >>= 1) {
+        if ((int)threadIdx.x < step)
+            for (int k = 0; k < 3; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n_map = 3.0 * (double)(H - kHalo) * (double)(W - kHalo), n_img = 3.0 * (double)H * (double)W;
+        // the caller's gradient scales carry the weights: w_l1 = (1 - lambda) / (3 H W), w_ssim = -lambda / (3 Ho Wo),
+        // w_depth = lambda_depth / (H W)
+        const double lambda = -(double)w_ssim * n_map;
+        const double loss = (double)w_l1 * part[1][0] + lambda + (double)w_ssim * part[0][0] + (double)w_depth * part[2][0];
+        out[0] = (float)loss;
+        out[1] = (float)(part[1][0] / n_img);
+        out[2] = (float)(part[0][0] / n_map);
+        out[3] = (float)(part[2][0] / ((double)H * (double)W));
+    }
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -582,6 +613,16 @@ int ts_photometric_loss_planes(int32_t height, int32_t width, const float* image
     if (v_image)
         hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kThreads), 0, s, height, width, 3, image, depth, target,
                            depth_target, ws, w_l1, w_ssim, w_depth, v_image, v_depth);
+    return launch_status();
+}
+
+int ts_photometric_loss_reduce(int32_t height, int32_t width, float w_l1, float w_ssim, float w_depth,
+                               const float* ws, float* out4, void* stream) {
+    if (height <= kHalo || width <= kHalo || !ws || !out4) return TS_E_BADARG;
+    const int64_t maps = (int64_t)9 * (height - kHalo) * (width - kHalo);
+    const int64_t triples = (ts_photometric_ws_floats(height, width) - maps) / 3;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, height, width, (int)triples,
+                       w_l1, w_ssim, w_depth, ws + maps, out4);
     return launch_status();
 }
 

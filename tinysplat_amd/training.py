@@ -25,6 +25,15 @@ DEFAULT_LRS = {"means": 0.00016, "colors_dc": 0.0025, "colors_rest": 0.000125, "
 PARAM_ORDER = ("means", "colors_dc", "colors_rest", "scales", "quats", "opacities")
 
 
+def _loss_values(lib, h, w, w_l1, w_ssim, w_depth, ws, dev) -> Tensor:
+    """{loss, l1, ssim, depth l1} as ONE four-float device tensor from the partial sums in ``ws`` (ABI 8: one launch
+    instead of a dozen one-element tensor operations between the loss kernels and the frame's backward pass)."""
+    out = torch.empty((4,), dtype=torch.float32, device=dev)
+    _call("ts_photometric_loss_reduce", lib.ts_photometric_loss_reduce, h, w, w_l1, w_ssim, w_depth, _ptr(ws), _ptr(out),
+          _stream(dev))
+    return out
+
+
 class _PhotometricLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, target, lambda_dssim):
@@ -41,16 +50,13 @@ class _PhotometricLoss(torch.autograd.Function):
         ho, wo = h - 10, w - 10
         lam = float(lambda_dssim)
         with torch.cuda.device(dev):
+            w_l1, w_ssim = (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo)
             _call("ts_photometric_loss", lib.ts_photometric_loss, h, w, _ptr(image), _ptr(target),
-                  (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo), _ptr(ws), _ptr(v_image),
-                  _stream(dev))
-        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
-        ssim = sums[0] / (3.0 * ho * wo)
-        l1 = sums[1] / (3.0 * h * w)
-        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim)).to(torch.float32)
+                  w_l1, w_ssim, _ptr(ws), _ptr(v_image), _stream(dev))
+            loss, l1, ssim, _ = _loss_values(lib, h, w, w_l1, w_ssim, 0.0, ws, dev).unbind(0)
         ctx.save_for_backward(v_image)
         ctx.mark_non_differentiable(l1, ssim)
-        return loss, l1.to(torch.float32), ssim.to(torch.float32)
+        return loss, l1, ssim
 
     @staticmethod
     def backward(ctx, v_loss, _v_l1, _v_ssim):
@@ -79,18 +85,13 @@ class _FrameLoss(torch.autograd.Function):
         ho, wo = h - 10, w - 10
         lam, lamd = float(lambda_dssim), float(lambda_depth) if dt is not None else 0.0
         with torch.cuda.device(dev):
+            w_l1, w_ssim, w_depth = (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo), lamd / (h * w)
             _call("ts_photometric_loss_rgbd", lib.ts_photometric_loss_rgbd, h, w, 4, _ptr(frame),
-                  _ptr(target), _ptr(dt), (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo),
-                  lamd / (h * w), _ptr(ws), _ptr(v_frame), _stream(dev))
-        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
-        ssim = sums[0] / (3.0 * ho * wo)
-        l1 = sums[1] / (3.0 * h * w)
-        ldepth = sums[2] / (h * w)
-        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim) + lamd * ldepth).to(torch.float32)
+                  _ptr(target), _ptr(dt), w_l1, w_ssim, w_depth, _ptr(ws), _ptr(v_frame), _stream(dev))
+            loss, l1, ssim, ldepth = _loss_values(lib, h, w, w_l1, w_ssim, w_depth, ws, dev).unbind(0)
         ctx.save_for_backward(v_frame)
-        outs = (l1.to(torch.float32), ssim.to(torch.float32), ldepth.to(torch.float32))
-        ctx.mark_non_differentiable(*outs)
-        return (loss,) + outs
+        ctx.mark_non_differentiable(l1, ssim, ldepth)
+        return loss, l1, ssim, ldepth
 
     @staticmethod
     def backward(ctx, v_loss, *_):
@@ -98,42 +99,48 @@ class _FrameLoss(torch.autograd.Function):
         return (None if v_frame is None else v_frame * v_loss), None, None, None, None   # out of place: retain_graph re-runs this (train.py:71)
 
 
+def planes_loss_and_gradient(rgb: Tensor, depth: Tensor, target: Tensor, depth_target: Optional[Tensor],
+                             lambda_dssim: float, lambda_depth: float, want_rgb: bool = True, want_depth: bool = True):
+    """train.py:58-69 on the adapter's two outputs as it hands them out (rgb[H,W,3] and depth[H,W], both contiguous:
+    frame.render_frame_planes) in one pair of launches, WITHOUT autograd: -> (values[4] = {loss, l1, ssim, depth l1},
+    dloss/drgb or None, dloss/ddepth or None).  ``TrainStep`` hands the two gradients straight to
+    ``torch.autograd.backward`` - no loss node, no ``grad * 1.0`` passes over 33 MB."""
+    dev = _need_hip(rgb, depth, target)
+    if rgb.dim() != 3 or rgb.shape[2] != 3 or not rgb.is_contiguous() or not depth.is_contiguous():
+        raise ValueError("rgb must be a contiguous [H, W, 3] tensor and depth a contiguous [H, W] one")
+    h, w = rgb.shape[0], rgb.shape[1]
+    if depth.shape != (h, w) or target.shape != (h, w, 3) or (depth_target is not None and depth_target.shape != (h, w)):
+        raise ValueError("depth must be [H, W], target [H, W, 3] and depth_target [H, W]")
+    if h <= 10 or w <= 10:
+        raise ValueError("SSIM with an 11-tap window needs H, W > 10")
+    rgb, depth, target = _f32c(rgb.detach()), _f32c(depth.detach()), _f32c(target)
+    dt = None if depth_target is None else _f32c(depth_target)
+    lib = _lib.load()
+    ws = torch.empty((int(lib.ts_photometric_ws_floats(h, w)),), dtype=torch.float32, device=dev)
+    v_rgb = torch.empty_like(rgb) if want_rgb else None
+    v_depth = torch.empty_like(depth) if (v_rgb is not None and want_depth and dt is not None) else None
+    ho, wo = h - 10, w - 10
+    lam, lamd = float(lambda_dssim), float(lambda_depth) if dt is not None else 0.0
+    w_l1, w_ssim, w_depth = (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo), lamd / (h * w)
+    with torch.cuda.device(dev):
+        _call("ts_photometric_loss_rgbd", lib.ts_photometric_loss_planes, h, w, _ptr(rgb), _ptr(depth),
+              _ptr(target), _ptr(dt), w_l1, w_ssim, w_depth, _ptr(ws), _ptr(v_rgb), _ptr(v_depth), _stream(dev))
+        values = _loss_values(lib, h, w, w_l1, w_ssim, w_depth, ws, dev)
+    return values, v_rgb, v_depth
+
+
 class _PlanesLoss(torch.autograd.Function):
-    """train.py:58-69 on the adapter's two outputs as it hands them out (rgb[H,W,3] and depth[H,W], both
-    contiguous: frame.render_frame_planes) in one pair of launches; the gradient comes back as two planes too."""
+    """``planes_loss_and_gradient`` as a differentiable function of rgb and depth."""
 
     @staticmethod
     def forward(ctx, rgb, depth, target, depth_target, lambda_dssim, lambda_depth):
-        dev = _need_hip(rgb, depth, target)
-        if rgb.dim() != 3 or rgb.shape[2] != 3 or not rgb.is_contiguous() or not depth.is_contiguous():
-            raise ValueError("rgb must be a contiguous [H, W, 3] tensor and depth a contiguous [H, W] one")
-        h, w = rgb.shape[0], rgb.shape[1]
-        if depth.shape != (h, w) or target.shape != (h, w, 3) or (depth_target is not None and depth_target.shape != (h, w)):
-            raise ValueError("depth must be [H, W], target [H, W, 3] and depth_target [H, W]")
-        if h <= 10 or w <= 10:
-            raise ValueError("SSIM with an 11-tap window needs H, W > 10")
-        rgb, depth, target = _f32c(rgb), _f32c(depth), _f32c(target)
-        dt = None if depth_target is None else _f32c(depth_target)
-        lib = _lib.load()
-        ws = torch.empty((int(lib.ts_photometric_ws_floats(h, w)),), dtype=torch.float32, device=dev)
-        v_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
-        v_depth = torch.empty_like(depth) if (v_rgb is not None and ctx.needs_input_grad[1] and dt is not None) else None
-        ho, wo = h - 10, w - 10
-        lam, lamd = float(lambda_dssim), float(lambda_depth) if dt is not None else 0.0
-        with torch.cuda.device(dev):
-            _call("ts_photometric_loss_rgbd", lib.ts_photometric_loss_planes, h, w, _ptr(rgb), _ptr(depth),
-                  _ptr(target), _ptr(dt), (1.0 - lam) / (3.0 * h * w), -lam / (3.0 * ho * wo),
-                  lamd / (h * w), _ptr(ws), _ptr(v_rgb), _ptr(v_depth), _stream(dev))
-        sums = ws[9 * ho * wo:].view(-1, 3).sum(dim=0, dtype=torch.float64)
-        ssim = sums[0] / (3.0 * ho * wo)
-        l1 = sums[1] / (3.0 * h * w)
-        ldepth = sums[2] / (h * w)
-        loss = ((1.0 - lam) * l1 + lam * (1.0 - ssim) + lamd * ldepth).to(torch.float32)
+        values, v_rgb, v_depth = planes_loss_and_gradient(rgb, depth, target, depth_target, lambda_dssim, lambda_depth,
+                                                          ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        loss, l1, ssim, ldepth = values.unbind(0)
         ctx.has_depth = v_depth is not None
         ctx.save_for_backward(*(t for t in (v_rgb, v_depth) if t is not None))
-        outs = (l1.to(torch.float32), ssim.to(torch.float32), ldepth.to(torch.float32))
-        ctx.mark_non_differentiable(*outs)
-        return (loss,) + outs
+        ctx.mark_non_differentiable(l1, ssim, ldepth)
+        return loss, l1, ssim, ldepth
 
     @staticmethod
     def backward(ctx, v_loss, *_):
@@ -281,12 +288,15 @@ class TrainStep:
         rgb, extras = self.scene.render(camera)
         frame = getattr(rgb, "_base", None)
         depth = extras["depth"]
+        direct = None
         if (rgb.dim() == 3 and rgb.shape[2] == 3 and rgb.is_contiguous() and rgb.is_cuda and depth.is_contiguous()
                 and depth.shape == rgb.shape[:2] and frame is None):
             # the adapter's one-node path hands out two contiguous images: the whole loss (train.py:58-69) on
             # them in one pair of launches, gradients back as two planes
-            loss, l1, ssim, _ = planes_loss(rgb, depth, target_rgb, target_depth, self.lambda_dssim,
-                                            self.lambda_depth)
+            values, v_rgb, v_depth = planes_loss_and_gradient(rgb, depth, target_rgb, target_depth, self.lambda_dssim,
+                                                              self.lambda_depth)
+            loss, l1, ssim, _ = values.unbind(0)
+            direct = ([rgb] + ([depth] if v_depth is not None else []), [v_rgb] + ([v_depth] if v_depth is not None else []))
         elif (frame is not None and frame.dim() == 3 and frame.shape[2] == 4 and frame.is_contiguous()
                 and extras["depth"]._base is frame):
             # the adapter's one-node path hands out views of ONE [H, W, 4] tensor: evaluate the
@@ -297,14 +307,16 @@ class TrainStep:
             loss, l1, ssim = photometric_loss(rgb, target_rgb, self.lambda_dssim)
             if target_depth is not None:                          # train.py:65-69
                 loss = loss + self.lambda_depth * (extras["depth"] - target_depth).abs().mean()
+        # `direct`: the loss launches already produced dloss / d(rgb, depth) - they go straight into the frame's backward
+        run_backward = (lambda: torch.autograd.backward(*direct)) if direct is not None else loss.backward
         if self.fused_adam:
             from .frame import fused_adam
             with fused_adam(self.optimizer):
-                loss.backward()
+                run_backward()
             if not self.optimizer.consume_fused():          # a render path without the one-node frame: the two-launch step
                 self.optimizer.step()
         else:
-            loss.backward()
+            run_backward()
             self.optimizer.step()
         xys_grad = extras["xys"].grad                          # consumed by densification (F2)
         if densifier is not None:

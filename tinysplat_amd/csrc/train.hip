@@ -312,9 +312,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void ssim_fwd_rows_kernel(int H, i
     // slot more than the window needs; 12 = 2 kBatch: two batches, one being filtered and one in flight).  On gfx9-class
     // targets loads and stores share one counter and may complete out of order, so with the map stores of earlier rows
     // in flight the compiler waits for EVERYTHING before the first use of a loaded register - a `cur = next` copy or a
-    // three-row ring end in s_waitcnt vmcnt(0) per row (111 us), one batch without look-ahead in a full round trip per
-    // batch (61 us).  So the NEXT batch is issued right after the first row of the current one has been consumed: the one
-    // wait per batch then finds loads that were issued a whole batch earlier.
+    // three-row ring end in s_waitcnt vmcnt(0) per row (111 us).  With one wait per SIX rows the other waves of the SIMD
+    // cover it: one batch without look-ahead 61 us, the next batch issued right after the first row of the current one
+    // has been consumed (its wait then finds loads a whole batch old) 59 - 62 us - the launch is ~0.6 VALU-bound by then.
     constexpr int kBatch = 6, kRing = kWin + 1;
     static_assert(kRing == 2 * kBatch, "two batches per unrolled body");
     RowRegs rb[2 * kBatch];

@@ -98,7 +98,7 @@ ENTRYWISE_NUMEL = 1000   # ... asserted on tensors with at least this many entri
 
 
 def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0, mask=None,
-               entrywise_min: float = ENTRYWISE_MIN, entrywise_scale: float = 1.0):
+               entrywise_min: float = ENTRYWISE_MIN, entrywise_scale: float = 1.0, entry_extra=None):
     """What is enforced, per tensor:
       * |ref|_inf <= 1: the north_star's literal bar, |got - ref| <= 1e-5 ABSOLUTE for every entry
         (whatever ``rel`` says; times ``entrywise_scale`` where a fuzz scene's measured conditioning set one);
@@ -128,7 +128,12 @@ def check_grad(what: str, got, ref, rel: float = 1e-5, max_bad_frac: float = 0.0
     within = (err <= ABS_BAR).double().mean().item() if err.numel() else 1.0
     # (entrywise_scale > 1: randomised scenes whose measured float32 conditioning allows more than the plain bar - the
     # entry-wise bar grows with the tolerance instead of being dropped, tools/fuzz_frame.py)
-    entrywise = (err <= entrywise_scale * ABS_BAR * ref.abs().clamp_min(1.0)).double().mean().item() if err.numel() else 1.0
+    # (entry_extra: an absolute allowance per entry on top of the entry-wise bar - the first-order propagation of float32
+    # rounding of the 2-D gradients through the projection VJP, measured on the oracle's graph: tools/fuzz_frame.py)
+    bar = entrywise_scale * ABS_BAR * ref.abs().clamp_min(1.0)
+    if entry_extra is not None:
+        bar = bar + entry_extra.detach().cpu().double()
+    entrywise = (err <= bar).double().mean().item() if err.numel() else 1.0
     import os
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     PARITY_LOG.append((test, what, worst, mag, tol, frac, within, entrywise))

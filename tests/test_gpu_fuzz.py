@@ -1,5 +1,5 @@
-"""Sixty-four cases of tools/fuzz_frame.py as tests (seeds 0 - 59: every case the tool had reported on before round 6; plus
-the four seeds of a 700-seed sweep - profiles/r06i_fuzz_* - that needed something said about them): randomised whole-frame
+"""Sixty-six cases of tools/fuzz_frame.py as tests (seeds 0 - 59: every case the tool had reported on before round 6; plus
+the six seeds of a 1000-seed sweep - profiles/r06i_fuzz_* - that needed something said about them): randomised whole-frame
 scenes (sizes down to one Gaussian and images smaller than a tile, SH degrees 0-3, footprints from sub-pixel to
 tile-covering, opaque / faint opacity laws, Gaussians behind the near plane, duplicated Gaussians with equal depths)
 on the HIP path against the oracle frame - radii exact, RGB 1e-5, depth 1e-5 max(1, |depth|) at stable pixels, every
@@ -22,8 +22,9 @@ pytestmark = pytest.mark.gpu
 #      (ENTRYWISE_SLACK);  400: a needle scene whose gradients stay below 1 - the absolute bar grows with the scene's measured
 #      conditioning like the relative one;  578: needles with exponent terms of 3e4 - the half-ulp rounding of the held conic
 #      (HELD_CONIC_ULPS);  595: one pixel that a 2e-4 difference between two float32 projections of a needle flips
-#      (conics_from: the two stages checked each on its own inputs)
-@pytest.mark.parametrize("seed", list(range(60)) + [119, 400, 578, 595])
+#      (conics_from: the two stages checked each on its own inputs);  734, 905 (of seeds 700 - 999): quaternion entries that are
+#      cancellations - the entry-wise bar carries the propagated float32 noise of the 2-D gradients (NOISE_ULPS)
+@pytest.mark.parametrize("seed", list(range(60)) + [119, 400, 578, 595, 734, 905])
 def test_random_frame_matches_oracle(seed):
     import fuzz_frame
     try:

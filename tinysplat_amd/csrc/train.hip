@@ -205,11 +205,11 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
 }
 
 // Pass 1 as a SLIDING WINDOW (round 6; the tiled kernel above stays for -DTS_SSIM_ROWS=0).  One wave owns 64 columns
-// of the SSIM map for one colour channel and walks kSeg map rows from the top: a pixel row is read once (64 + 10
+// of the SSIM map for one colour channel and walks `seg` map rows from the top: a pixel row is read once (64 + 10
 // columns, the next rows already in flight), filtered horizontally through a wave-private LDS line - no workgroup
 // barrier anywhere - and the eleven most recent horizontally filtered rows of the five maps stay in REGISTERS (a ring,
 // the row loop unrolled by the window length so that every index is static), so the vertical pass costs no memory
-// traffic at all.  Image bytes read 1.16 x (columns) x (kSeg + 10) / kSeg (rows) instead of 1.72 x, a third of the
+// traffic at all.  Image bytes read 1.16 x (columns) x (seg + 10) / seg (rows) instead of 1.72 x, a third of the
 // LDS traffic and none of the nine barriers of the tiled kernel, which ran at 1.8 TB/s of its own traffic (95 us at
 // 1920 x 1080: three workgroups per CU, 2.7 rounds).  The three channel waves of a column block share a workgroup (and
 // so the L1 lines of the interleaved pixels); its fourth wave sums the depth term.  sums: {ssim, l1, depth l1} per wave at
@@ -218,7 +218,26 @@ __global__ __launch_bounds__(kThreads) void ssim_fwd_kernel(int H, int W, int xs
 #define TS_SSIM_ROWS 1
 #endif
 constexpr int kCols = 64;              // map columns per wave
-constexpr int kSeg = 44;               // map rows per wave (1080p: 25 x 30 workgroups = 750 <= the 768 that are resident at once)
+// Map rows per wave, chosen per image so that the launch is ONE round of resident workgroups (three per CU at 140 - 168
+// VGPRs): 1080p on 256 CUs: 30 column blocks x 25 segments of 43 rows = 750 <= 768.  A small image gets short segments
+// (more waves, more halo rows each) instead of a handful of waves walking hundreds of rows one after the other.
+constexpr int kSegMin = 8, kSegMax = 64;
+inline int ssim_segment_rows(int ho, int wo) {
+    static int resident = 0;                                   // workgroups resident at once (per process: one device kind)
+    if (resident == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        resident = 3 * cus;
+    }
+    const int blocks_x = (wo + kCols - 1) / kCols;
+    const int segments = resident / blocks_x > 0 ? resident / blocks_x : 1;
+    const int seg = (ho + segments - 1) / segments;
+    return seg < kSegMin ? kSegMin : (seg > kSegMax ? kSegMax : seg);
+}
 constexpr int kLine = kCols + 16;      // LDS line: 74 pixels used
 constexpr int kRowsWaves = 4;          // waves per workgroup: three channels and the depth term
 
@@ -237,7 +256,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 struct RowRegs { float xm, xe, ym, ye; };              // one pixel row of a wave: main / extra columns of X and Y
 
-__global__ __launch_bounds__(64 * kRowsWaves) void ssim_fwd_rows_kernel(int H, int W, int xs,
+__global__ __launch_bounds__(64 * kRowsWaves) void ssim_fwd_rows_kernel(int H, int W, int xs, int seg,
                                                                          const float* __restrict__ X,
                                                                          const float* __restrict__ Xd,
                                                                          const float* __restrict__ Y,
@@ -248,8 +267,8 @@ __global__ __launch_bounds__(64 * kRowsWaves) void ssim_fwd_rows_kernel(int H, i
     constexpr float g[kWin] = {TS_GAUSS_WINDOW};
     const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
     const int Ho = H - kHalo, Wo = W - kHalo;
-    const int x0 = blockIdx.x * kCols, o0 = blockIdx.y * kSeg;
-    const int rows = min(kSeg, Ho - o0);                       // map rows of this wave (>= 1)
+    const int x0 = blockIdx.x * kCols, o0 = blockIdx.y * seg;
+    const int rows = min(seg, Ho - o0);                        // map rows of this wave (>= 1)
     const bool last_block = blockIdx.x == gridDim.x - 1, last_seg = blockIdx.y == gridDim.y - 1;
     const int xa = x0 + lane, xb = x0 + kCols + lane;
     const bool in_a = xa < W, in_b = lane < kHalo && xb < W;
@@ -561,7 +580,8 @@ extern "C" {
 int64_t ts_photometric_ws_floats(int32_t height, int32_t width) {
     if (height <= kHalo || width <= kHalo) return 0;
     const int64_t ho = height - kHalo, wo = width - kHalo;
-    const int64_t tiles = TS_SSIM_ROWS ? kRowsWaves * ((wo + kCols - 1) / kCols) * ((ho + kSeg - 1) / kSeg)      // one triple per wave
+    const int64_t seg = TS_SSIM_ROWS ? ssim_segment_rows((int)ho, (int)wo) : 1;
+    const int64_t tiles = TS_SSIM_ROWS ? kRowsWaves * ((wo + kCols - 1) / kCols) * ((ho + seg - 1) / seg)      // one triple per wave
                                        : (int64_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
     return 3 * ho * wo * 3 + 3 * tiles;
 }
@@ -572,8 +592,9 @@ void launch_ssim_fwd(int height, int width, int xs, const float* image, const fl
                      const float* depth_target, float* ws, hipStream_t s) {
     const size_t plane3 = (size_t)3 * (height - kHalo) * (width - kHalo) * 3;
     if (TS_SSIM_ROWS) {
-        const dim3 grid((width - kHalo + kCols - 1) / kCols, (height - kHalo + kSeg - 1) / kSeg);
-        hipLaunchKernelGGL(ssim_fwd_rows_kernel, grid, dim3(64 * kRowsWaves), 0, s, height, width, xs, image, depth,
+        const int seg = ssim_segment_rows(height - kHalo, width - kHalo);
+        const dim3 grid((width - kHalo + kCols - 1) / kCols, (height - kHalo + seg - 1) / seg);
+        hipLaunchKernelGGL(ssim_fwd_rows_kernel, grid, dim3(64 * kRowsWaves), 0, s, height, width, xs, seg, image, depth,
                            target, depth_target, ws, ws + plane3);
     } else {
         const dim3 grid((width + kTile - 1) / kTile, (height + kTile - 1) / kTile);

@@ -29,7 +29,9 @@ scenes: float32 accumulation of moments whose terms are ~1e5 times their sum), n
 needle scenes against the oracle run end to end in float64 (same conic values), allowing 4 x what the float32
 projection VJP loses on exact inputs (gsplat's formula -X G X with a near-singular conic; measured per case on the
 host).  Where only the entry-wise 99 % rule fails, the all-float32 oracle is asked the same question
-(ENTRYWISE_SLACK).  Seven hundred seeds: profiles/r06i_fuzz_*.
+(ENTRYWISE_SLACK), and the entry-wise bar of means / scales / quats carries the float32 noise of the 2-D gradients
+propagated through the oracle's projection backward (NOISE_ULPS; run_case).  A thousand seeds: profiles/r06i_fuzz_*,
+r06k_fuzz_*.
 
 usage: fuzz_frame.py [cases] [first_seed] [needle scenes only: 0 / 1]
 """
@@ -49,6 +51,7 @@ ENTRYWISE_FLOOR = 0.95   # share of the entries inside the (scaled) entry-wise b
 PROJECTION_SLACK = 4.0    # needle scenes: the kernels' conics vs the float64 projection, in units of the float32 oracle's own worst error
 HELD_CONIC_ULPS = 3.0     # systematic part of the float32 exponent bound: three held conic coefficients, one rounding each, each
                           # term of the exponent at most the largest one (see run_case)
+PROBES, NOISE_ULPS, NOISE_SIGMAS = 8, 4.0, 4.0   # entry-wise allowance from the 2-D gradients' float32 noise, see run_case
 ENTRYWISE_SLACK = 0.005  # how far behind the all-float32 oracle's share the HIP path's may be where BOTH miss the 99 %
 
 
@@ -218,7 +221,9 @@ def run_case(case):
     w_d = torch.rand(h, w, generator=g) * stable
     loss = (f["rgb"] * w_rgb).sum() + (f["depth"] * w_d).sum()
     if loss.requires_grad:                       # nothing visible: the oracle frame is a constant
-        loss.backward()
+        for k_ in ("conics", "depths"):
+            f[k_].retain_grad()
+        loss.backward(retain_graph=True)
     md = model.to(DEV).requires_grad_(True)
     rgb, extras = GaussianRasterizer(md, None, device=torch.device(DEV))(cam, (w, h), sh)
     ((rgb * w_rgb.to(DEV)).sum() + (extras["depth"] * w_d.to(DEV)).sum()).backward()
@@ -318,6 +323,33 @@ def run_case(case):
     # The entry-wise 99 % rule of helpers.check_grad is stated for the plain bar (1e-5 of the entry's own magnitude);
     # where the conditioning-derived tolerance is larger, the entry-wise bar grows in the same proportion
     # (allow / 2e-5) and the required share is ENTRYWISE_FLOOR - it is never switched off.
+    # What float32 rounding of the 2-D gradients is worth AFTER the projection VJP, entry by entry: a near-isotropic
+    # Gaussian's quaternion gradient (a tile-covering Gaussian's mean gradient) is a cancellation among terms a thousand
+    # times its size, so an error of a few ulps of the Gaussian's v_conic / v_xy - the compositing sums thousands of pixel
+    # terms in float32, in gsplat (atomicAdd) as here - is many times 1e-5 of such an ENTRY (seeds 52, 119, 734, 854,
+    # 905, 949: 1 - 3 % of the quats entries, the all-float32 oracle 0.7 - 2.5 %).  Measured on the oracle's own graph:
+    # independent noise of NOISE_ULPS eps32 x the Gaussian's largest |v_conic| (|v_xy|, |v_depth|) entry is pushed through
+    # the projection backward with random signs; its rms over PROBES draws, times NOISE_SIGMAS, joins the entry-wise bar
+    # of means / scales / quats.  The infinity-norm bound is untouched.
+    entry_extra = {}
+    if loss.requires_grad and f["xys"].grad is not None and f["conics"].grad is not None:
+        gen = torch.Generator().manual_seed(4000 + case["seed"])
+        u32 = 5.96e-8
+        amp = {"xys": f["xys"].grad.abs().max(dim=1, keepdim=True).values.expand_as(f["xys"]),
+               "conics": f["conics"].grad.abs().max(dim=1, keepdim=True).values.expand_as(f["conics"]),
+               "depths": f["depths"].grad.abs() if f["depths"].grad is not None else torch.zeros_like(f["depths"])}
+        acc = {nm_: torch.zeros_like(getattr(ref, nm_), dtype=torch.float64) for nm_ in ("means", "scales", "quats")}
+        for _ in range(PROBES):
+            outs, gouts = [], []
+            for k_ in ("xys", "conics", "depths"):
+                sign = torch.randint(0, 2, amp[k_].shape, generator=gen).to(amp[k_].dtype) * 2.0 - 1.0
+                outs.append(f[k_]); gouts.append(NOISE_ULPS * u32 * amp[k_] * sign)
+            got_ = torch.autograd.grad(outs, [ref.means, ref.scales, ref.quats], grad_outputs=gouts, retain_graph=True,
+                                       allow_unused=True)
+            for nm_, g_ in zip(("means", "scales", "quats"), got_):
+                if g_ is not None:
+                    acc[nm_] += g_.double() ** 2
+        entry_extra = {nm_: NOISE_SIGMAS * (a_ / PROBES).sqrt() for nm_, a_ in acc.items()}
     needs = {}
     f32_grads = None
     for nm in names:
@@ -332,7 +364,7 @@ def run_case(case):
 
         def check(at):
             check_grad(nm, a.grad, want, rel=at, entrywise_min=0.99 if at <= 2e-5 else ENTRYWISE_FLOOR,
-                       entrywise_scale=max(1.0, at / 2e-5))
+                       entrywise_scale=max(1.0, at / 2e-5), entry_extra=entry_extra.get(nm))
         def entry_rule_excuse(at, err):
             """Only the ENTRY-WISE rule failed at tolerance `at` (the infinity-norm bound holds).  Its reference runs the
             projection VJP in float32 autograd; on near-isotropic tile-covering Gaussians a quaternion gradient entry
@@ -354,6 +386,8 @@ def run_case(case):
             need = 0.99 if at <= 2e-5 else ENTRYWISE_FLOOR
             scale = max(1.0, at / 2e-5)
             bar = scale * 1e-5 * want.detach().double().abs().clamp_min(1.0)
+            if entry_extra.get(nm) is not None:
+                bar = bar + entry_extra[nm]
             share_hip = float(((a.grad.detach().cpu().double() - want.detach().double()).abs() <= bar).double().mean())
             share_f32 = float(((getattr(f32_grads, nm).grad.double() - want.detach().double()).abs() <= bar).double().mean())
             if share_f32 >= need or share_hip < share_f32 - ENTRYWISE_SLACK:

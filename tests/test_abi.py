@@ -38,6 +38,18 @@ def test_binding_covers_the_header_and_version_matches():
     lib = _lib.load()
     assert lib.ts_abi_version() == _lib.ABI_VERSION == 8
     assert lib.ts_scan_ws_ints(1) >= 1 and lib.ts_scan_ws_ints(10_000_000) >= 10_000_000 // 1024
+    # the loss workspace: three maps x three channels of (H-10)(W-10) floats, then one {ssim, l1, depth} triple per wave
+    # of the sliding-window pass - four waves per workgroup, 64 map columns x `seg` map rows each, seg in [8, 64] chosen so
+    # that the launch is one round of resident workgroups (three per CU; without a device the policy assumes 256 CUs)
+    for h, w in ((1080, 1920), (256, 256), (11, 11), (2160, 3840)):
+        maps = 9 * (h - 10) * (w - 10)
+        triples = (lib.ts_photometric_ws_floats(h, w) - maps) // 3
+        blocks_x = -(-(w - 10) // 64)
+        assert (lib.ts_photometric_ws_floats(h, w) - maps) % 3 == 0 and triples % (4 * blocks_x) == 0
+        segments = triples // (4 * blocks_x)
+        seg_lo, seg_hi = -(-(h - 10) // segments), (h - 10) if segments == 1 else -(-(h - 10) // (segments - 1)) - 1
+        assert 1 <= segments <= -(-(h - 10) // 8) and seg_lo <= 64 and (segments == 1 or seg_hi >= 8), (h, w, segments)
+    assert lib.ts_photometric_ws_floats(10, 100) == 0
     # list segments (ts_camera.hints bits 8..11) and the whole-tile share of a hybrid launch (bits 12..15): floats
     # behind final_Ts = T_fin + one checkpoint block of S records of (1+channels) 256 floats per cut tile
     from tinysplat_amd import frame
